@@ -1,0 +1,155 @@
+/*
+ * pvhip.h -- C ABI of libpvhip.so: the MI355X (gfx950) numeric back end that sits under the
+ * pyopenvino op-plugin boundary `compute(node, inputs, kernel_type, debug)`.
+ *
+ * The reference (yas-sim/pyopenvino) is pure Python and has no FFI of its own, so these entry points
+ * are what a binding for its per-layer hot path binds: one function per `kernel_<Op>_*` body of the
+ * reference plugins, plus device memory / stream / event plumbing and one RCCL gather.  Each
+ * declaration cites the reference function it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PVHIP_E* code otherwise; it never throws and
+ *     never synchronises the stream unless its comment says so; pvhip_last_error() returns a
+ *     human-readable description of the last failure on this thread.
+ *   - all tensor pointers are DEVICE pointers obtained from pvhip_malloc, contiguous, fp32 unless
+ *     noted; activations are NCHW, convolution weights OIHW, MatMul operands row-major 2-D.
+ *   - every kernel is enqueued on the library's single compute stream of the device selected by
+ *     pvhip_init (one host thread / process per GPU).
+ *   - sizes are element counts (not bytes) unless the name says bytes.
+ */
+#ifndef PVHIP_H
+#define PVHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVHIP_OK            0
+#define PVHIP_EHIP         -1   /* a HIP runtime call failed                                  */
+#define PVHIP_EINVAL       -2   /* argument rejected on the host (shape / attribute check)    */
+#define PVHIP_ENOTINIT     -3   /* pvhip_init has not been called                             */
+#define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
+#define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
+
+#define PVHIP_ABI_VERSION   1
+
+/* ---------------------------------------------------------------- runtime plumbing ---------- */
+/* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
+ * hands ndarray between plugins).  These give plugins a device-resident tensor to hand over instead. */
+int         pvhip_abi_version(void);
+const char* pvhip_last_error(void);
+int         pvhip_device_count(int* count);
+int         pvhip_init(int device);                     /* select device, create the compute stream  */
+int         pvhip_shutdown(void);                       /* free pool, destroy stream                 */
+int         pvhip_device_name(char* buf, size_t buflen);
+int         pvhip_malloc(void** ptr, size_t bytes);     /* pooled: freed blocks are reused by size   */
+int         pvhip_free(void* ptr);                      /* returns the block to the pool             */
+int         pvhip_pool_release(void);                   /* hipFree everything cached in the pool     */
+int         pvhip_pool_stats(size_t* bytes_in_use, size_t* bytes_cached);
+int         pvhip_memcpy_h2d(void* dst, const void* src, size_t bytes);  /* Parameter.py:11-13, Const.py:11-13 upload; async w.r.t. device, host buffer reusable on return */
+int         pvhip_memcpy_d2h(void* dst, const void* src, size_t bytes);  /* Result.py:17 read-back; SYNCHRONISES the stream */
+int         pvhip_memcpy_d2d(void* dst, const void* src, size_t bytes);
+int         pvhip_memset(void* dst, int byte, size_t bytes);
+int         pvhip_sync(void);                           /* hipStreamSynchronize on the compute stream */
+
+/* events on the compute stream: replace the per-node time.time() bracket of inference_engine.py:279-283 */
+int         pvhip_event_create(void** ev);
+int         pvhip_event_destroy(void* ev);
+int         pvhip_event_record(void* ev);
+int         pvhip_event_sync(void* ev);
+int         pvhip_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* hipGraph capture of one whole forward pass (run_tasks loop, inference_engine.py:259-292) */
+int         pvhip_graph_begin_capture(void);
+int         pvhip_graph_end_capture(void** graph_exec);
+int         pvhip_graph_launch(void* graph_exec);
+int         pvhip_graph_destroy(void* graph_exec);
+
+/* ---------------------------------------------------------------- streaming elementwise ----- */
+/* ReLU.py:9-12  kernel_ReLU_numpy: y = (x < 0) ? 0 : x   (NaN and -0.0 pass through)            */
+int pvhip_relu_f32(const float* x, float* y, size_t n);
+/* Clamp.py:9-12 kernel_Clamp_numpy: y = min(max(x, lo), hi), NaN propagates                     */
+int pvhip_clamp_f32(const float* x, float* y, size_t n, float lo, float hi);
+/* Sigmoid.py:10-13 kernel_Sigmoid_numpy: y = 1 / (1 + exp(-x))                                  */
+int pvhip_sigmoid_f32(const float* x, float* y, size_t n);
+
+/* Add.py:9-14 kernel_Add_numpy / Multiply.py:9-17 kernel_Multiply_numpy.
+ * out = a (op) b with numpy broadcasting already resolved by the caller into element strides:
+ * `shape` is the output shape (rank <= PVHIP_MAX_RANK), a_strides/b_strides are element strides of
+ * the operands viewed at the output shape (0 on broadcast axes).  The library picks a float4
+ * streaming kernel for the common cases (same shape; per-channel (1,C,1,1); trailing-row (1,F);
+ * scalar) and a generic strided kernel otherwise.                                               */
+#define PVHIP_MAX_RANK 6
+int pvhip_add_f32(const float* a, const float* b, float* out, int rank,
+                  const int64_t* shape, const int64_t* a_strides, const int64_t* b_strides);
+int pvhip_mul_f32(const float* a, const float* b, float* out, int rank,
+                  const int64_t* shape, const int64_t* a_strides, const int64_t* b_strides);
+
+/* ---------------------------------------------------------------- pooling / normalisation --- */
+/* MaxPool.py:41-72 kernel_MaxPool_numpy: max over the kh x kw window of the ZERO-padded input
+ * (pad cells take part with value 0), window clipped at the padded extent.  (oh, ow) are computed
+ * by the caller with the rule of MaxPool.py:10-38.                                               */
+int pvhip_maxpool2d_f32(const float* x, float* y, int n, int c, int h, int w, int oh, int ow,
+                        int kh, int kw, int sh, int sw, int pad_top, int pad_left,
+                        int pad_bottom, int pad_right);
+/* AvgPool.py:41-59 kernel_AvgPool_numpy: mean of x[y*sh : min(h-1, y*sh+kh), x*sw : min(w-1, x*sw+kw)]
+ * -- no padding, window clipped at h-1 / w-1 (reference behaviour, kept).  An empty window yields NaN. */
+int pvhip_avgpool2d_f32(const float* x, float* y, int n, int c, int h, int w, int oh, int ow,
+                        int kh, int kw, int sh, int sw);
+/* SoftMax.py:10-14 kernel_SoftMax_numpy applied per row: y[r,:] = exp(x[r,:]) / sum(exp(x[r,:])),
+ * no max subtraction (identical to the reference at batch 1; rows are independent images).      */
+int pvhip_softmax_rows_f32(const float* x, float* y, int rows, int cols);
+/* LRN.py:10-22 kernel_LRN_numpy: y = x / (bias + alpha * sum_{c' in [c-size/2, c+size/2]} x^2)^beta,
+ * window clipped to [0, C); alpha is NOT divided by size.  hw = H*W.                             */
+int pvhip_lrn_f32(const float* x, float* y, int n, int c, int hw, int size,
+                  float alpha, float beta, float bias);
+
+/* ---------------------------------------------------------------- data movement ------------- */
+/* Concat.py:9-13 kernel_Concat_numpy: srcs[i] is viewed as [outer][inner[i]] and copied to
+ * dst[outer][sum(inner)] at its running offset.  srcs / inner are HOST arrays of n_src entries.  */
+#define PVHIP_MAX_CONCAT 16
+int pvhip_concat_f32(int n_src, const float* const* srcs, const int64_t* inner, float* dst, int64_t outer);
+/* Transpose.py:9-13 kernel_Transpose_numpy, materialised: y = x.transpose(perm), y contiguous.   */
+int pvhip_transpose_f32(const float* x, float* y, int rank, const int64_t* in_shape, const int64_t* perm);
+
+/* ---------------------------------------------------------------- MFMA kernels -------------- */
+/* MatMul.py:9-17 kernel_MatMul_numpy: C[M,N] = op(A) . op(B); A is stored [M,K] (or [K,M] when
+ * trans_a), B is stored [K,N] (or [N,K] when trans_b); fp32 MFMA (v_mfma_f32_32x32x2_f32).        */
+int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int k,
+                     int trans_a, int trans_b);
+
+/* Convolution.py:57-87 im2col + kernel_Convolution_im2col ("special"), as an implicit GEMM:
+ *   y[n,k,oy,ox] = sum_{c,r,s} xpad[n,c,oy*sh+r,ox*sw+s] * w[k,c,r,s]      (dilation ignored, as :72-87 does)
+ * Step 1 (once per weight tensor): repack OIHW weights to the K-major panel the kernel streams.
+ *   wpack must hold pvhip_conv2d_pack_elems(k_out, c, kh, kw) floats.
+ * Step 2: the convolution proper.  (oh, ow) computed by the caller per Convolution.py:21-49.
+ *   bias (optional, may be NULL): per-output-channel value added in the epilogue; relu != 0 applies
+ *   the ReLU.py:11 rule in the epilogue (used only by the fused Convolution->Add->ReLU path).     */
+size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
+                        int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
+                        int sh, int sw, int pad_top, int pad_left,
+                        const float* bias, int relu);
+
+/* GroupConvolution.py:53-79 kernel_GroupConvolution_numpy, depthwise case only (weights
+ * [G,1,1,kh,kw], one input and one output channel per group), applied to every image.           */
+int pvhip_dwconv2d_f32(const float* x, const float* w, float* y, int n, int g, int h, int wdt,
+                       int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left);
+
+/* ---------------------------------------------------------------- multi-GPU gather ---------- */
+/* No reference counterpart (the reference is single-process).  Batch shards are independent; the only
+ * exchange is an all-gather of the Result tensor over RCCL/xGMI.  unique_id is a 128-byte buffer. */
+#define PVHIP_UNIQUE_ID_BYTES 128
+int pvhip_comm_unique_id(void* unique_id_out);
+int pvhip_comm_init(const void* unique_id, int rank, int world);
+int pvhip_comm_allgather_f32(const float* send, float* recv, size_t count_per_rank);
+int pvhip_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVHIP_H */

@@ -1,0 +1,16 @@
+# ORACLE -- test infrastructure only.  MaxPool: CPU restatement of reference op_plugins/MaxPool.py:111-135.
+import numpy as np
+
+from .. import ops
+from ._util import DTYPES, check, ints, out_port
+
+
+def name():
+    print('MaxPool')
+
+
+def compute(node: dict, inputs: dict = None, kernel_type: str = 'special', debug: bool = False):
+    check(node, inputs)
+    a = node['data']
+    res = ops.maxpool(inputs[0], ints(a['strides']), ints(a['pads_begin']), ints(a['pads_end']), ints(a['kernel']), a['rounding_type'], a['auto_pad'])
+    return {out_port(node): res}

@@ -1,0 +1,292 @@
+// libpvhip runtime plumbing: device selection, one compute stream, a size-bucketed device-memory
+// pool (the scheduler keeps every activation alive between infer() calls and re-produces the same
+// shapes every call, so exact-size reuse makes steady-state allocation free), copies, events and
+// hipGraph capture of a whole forward pass.
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "pvhip_common.h"
+
+namespace pvhip {
+
+State& state() {
+    static State s;
+    return s;
+}
+
+static thread_local char g_err[512] = "no error";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+struct Pool {
+    std::mutex                                  mu;
+    std::unordered_map<void*, size_t>           live;    // ptr -> rounded bytes
+    std::map<size_t, std::vector<void*>>        cached;  // rounded bytes -> free blocks
+    size_t                                      bytes_live = 0, bytes_cached = 0;
+};
+Pool& pool() {
+    static Pool p;
+    return p;
+}
+inline size_t round_up(size_t b) {
+    const size_t q = 512;
+    return b == 0 ? q : (b + q - 1) / q * q;
+}
+}  // namespace
+}  // namespace pvhip
+
+using namespace pvhip;
+
+extern "C" {
+
+int pvhip_abi_version(void) { return PVHIP_ABI_VERSION; }
+
+const char* pvhip_last_error(void) { return g_err; }
+
+int pvhip_device_count(int* count) {
+    PVHIP_CHECK_ARG(count != nullptr);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(PVHIP_EHIP, "hipGetDeviceCount -> %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return PVHIP_OK;
+}
+
+int pvhip_init(int device) {
+    State& s = state();
+    if (s.ready) {
+        if (s.device == device) return PVHIP_OK;
+        return fail(PVHIP_EINVAL, "pvhip_init: already initialised on device %d", s.device);
+    }
+    int n = 0;
+    PVHIP_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n)
+        return fail(PVHIP_EINVAL, "pvhip_init: device %d out of range (%d visible)", device, n);
+    PVHIP_HIP(hipSetDevice(device));
+    PVHIP_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    s.device = device;
+    s.ready  = true;
+    return PVHIP_OK;
+}
+
+int pvhip_pool_release(void) {
+    PVHIP_REQUIRE_INIT();
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    PVHIP_HIP(hipStreamSynchronize(state().stream));
+    for (auto& kv : p.cached)
+        for (void* ptr : kv.second) (void)hipFree(ptr);
+    p.cached.clear();
+    p.bytes_cached = 0;
+    return PVHIP_OK;
+}
+
+int pvhip_shutdown(void) {
+    State& s = state();
+    if (!s.ready) return PVHIP_OK;
+    (void)pvhip_comm_destroy();
+    (void)pvhip_pool_release();
+    {
+        Pool& p = pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        for (auto& kv : p.live) (void)hipFree(kv.first);
+        p.live.clear();
+        p.bytes_live = 0;
+    }
+    (void)hipStreamDestroy(s.stream);
+    s.stream = nullptr;
+    s.ready  = false;
+    s.device = -1;
+    return PVHIP_OK;
+}
+
+int pvhip_device_name(char* buf, size_t buflen) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(buf != nullptr && buflen > 0);
+    hipDeviceProp_t prop;
+    PVHIP_HIP(hipGetDeviceProperties(&prop, state().device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return PVHIP_OK;
+}
+
+int pvhip_malloc(void** ptr, size_t bytes) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(ptr != nullptr);
+    const size_t rb = round_up(bytes);
+    Pool&        p  = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    auto it = p.cached.find(rb);
+    if (it != p.cached.end() && !it->second.empty()) {
+        *ptr = it->second.back();
+        it->second.pop_back();
+        p.bytes_cached -= rb;
+    } else {
+        void*      d = nullptr;
+        hipError_t e = hipMalloc(&d, rb);
+        if (e != hipSuccess) {
+            // one retry after dropping the cache
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(state().stream);
+            for (auto& kv : p.cached)
+                for (void* c : kv.second) (void)hipFree(c);
+            p.cached.clear();
+            p.bytes_cached = 0;
+            e = hipMalloc(&d, rb);
+            if (e != hipSuccess)
+                return fail(PVHIP_EHIP, "pvhip_malloc(%zu bytes) -> %s", rb, hipGetErrorString(e));
+        }
+        *ptr = d;
+    }
+    p.live[*ptr] = rb;
+    p.bytes_live += rb;
+    return PVHIP_OK;
+}
+
+int pvhip_free(void* ptr) {
+    if (ptr == nullptr) return PVHIP_OK;
+    if (!state().ready) return PVHIP_OK;  // process teardown: memory already released
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    auto it = p.live.find(ptr);
+    if (it == p.live.end()) return fail(PVHIP_EINVAL, "pvhip_free: %p is not a live pvhip block", ptr);
+    const size_t rb = it->second;
+    p.live.erase(it);
+    p.bytes_live -= rb;
+    // Stream-ordered reuse: every consumer of this block was enqueued on the single compute
+    // stream before the free, and the next owner's work is enqueued after it.
+    p.cached[rb].push_back(ptr);
+    p.bytes_cached += rb;
+    return PVHIP_OK;
+}
+
+int pvhip_pool_stats(size_t* bytes_in_use, size_t* bytes_cached) {
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    if (bytes_in_use) *bytes_in_use = p.bytes_live;
+    if (bytes_cached) *bytes_cached = p.bytes_cached;
+    return PVHIP_OK;
+}
+
+int pvhip_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    PVHIP_REQUIRE_INIT();
+    if (bytes == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(dst != nullptr && src != nullptr);
+    PVHIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, state().stream));
+    // the host buffer may be pageable and is free to change once we return
+    PVHIP_HIP(hipStreamSynchronize(state().stream));
+    return PVHIP_OK;
+}
+
+int pvhip_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    PVHIP_REQUIRE_INIT();
+    if (bytes == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(dst != nullptr && src != nullptr);
+    PVHIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, state().stream));
+    PVHIP_HIP(hipStreamSynchronize(state().stream));
+    return PVHIP_OK;
+}
+
+int pvhip_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+    PVHIP_REQUIRE_INIT();
+    if (bytes == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(dst != nullptr && src != nullptr);
+    PVHIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, state().stream));
+    return PVHIP_OK;
+}
+
+int pvhip_memset(void* dst, int byte, size_t bytes) {
+    PVHIP_REQUIRE_INIT();
+    if (bytes == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(dst != nullptr);
+    PVHIP_HIP(hipMemsetAsync(dst, byte, bytes, state().stream));
+    return PVHIP_OK;
+}
+
+int pvhip_sync(void) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_HIP(hipStreamSynchronize(state().stream));
+    return PVHIP_OK;
+}
+
+int pvhip_event_create(void** ev) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(ev != nullptr);
+    hipEvent_t e;
+    PVHIP_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return PVHIP_OK;
+}
+
+int pvhip_event_destroy(void* ev) {
+    if (ev == nullptr || !state().ready) return PVHIP_OK;
+    PVHIP_HIP(hipEventDestroy((hipEvent_t)ev));
+    return PVHIP_OK;
+}
+
+int pvhip_event_record(void* ev) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(ev != nullptr);
+    PVHIP_HIP(hipEventRecord((hipEvent_t)ev, state().stream));
+    return PVHIP_OK;
+}
+
+int pvhip_event_sync(void* ev) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(ev != nullptr);
+    PVHIP_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return PVHIP_OK;
+}
+
+int pvhip_event_elapsed_ms(void* start, void* stop, float* ms) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(start != nullptr && stop != nullptr && ms != nullptr);
+    PVHIP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PVHIP_OK;
+}
+
+int pvhip_graph_begin_capture(void) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_HIP(hipStreamBeginCapture(state().stream, hipStreamCaptureModeThreadLocal));
+    return PVHIP_OK;
+}
+
+int pvhip_graph_end_capture(void** graph_exec) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(graph_exec != nullptr);
+    hipGraph_t g = nullptr;
+    PVHIP_HIP(hipStreamEndCapture(state().stream, &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t     e  = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(PVHIP_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(e));
+    *graph_exec = (void*)ge;
+    return PVHIP_OK;
+}
+
+int pvhip_graph_launch(void* graph_exec) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(graph_exec != nullptr);
+    PVHIP_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, state().stream));
+    return PVHIP_OK;
+}
+
+int pvhip_graph_destroy(void* graph_exec) {
+    if (graph_exec == nullptr || !state().ready) return PVHIP_OK;
+    PVHIP_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return PVHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,318 @@
+"""ctypes binding of libpvhip.so (include/pvhip.h) and the DeviceTensor handle that flows through
+the scheduler's ``inputs`` dicts instead of ndarrays.
+
+No PyTorch, no numpy compute: this module only moves bytes and calls the C ABI.  If the shared
+library is missing or no GPU is visible, every entry point raises -- there is no CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpvhip.so')
+
+MAX_RANK = 6
+MAX_CONCAT = 16
+UNIQUE_ID_BYTES = 128
+
+_c = ctypes
+_i64p = _c.POINTER(_c.c_int64)
+_fp = _c.c_void_p  # device pointers travel as plain integers
+
+# name -> (restype, argtypes); mirrors include/pvhip.h one to one (tests check the two agree)
+SIGNATURES = {
+    'pvhip_abi_version': (_c.c_int, []),
+    'pvhip_last_error': (_c.c_char_p, []),
+    'pvhip_device_count': (_c.c_int, [_c.POINTER(_c.c_int)]),
+    'pvhip_init': (_c.c_int, [_c.c_int]),
+    'pvhip_shutdown': (_c.c_int, []),
+    'pvhip_device_name': (_c.c_int, [_c.c_char_p, _c.c_size_t]),
+    'pvhip_malloc': (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_size_t]),
+    'pvhip_free': (_c.c_int, [_c.c_void_p]),
+    'pvhip_pool_release': (_c.c_int, []),
+    'pvhip_pool_stats': (_c.c_int, [_c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
+    'pvhip_memcpy_h2d': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
+    'pvhip_memcpy_d2h': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
+    'pvhip_memcpy_d2d': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
+    'pvhip_memset': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t]),
+    'pvhip_sync': (_c.c_int, []),
+    'pvhip_event_create': (_c.c_int, [_c.POINTER(_c.c_void_p)]),
+    'pvhip_event_destroy': (_c.c_int, [_c.c_void_p]),
+    'pvhip_event_record': (_c.c_int, [_c.c_void_p]),
+    'pvhip_event_sync': (_c.c_int, [_c.c_void_p]),
+    'pvhip_event_elapsed_ms': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_float)]),
+    'pvhip_graph_begin_capture': (_c.c_int, []),
+    'pvhip_graph_end_capture': (_c.c_int, [_c.POINTER(_c.c_void_p)]),
+    'pvhip_graph_launch': (_c.c_int, [_c.c_void_p]),
+    'pvhip_graph_destroy': (_c.c_int, [_c.c_void_p]),
+    'pvhip_relu_f32': (_c.c_int, [_fp, _fp, _c.c_size_t]),
+    'pvhip_clamp_f32': (_c.c_int, [_fp, _fp, _c.c_size_t, _c.c_float, _c.c_float]),
+    'pvhip_sigmoid_f32': (_c.c_int, [_fp, _fp, _c.c_size_t]),
+    'pvhip_add_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _i64p, _i64p, _i64p]),
+    'pvhip_mul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _i64p, _i64p, _i64p]),
+    'pvhip_maxpool2d_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 14),
+    'pvhip_avgpool2d_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 10),
+    'pvhip_softmax_rows_f32': (_c.c_int, [_fp, _fp, _c.c_int, _c.c_int]),
+    'pvhip_lrn_f32': (_c.c_int, [_fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float]),
+    'pvhip_concat_f32': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _i64p, _fp, _c.c_int64]),
+    'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
+    'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
+    'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 4),
+    'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int]),
+    'pvhip_dwconv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 12),
+    'pvhip_comm_unique_id': (_c.c_int, [_c.c_void_p]),
+    'pvhip_comm_init': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
+    'pvhip_comm_allgather_f32': (_c.c_int, [_fp, _fp, _c.c_size_t]),
+    'pvhip_comm_destroy': (_c.c_int, []),
+}
+
+# entry points whose return value is not a status code
+_NOT_STATUS = {'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems'}
+
+
+class PvhipError(RuntimeError):
+    """A libpvhip call returned a negative status."""
+
+
+_lib = None
+_initialised_device = None
+
+
+def load_library():
+    """dlopen libpvhip.so and declare every prototype.  Loud failure if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PvhipError('HIP extension {} is not built -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                         'or `make -C pyopenvino_amd/csrc`; there is no CPU fallback'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise PvhipError with the library's message on failure."""
+    lib = load_library()
+    rc = getattr(lib, name)(*args)
+    if name not in _NOT_STATUS and rc != 0:
+        raise PvhipError('{} failed ({}): {}'.format(name, rc, lib.pvhip_last_error().decode(errors='replace')))
+    return rc
+
+
+def device_count() -> int:
+    n = _c.c_int(0)
+    lib = load_library()
+    rc = lib.pvhip_device_count(_c.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def init(device: int = None) -> int:
+    """Bind this process to one GPU (default: LOCAL_RANK or 0) and create the compute stream."""
+    global _initialised_device
+    if device is None:
+        device = int(os.environ.get('LOCAL_RANK', '0'))
+        if device_count() == 1:
+            device = 0
+    if _initialised_device is not None:
+        if _initialised_device != device:
+            raise PvhipError('already bound to GPU {}'.format(_initialised_device))
+        return device
+    call('pvhip_init', int(device))
+    _initialised_device = device
+    return device
+
+
+def ensure_init():
+    if _initialised_device is None:
+        init()
+
+
+def is_initialised() -> bool:
+    return _initialised_device is not None
+
+
+def device_name() -> str:
+    ensure_init()
+    buf = ctypes.create_string_buffer(256)
+    call('pvhip_device_name', buf, 256)
+    return buf.value.decode()
+
+
+def synchronize():
+    ensure_init()
+    call('pvhip_sync')
+
+
+def pool_stats():
+    a, b = _c.c_size_t(0), _c.c_size_t(0)
+    call('pvhip_pool_stats', _c.byref(a), _c.byref(b))
+    return a.value, b.value
+
+
+class _Block:
+    """Owner of one pooled device allocation; returns it to the pool when the last view dies."""
+    __slots__ = ('ptr', 'nbytes')
+
+    def __init__(self, nbytes: int):
+        ensure_init()
+        p = _c.c_void_p(0)
+        call('pvhip_malloc', _c.byref(p), int(nbytes))
+        self.ptr = p.value or 0
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.pvhip_free(_c.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = 0
+
+
+def _contig_strides(shape):
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= int(d)
+    return tuple(reversed(st))
+
+
+class DeviceTensor:
+    """A dense, C-contiguous tensor resident in HBM.
+
+    Exposes ``shape`` / ``dtype`` / ``ndim`` / ``size`` like an ndarray so the reference's per-plugin
+    validation (``data.dtype == ...``, ``data.shape == dims``) keeps working on it unchanged, and
+    ``__array__`` so that host code that really wants the values (``np.asarray(t)``, the Result
+    plugin) gets a device-to-host copy -- which synchronises the stream.
+    """
+    __slots__ = ('_block', 'shape', 'dtype', '__weakref__')
+    __array_priority__ = 100
+
+    def __init__(self, block: _Block, shape, dtype=np.float32):
+        self._block = block
+        self.shape = tuple(int(d) for d in shape)
+        self.dtype = np.dtype(dtype)
+        if self.nbytes > block.nbytes:
+            raise PvhipError('view {} larger than its block'.format(self.shape))
+
+    # ---- construction
+    @classmethod
+    def empty(cls, shape, dtype=np.float32):
+        shape = tuple(int(d) for d in shape)
+        n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+        return cls(_Block(max(1, n) * np.dtype(dtype).itemsize), shape, dtype)
+
+    @classmethod
+    def from_numpy(cls, array, dtype=None):
+        a = np.ascontiguousarray(array, dtype=dtype)
+        t = cls.empty(a.shape, a.dtype)
+        if a.nbytes:
+            call('pvhip_memcpy_h2d', _c.c_void_p(t.ptr), a.ctypes.data_as(_c.c_void_p), a.nbytes)
+        return t
+
+    # ---- ndarray-like surface
+    @property
+    def ptr(self) -> int:
+        return self._block.ptr
+
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    @property
+    def size(self) -> int:
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    @property
+    def nbytes(self) -> int:
+        return self.size * self.dtype.itemsize
+
+    def reshape(self, *shape):
+        """Metadata-only reshape: the new tensor shares the device block."""
+        if len(shape) == 1 and not isinstance(shape[0], (int, np.integer)):
+            shape = tuple(shape[0])
+        shape = [int(d) for d in shape]
+        if shape.count(-1) > 1:
+            raise ValueError('can only specify one unknown dimension')
+        if -1 in shape:
+            known = 1
+            for d in shape:
+                if d != -1:
+                    known *= d
+            if known == 0 or self.size % known:
+                raise ValueError('cannot reshape tensor of size {} into shape {}'.format(self.size, tuple(shape)))
+            shape[shape.index(-1)] = self.size // known
+        n = 1
+        for d in shape:
+            n *= d
+        if n != self.size:
+            raise ValueError('cannot reshape tensor of size {} into shape {}'.format(self.size, tuple(shape)))
+        return DeviceTensor(self._block, shape, self.dtype)
+
+    def numpy(self) -> np.ndarray:
+        """Device-to-host copy (synchronises the compute stream)."""
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            call('pvhip_memcpy_d2h', out.ctypes.data_as(_c.c_void_p), _c.c_void_p(self.ptr), out.nbytes)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __repr__(self):
+        return 'DeviceTensor(shape={}, dtype={}, ptr=0x{:x})'.format(self.shape, self.dtype.name, self.ptr)
+
+
+def as_device(data, dtype=np.float32) -> DeviceTensor:
+    """Accept what a predecessor plugin handed over: a DeviceTensor (ours) or an ndarray (when our
+    plugins are mixed with host plugins, e.g. under the reference's own engine)."""
+    if isinstance(data, DeviceTensor):
+        return data
+    return DeviceTensor.from_numpy(np.asarray(data), dtype=dtype)
+
+
+def i64_array(values):
+    """Host int64 array in ctypes form (shapes, strides, permutations)."""
+    arr = (_c.c_int64 * max(1, len(values)))(*[int(v) for v in values])
+    return arr
+
+
+class Event:
+    """hipEvent on the compute stream (device-side timing of the hot path)."""
+
+    def __init__(self):
+        ensure_init()
+        h = _c.c_void_p(0)
+        call('pvhip_event_create', _c.byref(h))
+        self.handle = h.value
+
+    def record(self):
+        call('pvhip_event_record', _c.c_void_p(self.handle))
+        return self
+
+    def synchronize(self):
+        call('pvhip_event_sync', _c.c_void_p(self.handle))
+
+    def elapsed_ms(self, end: 'Event') -> float:
+        ms = _c.c_float(0.0)
+        call('pvhip_event_elapsed_ms', _c.c_void_p(self.handle), _c.c_void_p(end.handle), _c.byref(ms))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.pvhip_event_destroy(_c.c_void_p(self.handle))
+        except Exception:
+            pass
+        self.handle = None

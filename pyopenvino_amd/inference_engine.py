@@ -1,0 +1,309 @@
+"""OpenVINO-IR loader and list scheduler around the op-plugin boundary.
+
+Same public surface as the reference engine (``pyopenvino/inference_engine.py``): ``IECore``
+(``read_network`` ``:74-83``, ``load_network`` ``:86-90``), ``IENetwork`` and ``Executable_Network``
+(``schedule_tasks`` ``:218-242``, ``run_tasks`` ``:259-292``, ``infer`` ``:295-321``).  The model is a
+``networkx.DiGraph`` whose node dicts carry the IR attributes; a static task list is executed by
+calling ``plugins[type].compute(node, inputs, kernel_type=..., debug=False)`` per node -- that call is
+the drop-in boundary, and what flows through ``inputs`` here are device-resident tensors.
+
+Differences from the reference, all outside the numeric path:
+  * constants are decoded with ``np.frombuffer`` (zero copy) instead of ``struct.unpack`` into tuples;
+  * ``IENetwork.set_batch`` rewrites the batch dimension of every activation port so that a batch of
+    independent images runs through the same graph (the reference IRs are baked at N=1);
+  * plugins are discovered as modules of a package (default ``pyopenvino_amd.op_plugins``) instead of a
+    CWD-relative glob;
+  * ``infer`` can shard the batch across ranks (one process per GPU): every rank runs the unchanged
+    scheduler on its slice and the Result plugin all-gathers the Result tensors.
+"""
+import importlib
+import os
+import pkgutil
+import sys
+import time
+import xml.etree.ElementTree as et
+
+import networkx as nx
+import numpy as np
+
+from . import common_def
+
+DEFAULT_PLUGIN_PACKAGE = 'pyopenvino_amd.op_plugins'
+
+
+class Plugins:
+    """Registry ``{IR layer type: module}``; a module's file name is the layer type it implements
+    (reference inference_engine.py:28-43)."""
+
+    def __init__(self):
+        self.plugins = {}
+
+    def import_plugin(self, package: str, module_name: str, plugin_name: str = None):
+        module = importlib.import_module(package + '.' + module_name)
+        if not hasattr(module, 'compute'):
+            return None
+        key = plugin_name or module_name
+        setattr(self, key, module)
+        self.plugins[key] = module
+        return module
+
+    def load_plugins(self, plugin_path: str):
+        """``plugin_path`` is a dotted package name or a '/'-separated path to one."""
+        package = plugin_path.replace(os.sep, '.').replace('/', '.').strip('.')
+        pkg = importlib.import_module(package)
+        for info in pkgutil.iter_modules(pkg.__path__):
+            if not info.name.startswith('_'):
+                self.import_plugin(package, info.name)
+
+
+class IECore:
+    def __init__(self, plugin_package: str = DEFAULT_PLUGIN_PACKAGE):
+        self.plugins = Plugins()
+        self.plugins.load_plugins(plugin_package)
+
+    def construct_node_info(self, net, node_type: str) -> list:
+        return [net.G.nodes[node_id] for node_id, _ in net.find_node_by_type(node_type)]
+
+    def check_nodes(self, G: nx.DiGraph):
+        missing = {G.nodes[n]['type'] for n in G.nodes} - set(self.plugins.plugins)
+        if missing:
+            print('Unsupported nodes : {}'.format(sorted(missing)))
+        return missing
+
+    def read_network(self, model: str, weights=None):
+        """``model``: path of the IR ``.xml``.  ``weights``: path of the ``.bin`` (default: next to the
+        xml, as the reference does) or the blob itself (bytes / uint8 ndarray) when the weights were
+        synthesised in memory."""
+        net = IENetwork(self)
+        net.read_IR_Model(model, weights)
+        net.parse_IR_XML()
+        net.build_graph()
+        net.set_constants_to_graph()
+        net.inputs = self.construct_node_info(net, 'Parameter')
+        net.outputs = self.construct_node_info(net, 'Result')
+        return net
+
+    def load_network(self, network, device_name: str = 'GPU', num_requests: int = 1):
+        exenet = Executable_Network(network)
+        self.check_nodes(exenet.ienet.G)
+        exenet.schedule_tasks()
+        return exenet
+
+
+class IENetwork:
+    def __init__(self, iecore: IECore):
+        self.ie = iecore
+        self.xml = None
+        self.bin = None
+        self.G = None
+        self.layers = None
+        self.edges = None
+        self.inputs = None
+        self.outputs = None
+        self.batch_size = 1
+
+    # ------------------------------------------------------------------ IR reading
+    def read_IR_Model(self, model, weights=None):
+        stem, _ = os.path.splitext(model)
+        xml_file = stem + '.xml'
+        if not os.path.isfile(xml_file):
+            raise Exception('model {} is not found'.format(model))
+        self.xml = et.parse(xml_file)
+        if isinstance(weights, (bytes, bytearray, memoryview)):
+            self.bin = bytes(weights) if not isinstance(weights, bytes) else weights
+        elif isinstance(weights, np.ndarray):
+            self.bin = weights.tobytes()
+        else:
+            bin_file = weights if (isinstance(weights, str) and os.path.isfile(weights)) else stem + '.bin'
+            if not os.path.isfile(bin_file):
+                raise Exception('model {} is not found'.format(model))
+            with open(bin_file, 'rb') as f:
+                self.bin = f.read()
+
+    @staticmethod
+    def _ports(section):
+        ports = {}
+        if section is None:
+            return None
+        for port in section.findall('port'):
+            ports[int(port.attrib['id'])] = {
+                'precision': port.attrib['precision'],
+                'dims': tuple(int(d.text) for d in port.findall('dim')),
+            }
+        return ports
+
+    def parse_IR_XML(self):
+        root = self.xml.getroot()
+        if root.tag != 'net':
+            raise Exception('Not an OpenVINO IR file')
+        layers = {}
+        for layer in root.iterfind('./layers/layer'):
+            info = {k: v for k, v in layer.attrib.items() if k != 'id'}
+            data = layer.find('data')
+            if data is not None:
+                attrs = dict(data.attrib)
+                for key in ('shape', 'stride'):
+                    if key in attrs:
+                        attrs[key] = common_def.string_to_tuple(attrs[key]) if attrs[key].strip() else ()
+                info['data'] = attrs
+            for tag in ('input', 'output'):
+                ports = self._ports(layer.find(tag))
+                if ports is not None:
+                    info[tag] = ports
+            layers[int(layer.attrib['id'])] = info
+        self.layers = layers
+        self.edges = [(int(e.attrib['from-layer']), int(e.attrib['from-port']),
+                       int(e.attrib['to-layer']), int(e.attrib['to-port']))
+                      for e in root.iterfind('./edges/edge')]
+
+    def build_graph(self):
+        G = nx.DiGraph()
+        for node_id, info in self.layers.items():
+            G.add_node(node_id, **info)
+        for edge in self.edges:
+            G.add_edge(edge[0], edge[2], connection=edge)
+        assert nx.is_directed_acyclic_graph(G)
+        self.G = G
+
+    def set_constants_to_graph(self):
+        """Attach each Const's slice of the ``.bin`` blob (little-endian raw data) to its node."""
+        blob = memoryview(self.bin)
+        for node_id, _ in self.find_node_by_type('Const'):
+            node = self.G.nodes[node_id]
+            attrs = node['data']
+            offset, size = int(attrs['offset']), int(attrs['size'])
+            precision = attrs['element_type'].upper()
+            code, width = common_def.format_config[precision]
+            if offset + size > len(blob):
+                raise Exception('Const {} lies outside the weight blob'.format(node.get('name')))
+            values = np.frombuffer(blob[offset:offset + size], dtype=np.dtype('<' + code), count=size // width)
+            node['const'] = {'data': values, 'element_info': precision, 'size': size,
+                             'decode_info': common_def.format_config[precision]}
+
+    def find_node_by_type(self, type: str) -> list:
+        return [(n, self.G.nodes[n]['name']) for n in self.G.nodes if self.G.nodes[n]['type'] == type]
+
+    # ------------------------------------------------------------------ batch
+    def set_batch(self, batch: int):
+        """Run ``batch`` independent images through the graph: multiply the leading dimension of every
+        port that carries activations (anything downstream of a Parameter) by ``batch / current``.
+        Constant ports keep their shape; Reshape targets in the shipped IRs use -1 / 0 for the batch
+        axis, so they need no edit."""
+        batch = int(batch)
+        if batch < 1:
+            raise ValueError('batch must be >= 1')
+        if batch == self.batch_size:
+            return
+        if batch % self.batch_size and self.batch_size != 1:
+            raise ValueError('set_batch works from the IR batch (call it once, or with a multiple)')
+        old = self.batch_size
+        G = self.G
+        act_nodes = set()
+        for pid, _ in self.find_node_by_type('Parameter'):
+            act_nodes.add(pid)
+            act_nodes.update(nx.descendants(G, pid))
+
+        def scaled(dims):
+            if len(dims) == 0:
+                return dims
+            return (dims[0] // old * batch,) + tuple(dims[1:])
+
+        for nid in act_nodes:
+            node = G.nodes[nid]
+            for port in node.get('output', {}).values():
+                port['dims'] = scaled(port['dims'])
+            if node['type'] == 'Parameter':
+                node['data']['shape'] = scaled(tuple(node['data']['shape']))
+            for pred in G.pred[nid]:
+                if pred in act_nodes:
+                    sink_port = G.edges[(pred, nid)]['connection'][3]
+                    node['input'][sink_port]['dims'] = scaled(node['input'][sink_port]['dims'])
+        self.batch_size = batch
+
+
+class Executable_Network:
+    def __init__(self, ienetwork: IENetwork):
+        self.ienet = ienetwork
+        self.kernel_type = 'hip'        # the reference's 'naive' / 'numpy' / 'special' are accepted too
+        self.expected_result = None     # {node name: ndarray}: per-layer compare hook (cf. :284-287)
+        self.task_list = []
+        self.last_node_times = []       # [(node id, type, name, host seconds)] of the last run_tasks
+        self.comm = None                # parallel.BatchShardComm when the batch is sharded over ranks
+
+    def schedule_tasks(self):
+        """Static list schedule: sources (Const, Parameter) first, then repeated sweeps in node order
+        appending every node whose predecessors are all scheduled (same policy as :218-242)."""
+        G = self.ienet.G
+        order, done = [], set()
+        pending = []
+        for node_id in G.nodes:
+            if G.nodes[node_id]['type'] in ('Const', 'Parameter'):
+                order.append(node_id)
+                done.add(node_id)
+            else:
+                pending.append(node_id)
+        while pending:
+            still = []
+            for node_id in pending:
+                if all(p in done for p in G.pred[node_id]):
+                    order.append(node_id)
+                    done.add(node_id)
+                else:
+                    still.append(node_id)
+            if len(still) == len(pending):
+                raise RuntimeError('graph has nodes that can never become ready')
+            pending = still
+        self.task_list = order
+
+    def prepare_inputs_for_task(self, task) -> dict:
+        """{sink port: tensor} gathered from the predecessors' output ports, in edge order."""
+        G = self.ienet.G
+        inputs = {}
+        for pred in G.pred[task]:
+            src_node, src_port, _, sink_port = G.edges[(pred, task)]['connection']
+            inputs[sink_port] = G.nodes[src_node]['output'][src_port]['data']
+        return inputs
+
+    def run_tasks(self, verbose: bool = False):
+        G = self.ienet.G
+        registry = self.ienet.ie.plugins.plugins
+        times = []
+        for task in self.task_list:
+            node = G.nodes[task]
+            node_type = node['type']
+            inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
+            plugin = registry.get(node_type)
+            if plugin is None:
+                print("ERROR: Operation '{}' (node={}) is not supported.".format(node_type, node['name']))
+                sys.exit(-1)
+            t0 = time.time()
+            res = plugin.compute(node, inputs, kernel_type=self.kernel_type, debug=False)
+            dt = time.time() - t0
+            times.append((task, node_type, node['name'], dt))
+            if verbose:
+                print('{}, {}, {}, {}'.format(task, node_type, node['name'], dt))
+            if self.expected_result is not None and node['name'] in self.expected_result and len(res) > 0:
+                got = np.asarray(next(iter(res.values())))
+                want = np.asarray(self.expected_result[node['name']]).astype(got.dtype)
+                ok = got.shape == want.shape and np.allclose(got, want, rtol=1e-4, atol=1e-4 * max(1e-30, float(np.abs(want).max())))
+                print('{} : {}'.format(node['name'], 'match' if ok else 'MISMATCH'))
+            if len(res) > 0:
+                for port_id, data in res.items():
+                    node['output'][port_id]['data'] = data
+        self.last_node_times = times
+
+    def infer(self, inputs: dict, verbose: bool = False) -> dict:
+        G = self.ienet.G
+        by_name = {G.nodes[n]['name']: n for n in G.nodes}
+        for node_name, val in inputs.items():
+            if node_name in by_name:
+                G.nodes[by_name[node_name]]['param'] = val
+        for nid, _ in self.ienet.find_node_by_type('Result'):
+            G.nodes[nid]['comm'] = self.comm
+        if verbose:
+            print('# node_id node_name time (sec)')
+        t0 = time.time()
+        self.run_tasks(verbose)
+        if verbose:
+            print('@TOTAL_TIME,', time.time() - t0)
+        return {name: G.nodes[nid]['result'] for nid, name in self.ienet.find_node_by_type('Result')}

@@ -1,0 +1,42 @@
+# GroupConvolution -- HIP plugin, depthwise case.  Replaces kernel_GroupConvolution_numpy (reference
+# op_plugins/GroupConvolution.py:53-79), whose channel indexing (gp*ci+gp, :77) is only meaningful for
+# one input and one output channel per group -- the only case the shipped IRs contain.  The reference
+# computes batch element 0 only (:77-78); here every image of the batch is computed the same way.
+import ctypes
+
+from .. import common_def
+from .. import device as dev
+
+
+def name():
+    print('GroupConvolution')
+
+
+def calc_output_shape_group_conv(input_dim, kernel_dim, strides, pads_begin, pads_end, rounding_type, auto_pad):
+    return tuple(common_def.pooled_extent(input_dim[i], kernel_dim[i], strides[i], pads_begin[i], pads_end[i],
+                                          rounding_type, auto_pad, same_means_input=False) for i in (0, 1))
+
+
+def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bool = False):
+    if debug:
+        print(node)
+    common_def.validate_inputs(node, inputs)
+    attrs = node['data']
+    strides = common_def.string_to_tuple(attrs['strides'])
+    pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
+    pads_end = common_def.string_to_tuple(attrs['pads_end'])
+    x = dev.as_device(inputs[0])
+    w = dev.as_device(inputs[1])
+    n, c, h, wd = x.shape
+    grp, ch_o, ch_i, kh, kw = w.shape
+    if ch_o != 1 or ch_i != 1 or grp != c:
+        raise NotImplementedError('only depthwise GroupConvolution (weights [G,1,1,kh,kw], G == C) is supported, '
+                                  'got weights {} for input {}'.format(w.shape, x.shape))
+    oh, ow = calc_output_shape_group_conv((h, wd), (kh, kw), strides, pads_begin, pads_end, 'floor', attrs['auto_pad'])
+    hp, wp = h + pads_begin[0] + pads_end[0], wd + pads_begin[1] + pads_end[1]
+    if oh > 0 and ow > 0 and ((oh - 1) * strides[0] + kh > hp or (ow - 1) * strides[1] + kw > wp):
+        raise ValueError('operands could not be broadcast together: window exceeds the padded input')
+    y = dev.DeviceTensor.empty((n, grp, oh, ow))
+    dev.call('pvhip_dwconv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(w.ptr), ctypes.c_void_p(y.ptr),
+             n, grp, h, wd, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])
+    return {common_def.first_output_port(node): y}

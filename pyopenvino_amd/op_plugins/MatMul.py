@@ -1,0 +1,32 @@
+# MatMul -- HIP plugin (fp32 MFMA).  Replaces kernel_MatMul_numpy (reference op_plugins/MatMul.py:9-17):
+# 2-D operands, transpose flags are the strings 'true' / 'false'.
+import ctypes
+
+from .. import common_def
+from .. import device as dev
+
+
+def name():
+    print('MatMul')
+
+
+def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bool = False):
+    if debug:
+        print(node)
+    common_def.validate_inputs(node, inputs)
+    data = node['data']
+    a = dev.as_device(inputs[0])
+    b = dev.as_device(inputs[1])
+    if a.ndim != 2 or b.ndim != 2:
+        raise NotImplementedError('MatMul operands must be 2-D, got {} and {}'.format(a.shape, b.shape))
+    ta = data['transpose_a'] == 'true'
+    tb = data['transpose_b'] == 'true'
+    m, ka = (a.shape[1], a.shape[0]) if ta else a.shape
+    kb, n = (b.shape[1], b.shape[0]) if tb else b.shape
+    if ka != kb:
+        raise ValueError('matmul: Input operand 1 has a mismatch in its core dimension 0 (size {} is different '
+                         'from {})'.format(kb, ka))
+    c = dev.DeviceTensor.empty((m, n))
+    dev.call('pvhip_matmul_f32', ctypes.c_void_p(a.ptr), ctypes.c_void_p(b.ptr), ctypes.c_void_p(c.ptr), m, n, ka,
+             int(ta), int(tb))
+    return {common_def.first_output_port(node): c}

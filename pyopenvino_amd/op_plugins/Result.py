@@ -1,0 +1,24 @@
+# Result -- HIP plugin.  Replaces reference op_plugins/Result.py:7-18: validates and stores its input
+# as node['result'].  This is where the tensor leaves HBM (device-to-host copy, synchronises the
+# stream).  When the batch is sharded over ranks (node['comm'] set by the engine) the shards' Result
+# tensors are all-gathered over RCCL first, so every rank returns the whole batch.
+import numpy as np
+
+from .. import common_def
+from .. import device as dev
+
+
+def name():
+    print('Result')
+
+
+def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bool = False):
+    if debug:
+        print(node)
+    common_def.validate_inputs(node, inputs)
+    value = inputs[0]
+    comm = node.get('comm')
+    if comm is not None and comm.world > 1:
+        value = comm.allgather_rows(value)
+    node['result'] = value.numpy() if isinstance(value, dev.DeviceTensor) else np.asarray(value)
+    return []

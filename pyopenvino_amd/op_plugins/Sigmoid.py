@@ -1,0 +1,19 @@
+# Sigmoid -- HIP plugin.  Replaces kernel_Sigmoid_numpy (reference op_plugins/Sigmoid.py:10-13).
+import ctypes
+
+from .. import common_def
+from .. import device as dev
+
+
+def name():
+    print('Sigmoid')
+
+
+def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bool = False):
+    if debug:
+        print(node)
+    common_def.validate_inputs(node, inputs)
+    x = dev.as_device(inputs[0])
+    y = dev.DeviceTensor.empty(x.shape)
+    dev.call('pvhip_sigmoid_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), x.size)
+    return {common_def.first_output_port(node): y}

@@ -1,0 +1,66 @@
+"""The oracle (CPU restatement, oracle/) against the outputs of the REAL reference recorded in
+tests/golden/ by make_golden.py -- this is what pins the oracle.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import GOLDEN, assert_close, build_network, infer_one, layer_sums, load_case
+
+ORACLE_TOL = 2e-6  # oracle vs reference: same numpy underneath, only summation order may differ
+
+
+@pytest.mark.parametrize('path', helpers.op_case_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_op_matches_reference(path):
+    import importlib
+    node, inputs, want = load_case(path)
+    plugin = importlib.import_module('oracle.op_plugins.' + node['type'])
+    got = helpers.first_out(plugin.compute(node, inputs, kernel_type='special', debug=False))
+    assert got.shape == want.shape
+    if node['type'] in helpers.BIT_EXACT:
+        helpers.assert_bit_exact(got.astype(np.float32), want, node['name'])
+    else:
+        assert_close(got, want, ORACLE_TOL, node['name'])
+
+
+def test_oracle_mnist_end_to_end_and_layer_sums():
+    z = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))
+    _, net, ex = build_network('oracle.op_plugins', 'mnist')
+    ex.kernel_type = 'special'
+    for i in range(z['images'].shape[0]):
+        got = infer_one(ex, net, z['images'][i:i + 1])
+        assert_close(got, z['out'][i:i + 1], ORACLE_TOL, 'mnist image {}'.format(i))
+        if i == 0:
+            sums = layer_sums(net)
+            for nid, want in zip(z['layer_ids'], z['layer_sums']):
+                assert abs(sums[int(nid)] - want) <= 1e-5 * max(1.0, abs(want)), 'layer {}'.format(nid)
+    # the reference's own integrity assertions (integrity_test.py:57) and README.md:69-72 values
+    top = np.argsort(z['out'][0])[::-1]
+    assert list(top[:3]) == [2, 0, 1]
+    assert abs(z['out'][0][2] - 9.9999917e-01) < 1e-6 and abs(z['out'][0][0] - 7.8985e-07) < 1e-10
+    assert int(np.argmax(z['out'][1])) == 7
+
+
+def test_oracle_mnist_batch_equals_stacked_single_images():
+    z = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))
+    _, net, ex = build_network('oracle.op_plugins', 'mnist', batch=8)
+    got = infer_one(ex, net, z['images'])
+    assert_close(got, z['out'], ORACLE_TOL, 'mnist batch 8')
+
+
+@pytest.mark.parametrize('model,fname,shape', [('googlenet-v1', 'googlenet_e2e.npz', (1, 3, 224, 224)),
+                                               ('mnist_bn', 'mnist_bn_e2e.npz', (1, 1, 28, 28))])
+def test_oracle_synthetic_models(model, fname, shape):
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, fname))
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, model + '.xml'), int(z['weight_seed']))
+    _, net, ex = build_network('oracle.op_plugins', model, weights=blob)
+    for i, seed in enumerate(z['image_seeds']):
+        x = synth.uniform_pixels(int(seed), shape)
+        got = infer_one(ex, net, x)
+        assert_close(got, z['out'][i:i + 1], 1e-5, '{} image {}'.format(model, i))
+        if i == 0:
+            sums = layer_sums(net)
+            for nid, want in zip(z['layer_ids'], z['layer_sums']):
+                assert abs(sums[int(nid)] - want) <= 2e-5 * max(1.0, abs(want)), 'layer {}'.format(nid)
