@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: images/sec of googlenet-v1 fp32 at batch 256 per GPU (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole per-layer compute() path (Executable_Network.infer) over one batch of
+256 synthetic images per GPU, input already resident in HBM, ending with the Result tensor back on the
+host (and, for N > 1, an RCCL all-gather of the Result tensors first).  For N > 1 launch one process per
+GPU with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; torch.distributed
+(gloo) is used for the rendezvous / barrier / max-over-ranks only.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying
+  roofline      for the dominant kernel (conv_igemm_kernel, fp32 MFMA): algorithmic FLOPs of all 57
+                Convolution launches of a step / their summed device time measured with hipEvents on the
+                compute stream inside the timed steps;
+  cpu_baseline  the oracle (CPU restatement of the reference's 'special' path) timed on this host, N=1 per
+                image like the reference, on a bounded sample of the same workload.
+A per-op-type breakdown (device ms, algorithmic GB/s or TFLOP/s) goes to stderr and, if the directory
+exists, to gpurun_out/bench_breakdown.json.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+MODEL = 'googlenet-v1'
+BATCH_PER_GPU = 256
+WEIGHT_SEED = 1234
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def node_work(node, inputs_shapes, out_shape):
+    """Algorithmic work of one node: (flops, bytes) per SURVEY section 8(d): conv/matmul flops =
+    2*MACs; memory-bound ops bytes = 4*(elements read once + written once), broadcast operand once."""
+    t = node['type']
+    out_e = int(np.prod(out_shape)) if len(out_shape) else 1
+    in_e = [int(np.prod(s)) if len(s) else 1 for s in inputs_shapes]
+    if t == 'Convolution':
+        k, c, kh, kw = inputs_shapes[1]
+        return 2.0 * out_e * c * kh * kw, 4.0 * (in_e[0] + in_e[1] + out_e)
+    if t == 'MatMul':
+        kdim = inputs_shapes[0][-1]
+        return 2.0 * out_e * kdim, 4.0 * (sum(in_e) + out_e)
+    return 0.0, 4.0 * (sum(in_e) + out_e)
+
+
+def collect_work(net):
+    G = net.G
+    work = {}
+    for nid in G.nodes:
+        node = G.nodes[nid]
+        if node['type'] in ('Const', 'Parameter', 'Result') or 'output' not in node:
+            continue
+        ins = [node['input'][p]['dims'] for p in sorted(node.get('input', {}))]
+        if node['type'] in ('LRN', 'Reshape', 'Transpose'):
+            ins = ins[:1]
+        out = next(iter(node['output'].values()))['dims']
+        work[nid] = node_work(node, ins, out)
+    return work
+
+
+def cpu_baseline(blob, n_images):
+    """Oracle plugins, one image at a time (the only mode the reference supports)."""
+    from pyopenvino_amd import IECore, synth
+    ie = IECore(plugin_package='oracle.op_plugins')
+    net = ie.read_network(os.path.join(REPO, 'models', MODEL + '.xml'), weights=blob)
+    ex = ie.load_network(net)
+    ex.kernel_type = 'special'
+    name = net.inputs[0]['name']
+    ex.infer({name: synth.uniform_pixels(1, (1, 3, 224, 224))})   # warm-up (page-in, BLAS threads)
+    t0 = time.time()
+    for i in range(n_images):
+        ex.infer({name: synth.uniform_pixels(2 + i, (1, 3, 224, 224))})
+    dt = time.time() - t0
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [p for p in threadpool_info() if p.get('user_api') == 'blas']
+        if blas:
+            threads = int(blas[0]['num_threads'])
+    except Exception:
+        pass
+    return {'value': n_images / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '{} googlenet-v1 images, one N=1 forward each, oracle numpy/OpenBLAS plugins, {:.1f} s'.format(n_images, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU (BASELINE: 256)')
+    ap.add_argument('--cpu-images', type=int, default=6, help='images timed on the CPU baseline (0 = skip)')
+    ap.add_argument('--no-node-timing', action='store_true')
+    args = ap.parse_args()
+
+    from pyopenvino_amd import IECore, device, shard, synth
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit('bench.py --gpus {} must be launched with torch.distributed.run --nproc-per-node {}'.format(args.gpus, args.gpus))
+    group = shard.TorchGroup('gloo') if world > 1 else shard.SingleGroup()
+    rank = group.rank
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    device.init(local_rank if device.device_count() > 1 else 0)
+
+    xml = os.path.join(REPO, 'models', MODEL + '.xml')
+    blob = synth.synth_weights(xml, WEIGHT_SEED)
+    ie = IECore()
+    net = ie.read_network(xml, weights=blob)
+    net.set_batch(args.batch)
+    ex = ie.load_network(net)
+    comm = shard.BatchShardComm(group)
+    ex.comm = comm
+    comm.init_device()
+
+    # synthetic input of this rank's shard, resident in HBM before the timed region
+    x_host = synth.uniform_pixels(1000 + rank, (args.batch, 3, 224, 224))
+    x_dev = device.DeviceTensor.from_numpy(x_host)
+    in_name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
+
+    for _ in range(args.warmup):
+        out = ex.infer({in_name: x_dev})[out_name]
+    assert out.shape == (args.batch * world, 1000) and np.isfinite(out).all()
+
+    if not args.no_node_timing:
+        ex.device_timing = 'all'
+    per_node = {}
+    group.barrier()
+    device.synchronize()
+    t0 = time.perf_counter()
+    ev0 = device.Event().record()
+    for _ in range(args.steps):
+        out = ex.infer({in_name: x_dev})[out_name]
+        if ex.device_timing is not None:
+            for nid, typ, name, ms in ex.device_times_ms():
+                per_node.setdefault(nid, [typ, name, 0.0])[2] += ms
+    ev1 = device.Event().record()
+    device.synchronize()
+    group.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = group.allreduce_max(elapsed)
+    dev_ms = ev0.elapsed_ms(ev1)
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        result = {
+            'metric': 'images/sec googlenet-v1 fp32 @batch256', 'value': total_images / elapsed, 'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'models/googlenet-v1.xml 1x3x224x224 fp32, batch {} per GPU, synthetic weights seed {}, '
+                                   'input resident in HBM, Result copied to host'.format(args.batch, WEIGHT_SEED),
+                       'global_batch': args.batch * world,
+                       'parallelism': 'batch shard x{} (one process per GPU), RCCL all-gather of Result'.format(world)},
+            'device_ms_per_step': dev_ms / args.steps,
+        }
+        roof = None
+        if per_node:
+            work = collect_work(net)
+            by_type = {}
+            for nid, (typ, name, ms) in per_node.items():
+                fl, by = work.get(nid, (0.0, 0.0))
+                agg = by_type.setdefault(typ, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
+                agg['ms'] += ms / args.steps
+                agg['flops'] += fl
+                agg['bytes'] += by
+                agg['launches'] += 1
+            conv = by_type.get('Convolution')
+            if conv and conv['ms'] > 0:
+                tf = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
+                roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': tf / PEAK_MFMA_F32_TFLOPS, 'traffic': None,
+                        'kernel': 'conv_igemm_kernel (57 Convolution launches per step)',
+                        'flops_per_step': conv['flops'], 'ms_per_step': conv['ms']}
+            breakdown = {}
+            for typ, agg in sorted(by_type.items(), key=lambda kv: -kv[1]['ms']):
+                row = {'launches': agg['launches'], 'ms_per_step': round(agg['ms'], 4)}
+                if agg['flops'] > 0:
+                    row['TFLOP/s'] = round(agg['flops'] / (agg['ms'] * 1e-3) / 1e12, 2)
+                    row['frac_mfma_peak'] = round(row['TFLOP/s'] / PEAK_MFMA_F32_TFLOPS, 4)
+                if agg['ms'] > 0:
+                    row['GB/s'] = round(agg['bytes'] / (agg['ms'] * 1e-3) / 1e9, 1)
+                    row['frac_hbm_peak'] = round(row['GB/s'] / PEAK_HBM_GBS, 4)
+                breakdown[typ] = row
+            layers = [{'id': nid, 'type': typ, 'name': name, 'ms': round(ms / args.steps, 4),
+                       'gflop': round(work.get(nid, (0, 0))[0] / 1e9, 3), 'mb': round(work.get(nid, (0, 0))[1] / 1e6, 2)}
+                      for nid, (typ, name, ms) in sorted(per_node.items())]
+            print('per-op breakdown (device time per step):', file=sys.stderr)
+            for typ, row in breakdown.items():
+                print('  {:12s} {}'.format(typ, row), file=sys.stderr)
+            out_dir = os.path.join(REPO, 'gpurun_out')
+            if os.path.isdir(out_dir):
+                with open(os.path.join(out_dir, 'bench_breakdown.json'), 'w') as f:
+                    json.dump({'by_type': breakdown, 'layers': layers, 'device': device.device_name()}, f, indent=1)
+        result['roofline'] = roof
+        result['cpu_baseline'] = cpu_baseline(blob, args.cpu_images) if args.cpu_images > 0 else None
+        print(json.dumps(result), flush=True)
+
+    comm.close()
+    if world > 1:
+        group.barrier()
+        group.close()
+
+
+if __name__ == '__main__':
+    main()

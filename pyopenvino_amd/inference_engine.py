@@ -228,7 +228,9 @@ class Executable_Network:
         self.expected_result = None     # {node name: ndarray}: per-layer compare hook (cf. :284-287)
         self.task_list = []
         self.last_node_times = []       # [(node id, type, name, host seconds)] of the last run_tasks
-        self.comm = None                # parallel.BatchShardComm when the batch is sharded over ranks
+        self.comm = None                # shard.BatchShardComm when the batch is sharded over ranks
+        self.device_timing = None       # None, 'all', or a set of layer types: bracket those nodes with hipEvents
+        self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
 
     def schedule_tasks(self):
         """Static list schedule: sources (Const, Parameter) first, then repeated sweeps in node order
@@ -268,6 +270,7 @@ class Executable_Network:
         G = self.ienet.G
         registry = self.ienet.ie.plugins.plugins
         times = []
+        self._recycle_events()
         for task in self.task_list:
             node = G.nodes[task]
             node_type = node['type']
@@ -276,9 +279,14 @@ class Executable_Network:
             if plugin is None:
                 print("ERROR: Operation '{}' (node={}) is not supported.".format(node_type, node['name']))
                 sys.exit(-1)
+            timed = self.device_timing is not None and (self.device_timing == 'all' or node_type in self.device_timing)
+            if timed:
+                ev0 = self._event().record()
             t0 = time.time()
             res = plugin.compute(node, inputs, kernel_type=self.kernel_type, debug=False)
             dt = time.time() - t0
+            if timed:
+                self._timed.append((task, node_type, node['name'], ev0, self._event().record()))
             times.append((task, node_type, node['name'], dt))
             if verbose:
                 print('{}, {}, {}, {}'.format(task, node_type, node['name'], dt))
@@ -291,6 +299,26 @@ class Executable_Network:
                 for port_id, data in res.items():
                     node['output'][port_id]['data'] = data
         self.last_node_times = times
+
+    # ---- device-side per-node timing (hipEvents on the compute stream; cf. the time.time() bracket :279-283)
+    def _event(self):
+        from . import device
+        pool = self.__dict__.setdefault('_event_pool', [])
+        return pool.pop() if pool else device.Event()
+
+    def _recycle_events(self):
+        pool = self.__dict__.setdefault('_event_pool', [])
+        for _, _, _, e0, e1 in self._timed:
+            pool.extend((e0, e1))
+        self._timed = []
+
+    def device_times_ms(self):
+        """[(node id, type, name, milliseconds)] for the nodes bracketed in the last run_tasks (synchronises)."""
+        out = []
+        for task, node_type, name, e0, e1 in self._timed:
+            e1.synchronize()
+            out.append((task, node_type, name, e0.elapsed_ms(e1)))
+        return out
 
     def infer(self, inputs: dict, verbose: bool = False) -> dict:
         G = self.ienet.G

@@ -1,0 +1,20 @@
+#!/bin/bash
+# GPU-box routine: parity tests -> smoke -> bench -> rocprof stats.  Stops at the first step that is
+# killed by its timeout (never start another GPU step after a hang).
+set -u
+mkdir -p gpurun_out
+step() {  # step <seconds> <logfile> <cmd...>
+    local secs=$1 log=$2; shift 2
+    echo "=== $* (limit ${secs}s)" | tee -a gpurun_out/ci.log
+    timeout -k 10 "$secs" "$@" > "gpurun_out/$log" 2>&1
+    local rc=$?
+    echo "=== rc=$rc" | tee -a gpurun_out/ci.log
+    tail -n 25 "gpurun_out/$log"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT - stopping" | tee -a gpurun_out/ci.log; exit 99; fi
+    return $rc
+}
+: > gpurun_out/ci.log
+step 900 test_gpu.log python -m pytest tests -m gpu -q -x --timeout=600 ${PYTEST_EXTRA:-}
+step 300 smoke.log python -c "import __graft_entry__ as g; g.smoke()"
+step 600 bench.log python bench.py --steps ${BENCH_STEPS:-5} --warmup 2
+exit 0

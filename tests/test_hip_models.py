@@ -1,0 +1,122 @@
+"""Whole models through the HIP plugins: against the reference's recorded outputs, against the oracle at
+small batch, and through size-independent properties at the BASELINE batch sizes.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import GOLDEN, assert_close, build_network, infer_one, layer_sums
+
+pytestmark = pytest.mark.gpu
+
+HIP = 'pyopenvino_amd.op_plugins'
+ORACLE = 'oracle.op_plugins'
+
+
+def test_mnist_real_weights_vs_reference(hip):
+    """BASELINE config 1: models/mnist, mnist2.png -> the README.md:69-72 / integrity_test.py:57 answer."""
+    z = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))
+    _, net, ex = build_network(HIP, 'mnist')
+    got = infer_one(ex, net, z['images'][0:1])
+    assert_close(got, z['out'][0:1], helpers.REL_TOL, 'mnist2')
+    assert list(np.argsort(got[0])[::-1][:3]) == [2, 0, 1]
+    sums = layer_sums(net)
+    for nid, want in zip(z['layer_ids'], z['layer_sums']):
+        assert abs(sums[int(nid)] - want) <= 1e-4 * max(1.0, abs(want)), 'layer {}'.format(nid)
+    _, net8, ex8 = build_network(HIP, 'mnist', batch=8)
+    assert_close(infer_one(ex8, net8, z['images']), z['out'], helpers.REL_TOL, 'mnist batch 8')
+
+
+def test_mnist_batch64_vs_oracle(hip):
+    """BASELINE config 2: mnist batch 64 (mnist2 / mnist7 alternating + seeded noise images)."""
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))
+    imgs = [z['images'][i % 2:i % 2 + 1] if i < 16 else synth.uniform_pixels(900 + i, (1, 1, 28, 28)) for i in range(64)]
+    x = np.concatenate(imgs, 0)
+    _, net, ex = build_network(HIP, 'mnist', batch=64)
+    got = infer_one(ex, net, x)
+    _, onet, oex = build_network(ORACLE, 'mnist', batch=64)
+    want = infer_one(oex, onet, x)
+    assert_close(got, want, helpers.REL_TOL, 'mnist batch 64')
+    assert_close(got[0:1], z['out'][0:1], helpers.REL_TOL, 'row 0 == reference mnist2')
+    assert np.allclose(got.sum(axis=1), 1.0, atol=1e-5)
+    # second infer on the same executable network (buffers recycled through the pool): same answer
+    assert np.array_equal(infer_one(ex, net, x), got)
+
+
+@pytest.mark.parametrize('model,fname,shape', [('googlenet-v1', 'googlenet_e2e.npz', (3, 224, 224)),
+                                               ('mnist_bn', 'mnist_bn_e2e.npz', (1, 28, 28))])
+def test_synthetic_models_vs_reference(hip, model, fname, shape):
+    """GoogLeNet / mnist_bn on seeded synthetic weights: batch 2 on the GPU vs two N=1 runs of the reference."""
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, fname))
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, model + '.xml'), int(z['weight_seed']))
+    x = np.concatenate([synth.uniform_pixels(int(s), (1,) + shape) for s in z['image_seeds']], 0)
+    _, net, ex = build_network(HIP, model, weights=blob, batch=x.shape[0])
+    got = infer_one(ex, net, x)
+    assert_close(got, z['out'], helpers.REL_TOL, model)
+    assert np.array_equal(np.argmax(got, axis=1), np.argmax(z['out'], axis=1))
+    # per-layer checksums of image 0 (batch 1 run)
+    _, net1, ex1 = build_network(HIP, model, weights=blob)
+    infer_one(ex1, net1, x[0:1])
+    sums = layer_sums(net1)
+    worst = 0.0
+    for nid, want in zip(z['layer_ids'], z['layer_sums']):
+        worst = max(worst, abs(sums[int(nid)] - want) / max(1.0, abs(want)))
+    assert worst <= 1e-4, 'per-layer checksum drift {:.2e}'.format(worst)
+
+
+def test_googlenet_layerwise_vs_oracle(hip):
+    """Every node of GoogLeNet at batch 3: HIP output vs the oracle's output of the SAME node."""
+    from pyopenvino_amd import synth
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), 1234)
+    x = np.concatenate([synth.uniform_pixels(40 + i, (1, 3, 224, 224)) for i in range(3)], 0)
+    _, net, ex = build_network(HIP, 'googlenet-v1', weights=blob, batch=3)
+    _, onet, oex = build_network(ORACLE, 'googlenet-v1', weights=blob, batch=3)
+    infer_one(ex, net, x)
+    infer_one(oex, onet, x)
+    worst = ('', 0.0)
+    for nid in net.G.nodes:
+        node = net.G.nodes[nid]
+        if node['type'] in ('Const', 'Parameter', 'Result'):
+            continue
+        for port, p in node['output'].items():
+            got = np.asarray(p['data'])
+            want = np.asarray(onet.G.nodes[nid]['output'][port]['data'])
+            err = helpers.rel_err(got, want)
+            if err > worst[1]:
+                worst = ('{} {}'.format(nid, node['name']), err)
+            assert err <= helpers.REL_TOL, 'node {} ({}): {:.2e}'.format(nid, node['name'], err)
+    print('worst layer', worst)
+
+
+def test_googlenet_batch256_properties(hip):
+    """BASELINE config 3 at full size (no CPU oracle run at this size): rows sum to 1; images 0-1 of the
+    256-batch equal the reference's N=1 answers; a permuted batch gives permuted rows (independence)."""
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, 'googlenet_e2e.npz'))
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), int(z['weight_seed']))
+    B = 256
+    x = synth.uniform_pixels(4242, (B, 3, 224, 224))
+    for i, s in enumerate(z['image_seeds']):
+        x[i] = synth.uniform_pixels(int(s), (1, 3, 224, 224))[0]
+    _, net, ex = build_network(HIP, 'googlenet-v1', weights=blob, batch=B)
+    got = infer_one(ex, net, x)
+    assert got.shape == (B, 1000) and np.isfinite(got).all()
+    assert np.allclose(got.sum(axis=1), 1.0, atol=2e-5)
+    assert_close(got[:2], z['out'], helpers.REL_TOL, 'rows 0-1 vs reference')
+    perm = np.roll(np.arange(B), 37)
+    got_p = infer_one(ex, net, np.ascontiguousarray(x[perm]))
+    assert_close(got_p, got[perm], 1e-5, 'permuted batch')
+
+
+def test_device_resident_input_and_result_gather_world1(hip):
+    """A DeviceTensor handed to infer() is used in place (bench path); world==1 comm is the identity."""
+    from pyopenvino_amd import shard
+    z = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))
+    _, net, ex = build_network(HIP, 'mnist', batch=8)
+    ex.comm = shard.BatchShardComm(shard.SingleGroup())
+    xd = hip.DeviceTensor.from_numpy(z['images'])
+    got = infer_one(ex, net, xd)
+    assert_close(got, z['out'], helpers.REL_TOL, 'device-resident input')

@@ -1,0 +1,271 @@
+"""HIP plugins (through the C ABI) against the reference's recorded outputs and against the oracle on
+larger seeded shapes.  GPU only."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import assert_bit_exact, assert_close, first_out, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_plugin(type_):
+    return importlib.import_module('pyopenvino_amd.op_plugins.' + type_)
+
+
+def oracle_plugin(type_):
+    return importlib.import_module('oracle.op_plugins.' + type_)
+
+
+def check(node, inputs, want, what):
+    got = first_out(hip_plugin(node['type']).compute(node, inputs, kernel_type='hip', debug=False))
+    if node['type'] in helpers.BIT_EXACT:
+        assert_bit_exact(got, np.asarray(want, dtype=np.float32), what)
+        return 0.0
+    return assert_close(got, want, helpers.REL_TOL, what)
+
+
+@pytest.mark.parametrize('path', helpers.op_case_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_hip_op_matches_reference_fixture(hip, path):
+    node, inputs, want = load_case(path)
+    err = check(node, inputs, want, node['name'])
+    # the fp32 kernels are expected far inside the stated 1e-4: flag drift early
+    assert err <= 2e-5, '{}: {:.2e}'.format(node['name'], err)
+
+
+def make_node(type_, ins, data=None):
+    node = {'name': type_ + '_seeded', 'type': type_, 'version': 'opset1'}
+    if data:
+        node['data'] = dict(data)
+    node['input'] = {i: {'precision': 'I64' if a.dtype == np.int64 else 'FP32', 'dims': tuple(a.shape)} for i, a in enumerate(ins)}
+    node['output'] = {len(ins): {'precision': 'FP32', 'dims': ()}}
+    return node
+
+
+def vs_oracle(type_, ins, data=None, what=''):
+    node = make_node(type_, ins, data)
+    inputs = {i: a for i, a in enumerate(ins)}
+    want = first_out(oracle_plugin(type_).compute(node, inputs, kernel_type='special', debug=False))
+    return check(node, inputs, want, what or type_)
+
+
+def rnd(seed, shape, scale=1.0, shift=0.0):
+    from pyopenvino_amd import synth
+    return (synth.normal(seed, 99, int(np.prod(shape))) * scale + shift).astype(np.float32).reshape(shape)
+
+
+def conv_data(strides, pb, pe, auto_pad='explicit'):
+    return {'strides': '{}, {}'.format(*strides), 'dilations': '1, 1', 'pads_begin': '{}, {}'.format(*pb),
+            'pads_end': '{}, {}'.format(*pe), 'auto_pad': auto_pad}
+
+
+def pool_data(kernel, strides, pb, pe, rounding, auto_pad='explicit'):
+    return {'kernel': '{}, {}'.format(*kernel), 'strides': '{}, {}'.format(*strides), 'pads_begin': '{}, {}'.format(*pb),
+            'pads_end': '{}, {}'.format(*pe), 'rounding_type': rounding, 'auto_pad': auto_pad}
+
+
+# GoogLeNet / mnist / SSD layer shapes at a small batch: every tile configuration of the conv kernel
+CONV_SHAPES = [
+    # (x shape, w shape, strides, pads_begin, pads_end)
+    ((2, 3, 224, 224), (64, 3, 7, 7), (2, 2), (3, 3), (3, 3)),     # conv1/7x7_s2
+    ((3, 64, 56, 56), (64, 64, 1, 1), (1, 1), (0, 0), (0, 0)),      # conv2/3x3_reduce
+    ((3, 64, 56, 56), (192, 64, 3, 3), (1, 1), (1, 1), (1, 1)),     # conv2/3x3
+    ((5, 192, 28, 28), (16, 192, 1, 1), (1, 1), (0, 0), (0, 0)),    # 3a/5x5_reduce (K_out 16)
+    ((5, 16, 28, 28), (32, 16, 5, 5), (1, 1), (2, 2), (2, 2)),      # 3a/5x5
+    ((4, 480, 14, 14), (96, 480, 1, 1), (1, 1), (0, 0), (0, 0)),    # 4a/3x3_reduce
+    ((4, 96, 14, 14), (208, 96, 3, 3), (1, 1), (1, 1), (1, 1)),     # 4a/3x3 (K_out 208)
+    ((9, 832, 7, 7), (384, 832, 1, 1), (1, 1), (0, 0), (0, 0)),     # 5b/1x1
+    ((9, 192, 7, 7), (384, 192, 3, 3), (1, 1), (1, 1), (1, 1)),     # 5b/3x3
+    ((7, 48, 7, 7), (128, 48, 5, 5), (1, 1), (2, 2), (2, 2)),       # 5b/5x5
+    ((6, 1, 28, 28), (32, 1, 3, 3), (1, 1), (0, 0), (0, 0)),        # mnist conv 1 (C=1)
+    ((6, 64, 5, 5), (64, 64, 3, 3), (1, 1), (0, 0), (0, 0)),        # mnist conv 3
+    ((2, 3, 300, 300), (32, 3, 3, 3), (2, 2), (0, 0), (1, 1)),      # SSD Conv2d_0 (asymmetric pad)
+    ((1, 24, 14, 14), (24, 24, 1, 1), (1, 1), (0, 0), (0, 0)),      # tiny: fewer pixels than one tile
+]
+
+
+@pytest.mark.parametrize('xs,ws,st,pb,pe', CONV_SHAPES, ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_conv_model_shapes_vs_oracle(hip, xs, ws, st, pb, pe):
+    fan_in = ws[1] * ws[2] * ws[3]
+    x = rnd(sum(xs), xs)
+    w = rnd(sum(ws) + 1, ws, (2.0 / fan_in) ** 0.5)
+    vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'conv {} * {}'.format(xs, ws))
+
+
+def test_conv_every_tile_config(hip, monkeypatch):
+    """Force each (BM, BN) instantiation on one shape that has ragged edges in both tile dimensions."""
+    x = rnd(1, (3, 20, 13, 11))
+    w = rnd(2, (150, 20, 3, 3), 0.1)
+    for tile in ('32x128', '32x256', '64x128', '64x256', '128x128', '128x256'):
+        monkeypatch.setenv('PVHIP_CONV_TILE', tile)
+        vs_oracle('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)), 'tile ' + tile)
+
+
+def test_conv_identity_weights_asymmetric_input(hip):
+    """A = I check with asymmetric data: catches a transposed accumulator map (guide section 3)."""
+    c = 40
+    x = (np.arange(2 * c * 6 * 7, dtype=np.float32).reshape(2, c, 6, 7) % 251) - 100.0
+    w = np.zeros((c, c, 1, 1), dtype=np.float32)
+    w[np.arange(c), np.arange(c), 0, 0] = 1.0
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (0, 0), (0, 0)))
+    got = first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w}))
+    assert_bit_exact(got, x, 'identity 1x1 convolution')
+
+
+def test_conv_linearity_full_size_layer(hip):
+    """Size-independent property at a BASELINE-size layer (batch 256): conv(a*x1 + x2) == a*conv(x1) + conv(x2)."""
+    xs, ws = (256, 96, 14, 14), (208, 96, 3, 3)
+    x1, x2 = rnd(11, xs), rnd(12, xs)
+    w = rnd(13, ws, (2.0 / (96 * 9)) ** 0.5)
+    data = conv_data((1, 1), (1, 1), (1, 1))
+    run = lambda x: first_out(hip_plugin('Convolution').compute(make_node('Convolution', [x, w], data), {0: x, 1: w}))
+    y1, y2, y3 = run(x1), run(x2), run(2.0 * x1 + x2)
+    assert_close(y3, 2.0 * y1 + y2, 1e-5, 'linearity')
+    # and a corner of it against the oracle
+    want = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x1[:2], w], data), {0: x1[:2], 1: w}))
+    assert_close(y1[:2], want, helpers.REL_TOL, 'first two images vs oracle')
+
+
+def test_conv_error_behaviour_matches_reference(hip):
+    """17x17 stride 2 'same_upper' with pads (0,0)/(1,1): the reference's im2col raises ValueError
+    (window exceeds the padded input, Convolution.py:68); so do we."""
+    x, w = rnd(1, (1, 3, 17, 17)), rnd(2, (8, 3, 3, 3))
+    node = make_node('Convolution', [x, w], conv_data((2, 2), (0, 0), (1, 1), 'same_upper'))
+    with pytest.raises(ValueError):
+        hip_plugin('Convolution').compute(node, {0: x, 1: w})
+    with pytest.raises(AssertionError):   # dtype / dims validation, Convolution.py:154-157
+        bad = make_node('Convolution', [x, w], conv_data((1, 1), (0, 0), (0, 0)))
+        bad['input'][0]['dims'] = (1, 3, 16, 16)
+        hip_plugin('Convolution').compute(bad, {0: x, 1: w})
+
+
+@pytest.mark.parametrize('m,n,k', [(1, 10, 64), (64, 64, 576), (256, 1000, 1024), (3, 513, 100), (65, 1, 17)])
+def test_matmul_vs_oracle(hip, m, n, k):
+    a, b = rnd(m + n, (m, k)), rnd(k, (n, k), (2.0 / k) ** 0.5)
+    vs_oracle('MatMul', [a, b], {'transpose_a': 'false', 'transpose_b': 'true'}, 'matmul {}x{}x{}'.format(m, n, k))
+    vs_oracle('MatMul', [np.ascontiguousarray(a.T), np.ascontiguousarray(b.T)], {'transpose_a': 'true', 'transpose_b': 'false'},
+              'matmul^T {}x{}x{}'.format(m, n, k))
+
+
+POOL_CASES = [
+    ((4, 64, 112, 112), (3, 3), (2, 2), (0, 0), (0, 0), 'ceil'),
+    ((4, 192, 28, 28), (3, 3), (1, 1), (1, 1), (1, 1), 'ceil'),
+    ((9, 832, 7, 7), (3, 3), (1, 1), (1, 1), (1, 1), 'ceil'),
+    ((3, 832, 14, 14), (3, 3), (2, 2), (0, 0), (0, 0), 'ceil'),
+    ((8, 32, 26, 26), (2, 2), (2, 2), (0, 0), (0, 0), 'floor'),
+    ((2, 3, 11, 9), (3, 2), (2, 3), (1, 0), (0, 2), 'ceil'),
+]
+
+
+@pytest.mark.parametrize('xs,k,s,pb,pe,rounding', POOL_CASES, ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_maxpool_vs_oracle_bit_exact(hip, xs, k, s, pb, pe, rounding):
+    vs_oracle('MaxPool', [rnd(sum(xs), xs, 1.0, -0.7)], pool_data(k, s, pb, pe, rounding))
+
+
+def test_maxpool_nan_propagates(hip):
+    x = rnd(5, (1, 2, 6, 6))
+    x[0, 1, 2, 3] = np.nan
+    vs_oracle('MaxPool', [x], pool_data((3, 3), (1, 1), (1, 1), (1, 1), 'ceil'))
+
+
+def test_avgpool_googlenet_shape(hip):
+    vs_oracle('AvgPool', [rnd(3, (6, 1024, 7, 7))], pool_data((7, 7), (1, 1), (0, 0), (0, 0), 'ceil'))
+
+
+@pytest.mark.parametrize('shape', [(1,), (3,), (4,), (5, 7), (2, 3, 5, 7), (8, 64, 56, 56), (1, 1, 1, 1023), (2, 1048577)])
+def test_unary_sizes_bit_exact(hip, shape):
+    x = rnd(sum(shape), shape, 3.0)
+    vs_oracle('ReLU', [x])
+    vs_oracle('Clamp', [x], {'min': '0', 'max': '6'})
+    vs_oracle('Sigmoid', [x])
+
+
+def test_unary_empty_tensor(hip):
+    x = np.zeros((0, 4), dtype=np.float32)
+    node = make_node('ReLU', [x])
+    assert first_out(hip_plugin('ReLU').compute(node, {0: x})).shape == (0, 4)
+
+
+BCAST = [((4, 64, 56, 56), (1, 64, 1, 1)), ((6, 1000), (1, 1000)), ((3, 5, 7, 7), (1, 5, 1, 1)), ((2, 3, 4, 5), (1, 1, 1, 1)),
+         ((2, 3, 4, 5), (2, 3, 4, 5)), ((2, 3, 4, 5), (1, 3, 1, 5)), ((7, 13), (1, 13)), ((5, 3, 7, 7), (5, 1, 1, 1)),
+         ((2, 3, 4, 5), (5,)), ((3, 1, 49), (1, 1, 49))]
+
+
+@pytest.mark.parametrize('a_shape,b_shape', BCAST, ids=str)
+def test_add_mul_broadcast_bit_exact(hip, a_shape, b_shape):
+    a, b = rnd(1, a_shape), rnd(2, b_shape)
+    vs_oracle('Add', [a, b], {'auto_broadcast': 'numpy'})
+    vs_oracle('Multiply', [a, b], {'auto_broadcast': 'numpy'})
+    vs_oracle('Multiply', [b, a], {'auto_broadcast': 'numpy'})
+
+
+def test_add_rejects_non_broadcastable(hip):
+    a, b = rnd(1, (2, 3)), rnd(2, (2, 4))
+    with pytest.raises(ValueError):
+        hip_plugin('Add').compute(make_node('Add', [a, b]), {0: a, 1: b})
+
+
+@pytest.mark.parametrize('rows,cols', [(1, 10), (64, 10), (256, 1000), (3, 2049), (2, 5000)])
+def test_softmax_rows(hip, rows, cols):
+    x = rnd(rows + cols, (rows, cols), 4.0)
+    vs_oracle('SoftMax', [x], {'axis': '1'})
+    node = make_node('SoftMax', [x], {'axis': '1'})
+    got = first_out(hip_plugin('SoftMax').compute(node, {0: x}))
+    assert np.allclose(got.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_softmax_overflow_like_reference(hip):
+    """No max shift (SoftMax.py:12): logits > 88 overflow to inf/inf = NaN in the reference; same here."""
+    x = np.array([[100.0, 1.0, 2.0]], dtype=np.float32)
+    vs_oracle('SoftMax', [x], {'axis': '1'})
+
+
+@pytest.mark.parametrize('shape,size', [((4, 64, 56, 56), 5), ((2, 192, 28, 28), 5), ((1, 7, 5, 3), 5), ((2, 9, 4, 4), 3), ((1, 6, 3, 3), 4)])
+def test_lrn_vs_oracle(hip, shape, size):
+    data = {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': str(size)}
+    vs_oracle('LRN', [rnd(sum(shape), shape, 40.0), np.array([1], dtype=np.int64)], data)
+
+
+def test_lrn_generic_beta(hip):
+    data = {'alpha': '0.002', 'beta': '0.6', 'bias': '1.5', 'size': '5'}
+    vs_oracle('LRN', [rnd(3, (2, 10, 6, 6), 10.0), np.array([1], dtype=np.int64)], data)
+
+
+def test_concat_inception_shapes_bit_exact(hip):
+    parts = [rnd(i, (3, c, 7, 7)) for i, c in enumerate((384, 384, 128, 128))]
+    vs_oracle('Concat', parts, {'axis': '1'})
+    parts = [rnd(i, (2, c, 3)) for i, c in enumerate((5, 1, 7))]
+    vs_oracle('Concat', parts, {'axis': '1'})
+    parts = [rnd(i, (2, 3, c)) for i, c in enumerate((5, 1, 7))]
+    vs_oracle('Concat', parts, {'axis': '2'})
+    vs_oracle('Concat', [rnd(1, (2, 3)), rnd(2, (4, 3))], {'axis': '0'})
+
+
+def test_transpose_reshape(hip):
+    x = rnd(1, (8, 64, 3, 3))
+    vs_oracle('Transpose', [x, np.array([0, 2, 3, 1], dtype=np.int64)])
+    vs_oracle('Transpose', [rnd(2, (3, 4, 5)), np.array([2, 0, 1], dtype=np.int64)])
+    vs_oracle('Reshape', [x, np.array([-1, 576], dtype=np.int64)], {'special_zero': 'false'})
+    vs_oracle('Reshape', [x, np.array([0, -1], dtype=np.int64)], {'special_zero': 'true'})
+
+
+@pytest.mark.parametrize('xs,st,pb,pe', [((2, 32, 150, 150), (1, 1), (1, 1), (1, 1)), ((2, 64, 150, 150), (2, 2), (0, 0), (1, 1)),
+                                         ((3, 512, 19, 19), (2, 2), (1, 1), (1, 1)), ((2, 1024, 10, 10), (1, 1), (1, 1), (1, 1))])
+def test_depthwise_conv_vs_oracle(hip, xs, st, pb, pe):
+    w = rnd(7, (xs[1], 1, 1, 3, 3), 0.4)
+    vs_oracle('GroupConvolution', [rnd(sum(xs), xs), w], conv_data(st, pb, pe, 'same_upper'))
+
+
+def test_device_tensor_roundtrip_and_pool_reuse(hip):
+    x = rnd(1, (5, 7, 3))
+    t = hip.DeviceTensor.from_numpy(x)
+    assert t.shape == x.shape and t.dtype == np.float32
+    assert_bit_exact(np.asarray(t), x)
+    assert_bit_exact(np.asarray(t.reshape(35, -1)), x.reshape(35, 3))
+    ptr = t.ptr
+    del t
+    t2 = hip.DeviceTensor.empty((5, 7, 3))
+    assert t2.ptr == ptr, 'a freed block of the same size is reused'
