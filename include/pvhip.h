@@ -123,13 +123,14 @@ int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int
 
 /* Convolution.py:57-87 im2col + kernel_Convolution_im2col ("special"), as an implicit GEMM:
  *   y[n,k,oy,ox] = sum_{c,r,s} xpad[n,c,oy*sh+r,ox*sw+s] * w[k,c,r,s]      (dilation ignored, as :72-87 does)
- * Step 1 (once per weight tensor): repack OIHW weights to the K-major panel the kernel streams.
- *   wpack must hold pvhip_conv2d_pack_elems(k_out, c, kh, kw) floats.
+ * Step 1 (once per weight tensor and input extent h x w): repack OIHW weights to the K-major panel the
+ *   kernel streams and build the per-reduction-row gather table (byte offset of (c, r, s) in an h x w
+ *   image).  wpack must hold pvhip_conv2d_pack_elems(k_out, c, kh, kw) floats.
  * Step 2: the convolution proper.  (oh, ow) computed by the caller per Convolution.py:21-49.
  *   bias (optional, may be NULL): per-output-channel value added in the epilogue; relu != 0 applies
  *   the ReLU.py:11 rule in the epilogue (used only by the fused Convolution->Add->ReLU path).     */
 size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw);
-int    pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw, int h, int w);
 int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
                         int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
                         int sh, int sw, int pad_top, int pad_left,

@@ -31,29 +31,54 @@ constexpr int kKoutAlign = 128;  // packed panel width is a multiple of this
 
 struct ConvArgs {
     const float* x;
-    const int*   ktab;  // [kred_pad] : (c << 16) | (r << 8) | s, or negative for a padding row
+    const int*   ktab;  // [2][kred_pad + 2*kBK] : byte offsets c*H*W + r*W + s, then bit indices r*kw + s
     const float* wp;    // [kred_pad][kout_pad]
     float*       y;
     const float* bias;  // optional [K]
     int N, C, H, W, K, OH, OW;
-    int sh, sw, pt, pl;
+    int sh, sw, pt, pl, kh, kw;
+    unsigned x_bytes;
     int kred_pad, kout_pad;
     int P;              // N*OH*OW
     int n_mtiles;
     int relu;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// One gather element of the im2col tile: returns x[n, c, ih0 + r, iw0 + s] or 0 for a padding cell.
+// koff / rs are the wave-uniform table entry of the reduction row (byte offset c*H*W + r*W + s, and
+// the bit index r*kw + s -- or (r << 8) | s on the compare path), `inb` is the lane's in-bounds bit
+// mask over (r, s), `xoff` the lane's byte offset of x[n, 0, ih0, iw0].  An out-of-bounds cell becomes
+// an out-of-range buffer offset (the hardware returns 0): no branch, no select on the data.
+template <bool kMask>
+__device__ __forceinline__ float gather_one(__amdgpu_buffer_rsrc_t xr, int koff, int rs, unsigned long long inb,
+                                            unsigned xoff, int ih0, int iw0, int H, int W) {
+    unsigned bit;
+    if (kMask) {
+        bit = (unsigned)(inb >> rs) & 1u;   // padding rows carry rs = 63, a bit that is never set
+    } else {
+        const int r = rs >> 8, s = rs & 0xff;   // padding rows carry r = 0x7fff
+        bit = (((unsigned)(ih0 + r) < (unsigned)H) & ((unsigned)(iw0 + s) < (unsigned)W)) ? 1u : 0u;
+    }
+    // The whole offset goes through the VGPR: the 32-bit wrap of xoff + koff is what makes a window that
+    // starts in the top/left padding (xoff "negative") land on the right element.  A padding cell gets
+    // the offset 2^31, which is >= num_records (the host checks x_bytes <= 2^31) and, unlike an all-ones
+    // offset, cannot wrap back into range when the address unit adds the access size.
+    const unsigned off = bit ? (xoff + (unsigned)koff) : 0x80000000u;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMask>
 __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
     static_assert(WAVES_M * WAVES_N == kBlock / kWave, "4 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TM >= 1 && TN >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of 32x32");
-    static_assert(BN % kWave == 0 && kBlock % BN == 0, "a wave gathers one reduction row");
-    constexpr int B_ROWS_PER_PASS = kBlock / BN;
-    constexpr int B_LOADS         = kBK / B_ROWS_PER_PASS;
-    constexpr int A_F4_TOTAL      = kBK * BM / 4;
-    constexpr int A_F4            = (A_F4_TOTAL + kBlock - 1) / kBlock;
+    static_assert(BN % kWave == 0 && kBlock % BN == 0, "a wave gathers whole reduction rows");
+    constexpr int B_LOADS    = kBK * BN / kBlock;   // reduction rows gathered per lane per stage
+    constexpr int A_F4_TOTAL = kBK * BM / 4;
+    constexpr int A_F4       = (A_F4_TOTAL + kBlock - 1) / kBlock;
+    constexpr int KK         = kBK / 2;             // MFMA steps per stage
+    static_assert(B_LOADS % KK == 0 || KK % B_LOADS == 0, "gather is spread over the MFMA steps");
 
     __shared__ __attribute__((aligned(16))) float As[2][kBK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK][BN];
@@ -79,8 +104,10 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
     const int OHW = a.OH * a.OW;
     const int HW  = a.H * a.W;
     const int pc  = tid % BN;
-    const int prow0 = __builtin_amdgcn_readfirstlane(tid / BN);
-    int       ih0, iw0, xbase;
+    const int prow0 = __builtin_amdgcn_readfirstlane(tid / BN) * B_LOADS;  // first reduction row of this wave
+    int                ih0 = 0, iw0 = 0;
+    unsigned           xoff = 0;
+    unsigned long long inb  = 0;
     {
         const int gp = ptile * BN + pc;
         if (gp < a.P) {
@@ -90,53 +117,50 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
             const int ox  = rem - oy * a.OW;
             ih0           = oy * a.sh - a.pt;
             iw0           = ox * a.sw - a.pl;
-            xbase         = n * a.C * HW + ih0 * a.W + iw0;
+            xoff          = (unsigned)(n * a.C * HW + ih0 * a.W + iw0) * 4u;
+            if (kMask) {
+                for (int r = 0; r < a.kh; ++r)
+                    for (int s = 0; s < a.kw; ++s)
+                        if ((unsigned)(ih0 + r) < (unsigned)a.H && (unsigned)(iw0 + s) < (unsigned)a.W)
+                            inb |= 1ull << (r * a.kw + s);
+            }
         } else {
-            ih0 = INT_MIN / 2;  // every bounds test fails
-            iw0 = 0;
-            xbase = 0;
+            ih0 = INT_MIN / 2;  // every bounds test fails; the mask stays 0
         }
     }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
 
     float  breg[B_LOADS];
     float4 areg[A_F4];
+    int    tko[B_LOADS], trs[B_LOADS];   // table entries of the NEXT stage to gather (scalar registers)
+    const int* __restrict__ tab_rs = a.ktab + a.kred_pad + 2 * kBK;
 
-    auto load_tiles = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) {
-            const int kg  = kt * kBK + prow0 + j * B_ROWS_PER_PASS;  // wave-uniform
-            const int ent = a.ktab[kg];
-            const int c   = (ent >> 16) & 0x7fff;
-            const int r   = (ent >> 8) & 0xff;
-            const int s   = ent & 0xff;
-            const bool ok = (ent >= 0) && ((unsigned)(ih0 + r) < (unsigned)a.H) && ((unsigned)(iw0 + s) < (unsigned)a.W);
-            const int idx = ok ? (xbase + c * HW + r * a.W + s) : 0;
-            const float v = a.x[idx];
-            breg[j]       = ok ? v : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < A_F4; ++j) {
-            const int f = tid + j * kBlock;
-            if (A_F4_TOTAL % kBlock == 0 || f < A_F4_TOTAL) {
-                const int arow = f / (BM / 4);
-                const int ac4  = f % (BM / 4);
-                areg[j] = *reinterpret_cast<const float4*>(a.wp + (size_t)(kt * kBK + arow) * a.kout_pad + m0 + ac4 * 4);
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) Bs[buf][prow0 + j * B_ROWS_PER_PASS][pc] = breg[j];
-#pragma unroll
-        for (int j = 0; j < A_F4; ++j) {
-            const int f = tid + j * kBlock;
-            if (A_F4_TOTAL % kBlock == 0 || f < A_F4_TOTAL) {
-                const int arow = f / (BM / 4);
-                const int ac4  = f % (BM / 4);
-                *reinterpret_cast<float4*>(&As[buf][arow][ac4 * 4]) = areg[j];
-            }
-        }
-    };
+#define PV_LOAD_ENT(kt_)                                                              \
+    {                                                                                 \
+        const int* __restrict__ tp = a.ktab + (kt_) * kBK + prow0;                    \
+        const int* __restrict__ tq = tab_rs + (kt_) * kBK + prow0;                    \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j) { tko[j] = tp[j]; trs[j] = tq[j]; } \
+    }
+#define PV_GATHER(j_) breg[j_] = gather_one<kMask>(xr, tko[j_], trs[j_], inb, xoff, ih0, iw0, a.H, a.W)
+#define PV_LOAD_A(kt_)                                                                \
+    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                \
+        const int f = tid + j * kBlock;                                               \
+        if (A_F4_TOTAL % kBlock == 0 || f < A_F4_TOTAL) {                             \
+            const int arow = f / (BM / 4), ac4 = f % (BM / 4);                        \
+            areg[j] = *reinterpret_cast<const float4*>(a.wp + (size_t)((kt_) * kBK + arow) * a.kout_pad + m0 + ac4 * 4); \
+        }                                                                             \
+    }
+#define PV_STORE_TILES(buf_)                                                          \
+    {                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j) Bs[buf_][prow0 + j][pc] = breg[j]; \
+        _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                            \
+            const int f = tid + j * kBlock;                                           \
+            if (A_F4_TOTAL % kBlock == 0 || f < A_F4_TOTAL) {                         \
+                const int arow = f / (BM / 4), ac4 = f % (BM / 4);                    \
+                *reinterpret_cast<float4*>(&As[buf_][arow][ac4 * 4]) = areg[j];       \
+            }                                                                         \
+        }                                                                             \
+    }
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -152,15 +176,24 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
     const int b_col = wn * WN + l31;
 
     const int nk = a.kred_pad / kBK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int  buf  = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) load_tiles(kt + 1);
+    // prologue: stage 0 into LDS buffer 0; table entries of stage 1 into scalar registers
+    PV_LOAD_ENT(0);
 #pragma unroll
-        for (int kk = 0; kk < kBK / 2; ++kk) {
+    for (int j = 0; j < B_LOADS; ++j) PV_GATHER(j);
+    PV_LOAD_A(0);
+    PV_STORE_TILES(0);
+    PV_LOAD_ENT(1);   // the table has one spare stage of padding rows at its end
+    __syncthreads();
+
+    // The loop body has no conditionals: the last iteration gathers and stages one stage past the end
+    // (table rows there are padding rows -> the loads read as 0; the weight panel has one spare zero
+    // stage), which keeps every wait counter of the body exact.
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        PV_LOAD_A(kt + 1);
+        // MFMA steps of stage kt with the gather of stage kt+1 spread between them
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
             float af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = As[buf][2 * kk + lh][a_col + i * 32];
@@ -171,10 +204,21 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (B_LOADS >= KK) {
+#pragma unroll
+                for (int g = 0; g < B_LOADS / KK; ++g) PV_GATHER(kk * (B_LOADS / KK) + g);
+            } else if (kk % (KK / B_LOADS) == 0) {
+                PV_GATHER(kk / (KK / B_LOADS));
+            }
         }
-        if (more) store_tiles(buf ^ 1);
+        PV_LOAD_ENT(kt + 2);   // consumed one whole stage later
+        PV_STORE_TILES(buf ^ 1);
         __syncthreads();
     }
+#undef PV_LOAD_ENT
+#undef PV_GATHER
+#undef PV_LOAD_A
+#undef PV_STORE_TILES
 
     // ---- epilogue: accumulator register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
 #pragma unroll
@@ -201,25 +245,30 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
 }
 
 __global__ __launch_bounds__(kBlock) void conv_pack_kernel(const float* __restrict__ w, int* __restrict__ ktab,
-                                                            float* __restrict__ wp, int K, int C, int kh, int kw,
-                                                            int kred, int kred_pad, int kout_pad) {
-    const size_t total  = (size_t)kred_pad * kout_pad;
+                                                            float* __restrict__ wp, int K, int C, int kh, int kw, int H,
+                                                            int W, int kred, int kred_pad, int kout_pad) {
+    const size_t total  = (size_t)(kred_pad + kBK) * kout_pad;   // includes the spare zero stage
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bool   mask   = kh * kw < 64;
+    const int    tab_n  = kred_pad + 2 * kBK;                    // two spare stages for the table prefetch
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int kr = (int)(e / kout_pad);
         const int ko = (int)(e % kout_pad);
         wp[e]        = (kr < kred && ko < K) ? w[(size_t)ko * kred + kr] : 0.0f;
-        if (ko == 0) {
-            int ent = INT_MIN;
-            if (kr < kred) {
-                const int s = kr % kw;
-                const int t = kr / kw;
-                const int r = t % kh;
-                const int c = t / kh;
-                ent         = (c << 16) | (r << 8) | s;
-            }
-            ktab[kr] = ent;
+    }
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)tab_n; e += stride) {
+        const int kr = (int)e;
+        int koff = 0, rs = mask ? 63 : (0x7fff << 8);
+        if (kr < kred) {
+            const int s = kr % kw;
+            const int t = kr / kw;
+            const int r = t % kh;
+            const int c = t / kh;
+            koff        = (c * H * W + r * W + s) * 4;
+            rs          = mask ? (r * kw + s) : ((r << 8) | s);
         }
+        ktab[kr]         = koff;
+        ktab[tab_n + kr] = rs;
     }
 }
 
@@ -259,8 +308,12 @@ inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0,
-                       state().stream, a);
+    if (a.kh * a.kw < 64)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0,
+                           state().stream, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock),
+                           0, state().stream, a);
 }
 
 }  // namespace
@@ -271,20 +324,20 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     if (k_out <= 0 || c <= 0 || kh <= 0 || kw <= 0) return 0;
     const size_t kred_pad = (size_t)round_up_int(c * kh * kw, kBK);
     const size_t kout_pad = (size_t)round_up_int(k_out, kKoutAlign);
-    return kred_pad + kred_pad * kout_pad;
+    return 2 * (kred_pad + 2 * kBK) + (kred_pad + kBK) * kout_pad;   // two tables (+2 spare stages), weight panel (+1 zero stage)
 }
 
-int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw) {
+int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw, int h, int w) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(w_oihw != nullptr && wpack != nullptr);
-    PVHIP_CHECK_ARG(k_out > 0 && c > 0 && kh > 0 && kw > 0);
-    if (c >= 32768 || kh >= 256 || kw >= 256)
-        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_pack_f32: C=%d kh=%d kw=%d outside table encoding", c, kh, kw);
+    PVHIP_CHECK_ARG(k_out > 0 && c > 0 && kh > 0 && kw > 0 && h > 0 && w > 0);
+    if (kh >= 256 || kw >= 256 || (unsigned long long)c * h * w >= (1ull << 29))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_pack_f32: C=%d kh=%d kw=%d H=%d W=%d outside table encoding", c, kh, kw, h, w);
     const int kred = c * kh * kw, kred_pad = round_up_int(kred, kBK), kout_pad = round_up_int(k_out, kKoutAlign);
     int*   ktab = reinterpret_cast<int*>(wpack);
-    float* wp   = wpack + kred_pad;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)kred_pad * kout_pad)), dim3(kBlock), 0, state().stream,
-                       w_oihw, ktab, wp, k_out, c, kh, kw, kred, kred_pad, kout_pad);
+    float* wp   = wpack + 2 * (kred_pad + 2 * kBK);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kBK) * kout_pad)), dim3(kBlock), 0, state().stream,
+                       w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }
@@ -294,11 +347,11 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && k_out > 0 && kh > 0 && kw > 0 && oh >= 0 && ow >= 0);
     PVHIP_CHECK_ARG(sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0);
-    if (c >= 32768 || kh >= 256 || kw >= 256)
-        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f32: C=%d kh=%d kw=%d outside table encoding", c, kh, kw);
+    if (kh >= 256 || kw >= 256)
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f32: kh=%d kw=%d outside table encoding", kh, kw);
     const unsigned long long in_e = (unsigned long long)n * c * h * w, out_e = (unsigned long long)n * k_out * oh * ow;
-    if (in_e >= (1ull << 31) || out_e >= (1ull << 31))
-        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f32: tensor exceeds 2^31 elements");
+    if (in_e >= (1ull << 29) || out_e >= (1ull << 31))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f32: input exceeds 2^29 elements (buffer offsets below 2^31) or output 2^31");
     if (out_e == 0) return PVHIP_OK;
     PVHIP_CHECK_ARG(x != nullptr && wpack != nullptr && y != nullptr);
 
@@ -307,11 +360,12 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.kout_pad = round_up_int(k_out, kKoutAlign);
     a.x        = x;
     a.ktab     = reinterpret_cast<const int*>(wpack);
-    a.wp       = wpack + a.kred_pad;
+    a.wp       = wpack + 2 * (a.kred_pad + 2 * kBK);
     a.y        = y;
     a.bias     = bias;
     a.N = n; a.C = c; a.H = h; a.W = w; a.K = k_out; a.OH = oh; a.OW = ow;
-    a.sh = sh; a.sw = sw; a.pt = pad_top; a.pl = pad_left;
+    a.sh = sh; a.sw = sw; a.pt = pad_top; a.pl = pad_left; a.kh = kh; a.kw = kw;
+    a.x_bytes = (unsigned)(in_e * 4ull);
     a.P    = n * oh * ow;
     a.relu = relu;
 

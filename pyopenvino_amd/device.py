@@ -59,7 +59,7 @@ SIGNATURES = {
     'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
-    'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 4),
+    'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
     'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int]),
     'pvhip_dwconv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 12),
     'pvhip_comm_unique_id': (_c.c_int, [_c.c_void_p]),

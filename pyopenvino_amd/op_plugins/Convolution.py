@@ -19,17 +19,18 @@ def calc_output_shape(input_dim, kernel_dim, strides, pads_begin, pads_end, roun
                                           rounding_type, auto_pad, same_means_input=False) for i in (0, 1))
 
 
-def packed_weights(node: dict, w) -> 'dev.DeviceTensor':
-    """K-major weight panel for the kernel, built once per weight tensor and kept on the node (weights
-    are Const outputs: the same device block arrives on every infer)."""
+def packed_weights(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
+    """K-major weight panel + gather table for the kernel, built once per (weight tensor, input extent)
+    and kept on the node (weights are Const outputs: the same device block arrives on every infer)."""
     cached = node.get('_hip_wpack')
-    if cached is not None and cached[0] is w._block and cached[1] == w.shape:
+    key = (w.shape, h, wd)
+    if cached is not None and cached[0] is w._block and cached[1] == key:
         return cached[2]
     k, c, kh, kw = w.shape
     elems = dev.call('pvhip_conv2d_pack_elems', k, c, kh, kw)
     wpack = dev.DeviceTensor.empty((int(elems),))
-    dev.call('pvhip_conv2d_pack_f32', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wpack.ptr), k, c, kh, kw)
-    node['_hip_wpack'] = (w._block, w.shape, wpack)
+    dev.call('pvhip_conv2d_pack_f32', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wpack.ptr), k, c, kh, kw, h, wd)
+    node['_hip_wpack'] = (w._block, key, wpack)
     return wpack
 
 
@@ -45,7 +46,7 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, relu=
         raise ValueError('could not broadcast input array: window exceeds the padded input '
                          '({}x{} padded, kernel {}x{}, stride {}, output {}x{})'.format(hp, wp, kh, kw, strides, oh, ow))
     y = dev.DeviceTensor.empty((n, kn, oh, ow))
-    wpack = packed_weights(node, w)
+    wpack = packed_weights(node, w, h, wd)
     dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(y.ptr),
              n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
              ctypes.c_void_p(bias.ptr if bias is not None else 0), int(bool(relu)))
