@@ -68,7 +68,7 @@ __device__ __forceinline__ float gather_one(__amdgpu_buffer_rsrc_t xr, int koff,
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool kMask>
-__global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
     static_assert(WAVES_M * WAVES_N == kBlock / kWave, "4 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -78,7 +78,6 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
     constexpr int A_F4_TOTAL = kBK * BM / 4;
     constexpr int A_F4       = (A_F4_TOTAL + kBlock - 1) / kBlock;
     constexpr int KK         = kBK / 2;             // MFMA steps per stage
-    static_assert(B_LOADS % KK == 0 || KK % B_LOADS == 0, "gather is spread over the MFMA steps");
 
     __shared__ __attribute__((aligned(16))) float As[2][kBK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK][BN];
@@ -188,29 +187,43 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(ConvArgs a) {
     // The loop body has no conditionals: the last iteration gathers and stages one stage past the end
     // (table rows there are padding rows -> the loads read as 0; the weight panel has one spare zero
     // stage), which keeps every wait counter of the body exact.
+    //
+    // Order inside one stage (pinned with sched_barrier so the scheduler cannot sink the global loads
+    // behind the MFMAs, which would expose their whole latency before the LDS write):
+    //   1. LDS reads of the first MFMA step of stage kt          (latency hidden behind 2.)
+    //   2. all global loads of stage kt+1 (A panel + gather)      (in flight during 3.)
+    //   3. MFMA steps of stage kt, operands of step kk+1 read from LDS before the MFMAs of step kk
+    //   4. table prefetch for stage kt+2, LDS write of stage kt+1, barrier
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lh][a_col + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bs[buf][lh][b_col + j * 32];
         PV_LOAD_A(kt + 1);
-        // MFMA steps of stage kt with the gather of stage kt+1 spread between them
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) PV_GATHER(j);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            float af[TM], bf[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][2 * kk + lh][a_col + i * 32];
+                for (int i = 0; i < TM; ++i) af[nxt][i] = As[buf][2 * (kk + 1) + lh][a_col + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][2 * kk + lh][b_col + j * 32];
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[buf][2 * (kk + 1) + lh][b_col + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-            if (B_LOADS >= KK) {
-#pragma unroll
-                for (int g = 0; g < B_LOADS / KK; ++g) PV_GATHER(kk * (B_LOADS / KK) + g);
-            } else if (kk % (KK / B_LOADS) == 0) {
-                PV_GATHER(kk / (KK / B_LOADS));
-            }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            // emit this step as: LDS reads of step kk+1, then the MFMAs of step kk
+            if (kk + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         PV_LOAD_ENT(kt + 2);   // consumed one whole stage later
         PV_STORE_TILES(buf ^ 1);
         __syncthreads();
@@ -369,23 +382,17 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.P    = n * oh * ow;
     a.relu = relu;
 
-    // ---- tile selection: output-channel tile with the least padding (ties -> larger), pixel tile
-    // 256 unless that leaves fewer than two workgroups per CU.
-    int best_bm = 32, best_pad = round_up_int(k_out, 32);
-    for (int bm : {64, 128}) {
-        const int padded = round_up_int(k_out, bm);
-        if (padded <= best_pad) { best_pad = padded; best_bm = bm; }
-    }
-    int       bm = best_bm, bn = 256;
-    const char* env = getenv("PVHIP_CONV_TILE");  // "BMxBN" override for tuning experiments
+    // ---- tile selection (calibrated with scripts/tune_conv.py on the GoogLeNet shapes at batch 256):
+    // 128-pixel tiles; 64 output channels per tile when that wastes less than half a tile and still
+    // leaves >= 4 workgroups per CU, else 32.  PVHIP_CONV_TILE=BMxBN overrides (tuning runs only).
+    int bm = (k_out % 64 == 0 || k_out % 64 > 32) ? 64 : 32, bn = 128;
+    if (bm == 64 && (long)((a.P + 127) / 128) * ((k_out + 63) / 64) < 4 * kNumCU) bm = 32;
+    const char* env = getenv("PVHIP_CONV_TILE");
     if (env != nullptr) {
         int ebm = 0, ebn = 0;
         if (sscanf(env, "%dx%d", &ebm, &ebn) == 2 && (ebm == 32 || ebm == 64 || ebm == 128) && (ebn == 128 || ebn == 256)) {
             bm = ebm; bn = ebn;
         }
-    } else {
-        const long blocks256 = (long)((a.P + 255) / 256) * (best_pad / bm);
-        if (blocks256 < 2 * kNumCU) bn = 128;
     }
     a.n_mtiles       = (k_out + bm - 1) / bm;
     const int n_ptiles = (a.P + bn - 1) / bn;
