@@ -46,6 +46,87 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_kernel(const float* __restri
     }
 }
 
+// LDS-staged MaxPool: a workgroup owns G consecutive (n, c) planes.  Planes are contiguous in NCHW, so
+// the input of a group is ONE dense run of G*H*W floats: it is streamed into LDS with 16-byte loads
+// (every byte of the input is read from HBM exactly once, fully coalesced), the windows are then read
+// from LDS, and the outputs of the group -- again one dense run of G*OH*OW floats -- leave as 16-byte
+// stores.  np.max semantics: a NaN anywhere in the window (or a pad cell's 0.0) takes part.
+template <int KH, int KW>   // 0 = run-time extent
+__global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                PoolArgs a, int G) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int kh = KH ? KH : a.kh, kw = KW ? KW : a.kw;
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+    const int g0 = blockIdx.x * G;
+    const int gn = min(G, a.n_planes - g0);
+    const int n_in = gn * hw, n_out = gn * ohw;
+    const float* __restrict__ xin = x + (size_t)g0 * hw;
+    float* __restrict__ yout      = y + (size_t)g0 * ohw;
+
+    // ---- stream the group into LDS
+    if ((((size_t)g0 * hw) & 3) == 0) {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
+        float4* t4 = reinterpret_cast<float4*>(tile);
+        const int n4 = n_in >> 2;
+        for (int i = threadIdx.x; i < n4; i += kBlock) t4[i] = x4[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+    } else {
+        for (int i = threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+    }
+    __syncthreads();
+
+    // ---- windows from LDS; one lane produces 4 consecutive outputs of the group
+    const bool vec_out = ((((size_t)g0 * ohw) & 3) == 0);
+    for (int o = threadIdx.x * 4; o < n_out; o += kBlock * 4) {
+        int g   = o / ohw;
+        int rem = o - g * ohw;
+        int oy  = rem / a.ow;
+        int ox  = rem - oy * a.ow;
+        float res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float m      = -INFINITY;
+            bool  anynan = false;
+            if (o + q < n_out) {
+                const float* __restrict__ tp = tile + g * hw;
+                const int py0 = oy * a.sh, px0 = ox * a.sw;
+#pragma unroll
+                for (int ky = 0; ky < (KH ? KH : 1); ++ky) {
+                    for (int kyr = ky; kyr < kh; kyr += (KH ? KH : 1)) {   // run-time trip when KH == 0
+                        const int py = py0 + kyr;
+                        if (py < a.hp) {
+                            const int  iy     = py - a.pt;
+                            const bool row_in = (unsigned)iy < (unsigned)a.h;
+#pragma unroll
+                            for (int kx = 0; kx < (KW ? KW : 1); ++kx) {
+                                for (int kxr = kx; kxr < kw; kxr += (KW ? KW : 1)) {
+                                    const int px = px0 + kxr;
+                                    if (px < a.wp) {
+                                        const int ix = px - a.pl;
+                                        float     v  = 0.0f;
+                                        if (row_in && (unsigned)ix < (unsigned)a.w) v = tp[iy * a.w + ix];
+                                        anynan |= (v != v);
+                                        m = fmaxf(m, v);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            res[q] = anynan ? NAN : m;
+            if (++ox == a.ow) { ox = 0; if (++oy == a.oh) { oy = 0; ++g; } }
+        }
+        if (vec_out && o + 3 < n_out) {
+            *reinterpret_cast<float4*>(yout + o) = make_float4(res[0], res[1], res[2], res[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (o + q < n_out) yout[o + q] = res[q];
+        }
+    }
+}
+
 // AvgPool with the reference's window rule (AvgPool.py:56): rows [oy*sh, min(h-1, oy*sh+kh)),
 // cols [ox*sw, min(w-1, ox*sw+kw)), no padding; mean = sum / count in fp32; empty window -> NaN.
 __global__ __launch_bounds__(kBlock) void avgpool2d_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -101,7 +182,29 @@ int pvhip_maxpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
     // every window must start inside the padded extent (numpy would raise on an empty np.max)
     if ((oh - 1) * sh >= a.hp || (ow - 1) * sw >= a.wp)
         return fail(PVHIP_EINVAL, "pvhip_maxpool2d_f32: window starts outside the padded input");
-    hipLaunchKernelGGL(maxpool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, x, y, a, total);
+    // LDS-staged path when at least one whole plane fits in 60 KB of LDS; else the direct kernel.
+    const size_t plane_bytes = (size_t)h * w * sizeof(float);
+    const size_t lds_budget  = 60 * 1024;
+    if (plane_bytes <= lds_budget) {
+        const int planes = n * c;
+        int       G      = (int)(48 * 1024 / plane_bytes);
+        if (G < 1) G = 1;
+        // keep >= 8 workgroups per CU when the tensor allows, and G a multiple of 4 when H*W is not
+        // (so that every group starts 16-byte aligned)
+        while (G > 4 && (planes + G - 1) / G < 8 * kNumCU) G >>= 1;
+        if ((h * w) % 4 != 0 && G >= 4) G &= ~3;
+        if (G > planes) G = planes;
+        const size_t lds  = (size_t)G * plane_bytes;
+        const int    grid = (planes + G - 1) / G;
+        if (kh == 3 && kw == 3)
+            hipLaunchKernelGGL((maxpool2d_lds_kernel<3, 3>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G);
+        else if (kh == 2 && kw == 2)
+            hipLaunchKernelGGL((maxpool2d_lds_kernel<2, 2>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G);
+        else
+            hipLaunchKernelGGL((maxpool2d_lds_kernel<0, 0>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G);
+    } else {
+        hipLaunchKernelGGL(maxpool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, x, y, a, total);
+    }
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -230,6 +230,9 @@ class Executable_Network:
         self.last_node_times = []       # [(node id, type, name, host seconds)] of the last run_tasks
         self.comm = None                # shard.BatchShardComm when the batch is sharded over ranks
         self.device_timing = None       # None, 'all', or a set of layer types: bracket those nodes with hipEvents
+        self.fuse_epilogues = True      # run Convolution -> Add(per-channel const) -> ReLU chains as one launch
+        self._fusion = {}               # conv node id -> {'bias': const id, 'add': id, 'relu': id or None}
+        self._fused_away = set()        # node ids whose compute() is folded into their producer
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
 
     def schedule_tasks(self):
@@ -256,6 +259,47 @@ class Executable_Network:
                 raise RuntimeError('graph has nodes that can never become ready')
             pending = still
         self.task_list = order
+        self.plan_fusion()
+
+    def plan_fusion(self):
+        """Peephole over the scheduled graph (SURVEY 8(f)-1): a Convolution whose only consumer is an Add of a
+        per-output-channel Const (1,K,1,1), optionally followed by a ReLU as the Add's only consumer, is run
+        as ONE launch: the Convolution plugin receives the bias tensor / relu flag on its node dict and
+        applies them in the kernel epilogue (the same fp32 add and the same select, so the fused result is
+        bit-identical to the three launches); the Add and ReLU nodes are not dispatched and their output
+        ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
+        plugin) never see them because fusion is only planned for this package's plugin."""
+        self._fusion, self._fused_away = {}, set()
+        if not self.fuse_epilogues:
+            return
+        G = self.ienet.G
+        conv_plugin = self.ienet.ie.plugins.plugins.get('Convolution')
+        if conv_plugin is None or not getattr(conv_plugin, 'SUPPORTS_FUSED_EPILOGUE', False):
+            return
+        for cid in G.nodes:
+            if G.nodes[cid]['type'] != 'Convolution':
+                continue
+            succ = list(G.successors(cid))
+            if len(succ) != 1 or G.nodes[succ[0]]['type'] != 'Add':
+                continue
+            aid = succ[0]
+            if G.edges[(cid, aid)]['connection'][3] != 0:
+                continue
+            others = [p for p in G.pred[aid] if p != cid]
+            if len(others) != 1 or G.nodes[others[0]]['type'] != 'Const':
+                continue
+            bid = others[0]
+            k_out = next(iter(G.nodes[cid]['output'].values()))['dims'][1]
+            if tuple(G.nodes[bid]['data']['shape']) != (1, k_out, 1, 1) or G.nodes[bid]['data']['element_type'] != 'f32':
+                continue
+            rid = None
+            asucc = list(G.successors(aid))
+            if len(asucc) == 1 and G.nodes[asucc[0]]['type'] == 'ReLU':
+                rid = asucc[0]
+            self._fusion[cid] = {'bias': bid, 'add': aid, 'relu': rid}
+            self._fused_away.add(aid)
+            if rid is not None:
+                self._fused_away.add(rid)
 
     def prepare_inputs_for_task(self, task) -> dict:
         """{sink port: tensor} gathered from the predecessors' output ports, in edge order."""
@@ -272,9 +316,18 @@ class Executable_Network:
         times = []
         self._recycle_events()
         for task in self.task_list:
+            if task in self._fused_away:
+                continue
             node = G.nodes[task]
             node_type = node['type']
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
+            fusion = self._fusion.get(task)
+            if fusion is not None:
+                node['_fuse_bias'] = G.nodes[fusion['bias']]['output'][0]['data']
+                node['_fuse_relu'] = fusion['relu'] is not None
+            else:
+                node.pop('_fuse_bias', None)
+                node.pop('_fuse_relu', None)
             plugin = registry.get(node_type)
             if plugin is None:
                 print("ERROR: Operation '{}' (node={}) is not supported.".format(node_type, node['name']))
@@ -298,6 +351,12 @@ class Executable_Network:
             if len(res) > 0:
                 for port_id, data in res.items():
                     node['output'][port_id]['data'] = data
+                if fusion is not None:
+                    fused = next(iter(res.values()))
+                    for nid in (fusion['add'], fusion['relu']):
+                        if nid is not None:
+                            out = G.nodes[nid]['output']
+                            out[next(iter(out))]['data'] = fused
         self.last_node_times = times
 
     # ---- device-side per-node timing (hipEvents on the compute stream; cf. the time.time() bracket :279-283)

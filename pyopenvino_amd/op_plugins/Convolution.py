@@ -10,6 +10,11 @@ from .. import common_def
 from .. import device as dev
 
 
+# The engine may hand over a Convolution -> Add(per-channel Const) -> ReLU chain as one call: node['_fuse_bias']
+# (DeviceTensor of K values) and node['_fuse_relu'] are then applied in the kernel epilogue.
+SUPPORTS_FUSED_EPILOGUE = True
+
+
 def name():
     print('Convolution')
 
@@ -65,7 +70,11 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     auto_pad = attrs['auto_pad']
     x = dev.as_device(inputs[0])
     w = dev.as_device(inputs[1])
-    y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad)
+    bias = node.get('_fuse_bias')
+    if bias is not None:
+        bias = dev.as_device(bias)
+        assert bias.size == w.shape[0]
+    y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, relu=bool(node.get('_fuse_relu', False)))
     port = common_def.first_output_port(node)
     assert common_def.type_convert_tbl[node['output'][port]['precision']] == np.float32
     return {port: y}

@@ -64,13 +64,17 @@ def first_out(res):
     return np.asarray(next(iter(res.values())))
 
 
-def build_network(plugin_package, model, weights=None, batch=1):
+def build_network(plugin_package, model, weights=None, batch=1, fuse=True):
+    """fuse=False dispatches every node on its own (needed when per-layer outputs are compared)."""
     from pyopenvino_amd import IECore
     ie = IECore(plugin_package=plugin_package)
     net = ie.read_network(os.path.join(MODELS, model + '.xml'), weights)
     if batch != 1:
         net.set_batch(batch)
     ex = ie.load_network(net)
+    if not fuse:
+        ex.fuse_epilogues = False
+        ex.plan_fusion()
     return ie, net, ex
 
 

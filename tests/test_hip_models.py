@@ -17,7 +17,7 @@ ORACLE = 'oracle.op_plugins'
 def test_mnist_real_weights_vs_reference(hip):
     """BASELINE config 1: models/mnist, mnist2.png -> the README.md:69-72 / integrity_test.py:57 answer."""
     z = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))
-    _, net, ex = build_network(HIP, 'mnist')
+    _, net, ex = build_network(HIP, 'mnist', fuse=False)
     got = infer_one(ex, net, z['images'][0:1])
     assert_close(got, z['out'][0:1], helpers.REL_TOL, 'mnist2')
     assert list(np.argsort(got[0])[::-1][:3]) == [2, 0, 1]
@@ -58,7 +58,7 @@ def test_synthetic_models_vs_reference(hip, model, fname, shape):
     assert_close(got, z['out'], helpers.REL_TOL, model)
     assert np.array_equal(np.argmax(got, axis=1), np.argmax(z['out'], axis=1))
     # per-layer checksums of image 0 (batch 1 run)
-    _, net1, ex1 = build_network(HIP, model, weights=blob)
+    _, net1, ex1 = build_network(HIP, model, weights=blob, fuse=False)
     infer_one(ex1, net1, x[0:1])
     sums = layer_sums(net1)
     worst = 0.0
@@ -72,7 +72,7 @@ def test_googlenet_layerwise_vs_oracle(hip):
     from pyopenvino_amd import synth
     blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), 1234)
     x = np.concatenate([synth.uniform_pixels(40 + i, (1, 3, 224, 224)) for i in range(3)], 0)
-    _, net, ex = build_network(HIP, 'googlenet-v1', weights=blob, batch=3)
+    _, net, ex = build_network(HIP, 'googlenet-v1', weights=blob, batch=3, fuse=False)
     _, onet, oex = build_network(ORACLE, 'googlenet-v1', weights=blob, batch=3)
     infer_one(ex, net, x)
     infer_one(oex, onet, x)
@@ -120,3 +120,22 @@ def test_device_resident_input_and_result_gather_world1(hip):
     xd = hip.DeviceTensor.from_numpy(z['images'])
     got = infer_one(ex, net, xd)
     assert_close(got, z['out'], helpers.REL_TOL, 'device-resident input')
+
+
+def test_fused_epilogue_is_bit_identical_and_aliases(hip):
+    """Convolution -> Add(bias) -> ReLU run as one launch (the default) gives exactly the bits of the three
+    separate launches; the fused-away nodes' output ports alias the fused tensor."""
+    from pyopenvino_amd import synth
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), 1234)
+    x = np.concatenate([synth.uniform_pixels(70 + i, (1, 3, 224, 224)) for i in range(2)], 0)
+    _, net_f, ex_f = build_network(HIP, 'googlenet-v1', weights=blob, batch=2)
+    _, net_u, ex_u = build_network(HIP, 'googlenet-v1', weights=blob, batch=2, fuse=False)
+    assert len(ex_f._fusion) == 57 and len(ex_f._fused_away) == 114 and not ex_u._fusion
+    out_f, out_u = infer_one(ex_f, net_f, x), infer_one(ex_u, net_u, x)
+    assert np.array_equal(out_f, out_u)
+    for cid, f in ex_f._fusion.items():
+        fused = next(iter(net_f.G.nodes[cid]['output'].values()))['data']
+        relu_u = next(iter(net_u.G.nodes[f['relu']]['output'].values()))['data']
+        assert next(iter(net_f.G.nodes[f['relu']]['output'].values()))['data'] is fused
+        if cid in (4, 293):   # first and one late layer: full tensors, bit for bit
+            helpers.assert_bit_exact(np.asarray(fused), np.asarray(relu_u), 'fused conv {}'.format(cid))
