@@ -46,84 +46,132 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_kernel(const float* __restri
     }
 }
 
+// Division by a run-time-uniform divisor as multiply-high + shift (exact for n < 2^31).
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u, d};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;                       // 2^(s-1) < d <= 2^s
+    const unsigned long long k = 31ull + s;
+    f.mul   = (unsigned)(((1ull << k) + d - 1) / d);   // ceil(2^k / d) in [2^31, 2^32)
+    f.shift = s - 1;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+    return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shift);
+}
+
+struct PoolDivs {
+    FastDiv hw, w, ohw, ow;
+};
+
 // LDS-staged MaxPool: a workgroup owns G consecutive (n, c) planes.  Planes are contiguous in NCHW, so
-// the input of a group is ONE dense run of G*H*W floats: it is streamed into LDS with 16-byte loads
-// (every byte of the input is read from HBM exactly once, fully coalesced), the windows are then read
-// from LDS, and the outputs of the group -- again one dense run of G*OH*OW floats -- leave as 16-byte
-// stores.  np.max semantics: a NaN anywhere in the window (or a pad cell's 0.0) takes part.
-template <int KH, int KW>   // 0 = run-time extent
+// the input of a group is ONE dense run of G*H*W floats: it is read from HBM exactly once with 16-byte
+// loads and laid out in LDS as G zero-PADDED planes [hp][wp] (the pad cells hold the 0.0 that takes part
+// in the reference's max), so a window is kh*kw unconditional LDS reads.  Lanes own consecutive outputs
+// (conflict-free LDS reads at stride 1, 2-way at stride 2); the outputs of a group are again one dense
+// run, written coalesced.  CLIP handles ceil-mode windows that overhang the padded extent (those cells
+// are excluded from the max, MaxPool.py:69).  np.max semantics: a NaN in the window wins.
+template <int KH, int KW, bool CLIP>   // KH == 0: run-time window extent
 __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                PoolArgs a, int G) {
+                                                                PoolArgs a, int G, PoolDivs dv) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int kh = KH ? KH : a.kh, kw = KW ? KW : a.kw;
     const int hw = a.h * a.w, ohw = a.oh * a.ow;
+    const int wl = a.wp, plane_l = a.hp * a.wp;
     const int g0 = blockIdx.x * G;
     const int gn = min(G, a.n_planes - g0);
     const int n_in = gn * hw, n_out = gn * ohw;
     const float* __restrict__ xin = x + (size_t)g0 * hw;
     float* __restrict__ yout      = y + (size_t)g0 * ohw;
+    const bool padded  = (plane_l != hw);
+    const bool aligned = ((((size_t)g0 * hw) & 3) == 0);
 
-    // ---- stream the group into LDS
-    if ((((size_t)g0 * hw) & 3) == 0) {
-        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
-        float4* t4 = reinterpret_cast<float4*>(tile);
-        const int n4 = n_in >> 2;
-        for (int i = threadIdx.x; i < n4; i += kBlock) t4[i] = x4[i];
-        for (int i = (n4 << 2) + threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+    if (!padded) {
+        // no padding: the LDS image is the dense run itself
+        if (aligned) {
+            const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
+            float4* t4 = reinterpret_cast<float4*>(tile);
+            const int n4 = n_in >> 2;
+            for (int i = threadIdx.x; i < n4; i += kBlock) t4[i] = x4[i];
+            for (int i = (n4 << 2) + threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+        } else {
+            for (int i = threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+        }
     } else {
-        for (int i = threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+        // zero the padded image, then scatter the dense run into its interior
+        {
+            float4* t4 = reinterpret_cast<float4*>(tile);
+            const int n4 = (gn * plane_l + 3) >> 2;   // the allocation is rounded up to 16 bytes
+            for (int i = threadIdx.x; i < n4; i += kBlock) t4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
+        if (aligned) {
+            const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
+            const int n4 = n_in >> 2;
+            for (int i = threadIdx.x; i < n4; i += kBlock) {
+                const float4   v = x4[i];
+                const unsigned e = (unsigned)i * 4u;
+                unsigned g  = fdiv(e, dv.hw);
+                unsigned r  = e - g * (unsigned)hw;
+                unsigned iy = fdiv(r, dv.w);
+                unsigned ix = r - iy * (unsigned)a.w;
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    tile[g * plane_l + (iy + a.pt) * wl + ix + a.pl] = vv[q];
+                    if (++ix == (unsigned)a.w) { ix = 0; if (++iy == (unsigned)a.h) { iy = 0; ++g; } }
+                }
+            }
+            for (int e = (n4 << 2) + threadIdx.x; e < n_in; e += kBlock) {
+                const unsigned g = fdiv((unsigned)e, dv.hw), r = (unsigned)e - g * (unsigned)hw;
+                const unsigned iy = fdiv(r, dv.w), ix = r - iy * (unsigned)a.w;
+                tile[g * plane_l + (iy + a.pt) * wl + ix + a.pl] = xin[e];
+            }
+        } else {
+            for (int e = threadIdx.x; e < n_in; e += kBlock) {
+                const unsigned g = fdiv((unsigned)e, dv.hw), r = (unsigned)e - g * (unsigned)hw;
+                const unsigned iy = fdiv(r, dv.w), ix = r - iy * (unsigned)a.w;
+                tile[g * plane_l + (iy + a.pt) * wl + ix + a.pl] = xin[e];
+            }
+        }
     }
     __syncthreads();
 
-    // ---- windows from LDS; one lane produces 4 consecutive outputs of the group
-    const bool vec_out = ((((size_t)g0 * ohw) & 3) == 0);
-    for (int o = threadIdx.x * 4; o < n_out; o += kBlock * 4) {
-        int g   = o / ohw;
-        int rem = o - g * ohw;
-        int oy  = rem / a.ow;
-        int ox  = rem - oy * a.ow;
-        float res[4];
+    for (int o = threadIdx.x; o < n_out; o += kBlock) {
+        const unsigned g   = fdiv((unsigned)o, dv.ohw);
+        const unsigned rem = (unsigned)o - g * (unsigned)ohw;
+        const unsigned oy  = fdiv(rem, dv.ow);
+        const unsigned ox  = rem - oy * (unsigned)a.ow;
+        const int py0 = (int)oy * a.sh, px0 = (int)ox * a.sw;
+        const float* __restrict__ tp = tile + g * plane_l + py0 * wl + px0;
+        float m      = -INFINITY;
+        bool  anynan = false;
+        if (KH != 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float m      = -INFINITY;
-            bool  anynan = false;
-            if (o + q < n_out) {
-                const float* __restrict__ tp = tile + g * hw;
-                const int py0 = oy * a.sh, px0 = ox * a.sw;
+            for (int ky = 0; ky < (KH ? KH : 1); ++ky) {
+                const bool row_ok = !CLIP || (py0 + ky < a.hp);
 #pragma unroll
-                for (int ky = 0; ky < (KH ? KH : 1); ++ky) {
-                    for (int kyr = ky; kyr < kh; kyr += (KH ? KH : 1)) {   // run-time trip when KH == 0
-                        const int py = py0 + kyr;
-                        if (py < a.hp) {
-                            const int  iy     = py - a.pt;
-                            const bool row_in = (unsigned)iy < (unsigned)a.h;
-#pragma unroll
-                            for (int kx = 0; kx < (KW ? KW : 1); ++kx) {
-                                for (int kxr = kx; kxr < kw; kxr += (KW ? KW : 1)) {
-                                    const int px = px0 + kxr;
-                                    if (px < a.wp) {
-                                        const int ix = px - a.pl;
-                                        float     v  = 0.0f;
-                                        if (row_in && (unsigned)ix < (unsigned)a.w) v = tp[iy * a.w + ix];
-                                        anynan |= (v != v);
-                                        m = fmaxf(m, v);
-                                    }
-                                }
-                            }
-                        }
+                for (int kx = 0; kx < (KW ? KW : 1); ++kx) {
+                    if (row_ok && (!CLIP || (px0 + kx < a.wp))) {
+                        const float v = tp[ky * wl + kx];
+                        anynan |= (v != v);
+                        m = fmaxf(m, v);
                     }
                 }
             }
-            res[q] = anynan ? NAN : m;
-            if (++ox == a.ow) { ox = 0; if (++oy == a.oh) { oy = 0; ++g; } }
-        }
-        if (vec_out && o + 3 < n_out) {
-            *reinterpret_cast<float4*>(yout + o) = make_float4(res[0], res[1], res[2], res[3]);
         } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (o + q < n_out) yout[o + q] = res[q];
+            for (int ky = 0; ky < kh && py0 + ky < a.hp; ++ky)
+                for (int kx = 0; kx < kw && px0 + kx < a.wp; ++kx) {
+                    const float v = tp[ky * wl + kx];
+                    anynan |= (v != v);
+                    m = fmaxf(m, v);
+                }
         }
+        yout[o] = anynan ? NAN : m;
     }
 }
 
@@ -182,26 +230,34 @@ int pvhip_maxpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
     // every window must start inside the padded extent (numpy would raise on an empty np.max)
     if ((oh - 1) * sh >= a.hp || (ow - 1) * sw >= a.wp)
         return fail(PVHIP_EINVAL, "pvhip_maxpool2d_f32: window starts outside the padded input");
-    // LDS-staged path when at least one whole plane fits in 60 KB of LDS; else the direct kernel.
-    const size_t plane_bytes = (size_t)h * w * sizeof(float);
+    // LDS-staged path when at least one whole padded plane fits in 60 KB of LDS; else the direct kernel.
+    const size_t plane_bytes = (size_t)a.hp * a.wp * sizeof(float);
     const size_t lds_budget  = 60 * 1024;
     if (plane_bytes <= lds_budget) {
         const int planes = n * c;
         int       G      = (int)(48 * 1024 / plane_bytes);
         if (G < 1) G = 1;
         // keep >= 8 workgroups per CU when the tensor allows, and G a multiple of 4 when H*W is not
-        // (so that every group starts 16-byte aligned)
+        // (so that every group starts 16-byte aligned in HBM)
         while (G > 4 && (planes + G - 1) / G < 8 * kNumCU) G >>= 1;
         if ((h * w) % 4 != 0 && G >= 4) G &= ~3;
         if (G > planes) G = planes;
-        const size_t lds  = (size_t)G * plane_bytes;
+        const size_t lds  = (((size_t)G * plane_bytes) + 15) & ~(size_t)15;
         const int    grid = (planes + G - 1) / G;
-        if (kh == 3 && kw == 3)
-            hipLaunchKernelGGL((maxpool2d_lds_kernel<3, 3>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G);
-        else if (kh == 2 && kw == 2)
-            hipLaunchKernelGGL((maxpool2d_lds_kernel<2, 2>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G);
-        else
-            hipLaunchKernelGGL((maxpool2d_lds_kernel<0, 0>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G);
+        const bool   clip = ((oh - 1) * sh + kh > a.hp) || ((ow - 1) * sw + kw > a.wp);
+        PoolDivs dv{make_fastdiv((unsigned)(h * w)), make_fastdiv((unsigned)w), make_fastdiv((unsigned)(oh * ow)),
+                    make_fastdiv((unsigned)ow)};
+#define PV_POOL_LAUNCH(KH_, KW_)                                                                              \
+    do {                                                                                                      \
+        if (clip)                                                                                             \
+            hipLaunchKernelGGL((maxpool2d_lds_kernel<KH_, KW_, true>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G, dv);  \
+        else                                                                                                  \
+            hipLaunchKernelGGL((maxpool2d_lds_kernel<KH_, KW_, false>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G, dv); \
+    } while (0)
+        if (kh == 3 && kw == 3) PV_POOL_LAUNCH(3, 3);
+        else if (kh == 2 && kw == 2) PV_POOL_LAUNCH(2, 2);
+        else PV_POOL_LAUNCH(0, 0);
+#undef PV_POOL_LAUNCH
     } else {
         hipLaunchKernelGGL(maxpool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, x, y, a, total);
     }
