@@ -19,6 +19,7 @@ A per-op-type breakdown (device ms, algorithmic GB/s or TFLOP/s) goes to stderr 
 exists, to gpurun_out/bench_breakdown.json.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -98,7 +99,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU (BASELINE: 256)')
-    ap.add_argument('--cpu-images', type=int, default=6, help='images timed on the CPU baseline (0 = skip)')
+    ap.add_argument('--cpu-images', type=int, default=60, help='images timed on the CPU baseline (0 = skip)')
     ap.add_argument('--no-node-timing', action='store_true')
     args = ap.parse_args()
 
@@ -132,7 +133,9 @@ def main():
     assert out.shape == (args.batch * world, 1000) and np.isfinite(out).all()
 
     if not args.no_node_timing:
-        ex.device_timing = 'all'
+        # bracket only nodes that launch kernels (Const / Parameter / Reshape / Result are host-side or copies)
+        ex.device_timing = {'Convolution', 'MatMul', 'MaxPool', 'AvgPool', 'Add', 'Multiply', 'ReLU', 'SoftMax', 'LRN',
+                            'Concat', 'Transpose', 'GroupConvolution', 'Clamp', 'Sigmoid'}
     per_node = {}
     group.barrier()
     device.synchronize()
@@ -175,11 +178,25 @@ def main():
                 agg['launches'] += 1
             conv = by_type.get('Convolution')
             if conv and conv['ms'] > 0:
-                tf = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
+                n_launch = conv['launches']
+                flops_per_launch = conv['flops'] / n_launch          # algorithmic: 2*N*K*C*kh*kw*oh*ow, averaged
+                avg_launch_ms = conv['ms'] / n_launch                # hipEvents on the compute stream, timed steps
+                tf = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
+                traffic, traffic_src = None, None
+                for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_traffic.json')), reverse=True):
+                    try:
+                        k = json.load(open(path))['kernels']['conv_igemm_kernel']
+                        traffic = k['read_bytes_per_launch'] + k['write_bytes_per_launch']
+                        traffic_src = os.path.relpath(path, REPO)
+                        break
+                    except Exception:
+                        continue
                 roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': tf / PEAK_MFMA_F32_TFLOPS, 'traffic': None,
-                        'kernel': 'conv_igemm_kernel (57 Convolution launches per step)',
-                        'flops_per_step': conv['flops'], 'ms_per_step': conv['ms']}
+                        'frac': tf / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic,
+                        'kernel': 'conv_igemm_kernel (all instantiations; {} Convolution launches per step, bias+ReLU fused)'.format(n_launch),
+                        'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_launch_ms * 1e3,
+                        'algorithmic_bytes_per_launch': conv['bytes'] / n_launch,
+                        'traffic_source': traffic_src}
             breakdown = {}
             for typ, agg in sorted(by_type.items(), key=lambda kv: -kv[1]['ms']):
                 row = {'launches': agg['launches'], 'ms_per_step': round(agg['ms'], 4)}

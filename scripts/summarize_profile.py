@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of scripts/profile_bench.sh into the small summaries kept under profiles/:
+
+  profiles/<tag>_kernel_stats.csv   per-kernel calls / total / average / percentage (rocprofv3 --stats)
+  profiles/<tag>_summary.md         the same, readable, plus the conv_igemm aggregate the bench's roofline uses
+  profiles/<tag>_traffic.json       HBM bytes per launch of the dominant kernel family from the PMC passes
+                                    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, both in KB)
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, '**', pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    raw, tag = sys.argv[1], sys.argv[2]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(repo, 'profiles')
+    os.makedirs(prof, exist_ok=True)
+    md = ['# rocprofv3 summary `{}`'.format(tag), '',
+          'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0` '
+          '(7 forward passes of googlenet-v1, batch 256, 1 GPU).', '']
+    stats = find(os.path.join(raw, 'stats'), '*kernel_stats.csv')
+    conv_total_ns = conv_calls = 0
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        with open(os.path.join(prof, tag + '_kernel_stats.csv'), 'w') as f:
+            f.write(open(stats).read())
+        md += ['| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
+        for r in rows:
+            name = r['Name']
+            short = name.replace('(anonymous namespace)::', '').split('(')[0][:70]
+            md.append('| `{}` | {} | {:.3f} | {:.2f} | {} |'.format(short, r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                                                  float(r['AverageNs']) / 1e3, r['Percentage']))
+            if 'conv_igemm_kernel' in name:
+                conv_total_ns += float(r['TotalDurationNs'])
+                conv_calls += int(r['Calls'])
+        if conv_calls:
+            md += ['', '**conv_igemm_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+                   '({:.3f} ms per forward pass of 57 launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
+                                                                         conv_total_ns / conv_calls * 57 / 1e6)]
+    line = os.path.join(raw, 'bench_line_under_profiler.json')
+    if os.path.isfile(line) and os.path.getsize(line):
+        b = json.loads(open(line).read())
+        md += ['', 'bench.py line of the profiled run: {:.1f} images/s, {:.3f} ms/step; roofline.achieved {:.2f} TFLOP/s over '
+               '{:.3f} ms of Convolution launches per step (hipEvents).'.format(b['value'], b['ms_per_step'], b['roofline']['achieved'],
+                                                                                b['roofline']['ms_per_step'])]
+    traffic = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        cc = find(os.path.join(raw, 'pmc_' + counter), '*counter_collection.csv')
+        if not cc:
+            continue
+        per_kernel = {}
+        for r in csv.DictReader(open(cc)):
+            if r['Counter_Name'] != counter:
+                continue
+            fam = 'conv_igemm_kernel' if 'conv_igemm_kernel' in r['Kernel_Name'] else r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('<')[0].replace('void ', '')
+            agg = per_kernel.setdefault(fam, [0.0, 0])
+            agg[0] += float(r['Counter_Value'])
+            agg[1] += 1
+        traffic[counter] = {k: {'sum_kb': v[0], 'launches': v[1]} for k, v in per_kernel.items()}
+    if traffic.get('FETCH_SIZE') and traffic.get('WRITE_SIZE'):
+        out = {'tag': tag, 'note': 'KB counters from separate --pmc passes; read side doubled (gfx950 FETCH_SIZE reports half of a wide '
+                                   'coalesced stream, MI355X_MICROARCH.md section HBM); bytes per launch', 'kernels': {}}
+        md += ['', '## HBM traffic per launch (PMC, corrected)', '', '| kernel family | launches | read MB | write MB | total MB |', '|---|---|---|---|---|']
+        for fam, f in traffic['FETCH_SIZE'].items():
+            w = traffic['WRITE_SIZE'].get(fam)
+            if not w or not f['launches']:
+                continue
+            rd = 2.0 * f['sum_kb'] * 1024.0 / f['launches']
+            wr = w['sum_kb'] * 1024.0 / max(1, w['launches'])
+            out['kernels'][fam] = {'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr, 'launches_sampled': f['launches']}
+            md.append('| `{}` | {} | {:.2f} | {:.2f} | {:.2f} |'.format(fam, f['launches'], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+        with open(os.path.join(prof, tag + '_traffic.json'), 'w') as fo:
+            json.dump(out, fo, indent=1)
+    sq = find(os.path.join(raw, 'pmc_SQ'), '*counter_collection.csv')
+    if sq:
+        agg = {}
+        for r in csv.DictReader(open(sq)):
+            if 'conv_igemm_kernel' in r['Kernel_Name']:
+                agg[r['Counter_Name']] = agg.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+        if agg.get('GRBM_GUI_ACTIVE'):
+            cyc = agg['GRBM_GUI_ACTIVE'] / 8.0
+            md += ['', '## conv_igemm_kernel, SQ counters summed over its launches', '']
+            md += ['- MFMA pipe busy: {:.1f} % of SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))'.format(
+                100.0 * agg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / cyc)]
+            for k in sorted(agg):
+                md.append('- {} = {:.4g}'.format(k, agg[k]))
+    with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
+        f.write('\n'.join(md) + '\n')
+    print('\n'.join(md))
+
+
+if __name__ == '__main__':
+    main()

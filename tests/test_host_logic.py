@@ -1,0 +1,178 @@
+"""Host-side logic and the C-ABI surface; no GPU needed (no compute entry point is called)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import MODELS, REPO
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from pyopenvino_amd import device
+    header = open(os.path.join(REPO, 'include', 'pvhip.h')).read()
+    declared = set(re.findall(r'\b(pvhip_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 40
+    lib = device.load_library()                       # dlopen + prototypes; AttributeError if one is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(device.SIGNATURES), declared ^ set(device.SIGNATURES)
+    nm = subprocess.run(['nm', '-D', '--defined-only', device.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r' T (pvhip_[a-z0-9_]+)', nm))
+    assert declared <= exported
+    assert lib.pvhip_abi_version() == 1
+    assert isinstance(lib.pvhip_last_error(), bytes)
+
+
+def test_header_argument_counts_match_ctypes_signatures():
+    from pyopenvino_amd import device
+    header = open(os.path.join(REPO, 'include', 'pvhip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    for name, (_, argtypes) in device.SIGNATURES.items():
+        m = re.search(r'\b' + name + r'\s*\(([^;]*?)\)\s*;', header, flags=re.S)
+        assert m, name
+        args = m.group(1).strip()
+        n = 0 if args in ('', 'void') else len(args.split(','))
+        assert n == len(argtypes), '{}: header has {} parameters, ctypes {}'.format(name, n, len(argtypes))
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from pyopenvino_amd import device
+    if device.device_count() > 0:
+        pytest.skip('a GPU is visible here')
+    with pytest.raises(device.PvhipError):
+        device.DeviceTensor.from_numpy(np.zeros(4, dtype=np.float32))
+    import importlib
+    relu = importlib.import_module('pyopenvino_amd.op_plugins.ReLU')
+    node = {'name': 'r', 'type': 'ReLU', 'input': {0: {'precision': 'FP32', 'dims': (4,)}}, 'output': {1: {'precision': 'FP32', 'dims': (4,)}}}
+    with pytest.raises(device.PvhipError):
+        relu.compute(node, {0: np.zeros(4, dtype=np.float32)})
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, 'pyopenvino_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'import torch' not in src or f == 'shard.py', f     # torch only as gloo plumbing in shard.py
+
+
+def test_ir_loader_and_scheduler_match_reference_structure():
+    from pyopenvino_amd import IECore
+    ie = IECore()
+    assert {'Convolution', 'MatMul', 'MaxPool', 'Add', 'ReLU', 'SoftMax', 'Multiply', 'AvgPool', 'Concat', 'LRN',
+            'GroupConvolution', 'Clamp', 'Sigmoid', 'Const', 'Parameter', 'Result', 'Reshape', 'Transpose'} <= set(ie.plugins.plugins)
+    net = ie.read_network(os.path.join(MODELS, 'mnist.xml'))
+    assert len(net.G.nodes) == 33 and net.inputs[0]['name'] == 'conv2d_input'
+    assert net.inputs[0]['data']['shape'] == (1, 1, 28, 28)
+    conv = net.G.nodes[2]
+    assert conv['type'] == 'Convolution' and conv['data']['strides'] == '1, 1' and conv['input'][1]['dims'] == (32, 1, 3, 3)
+    w = net.G.nodes[1]['const']
+    assert w['element_info'] == 'F32' and w['data'].dtype == np.float32 and w['data'].size == 288
+    ex = ie.load_network(net)
+    order = ex.task_list
+    assert sorted(order) == sorted(net.G.nodes)
+    pos = {n: i for i, n in enumerate(order)}
+    for a, b in net.G.edges:
+        assert pos[a] < pos[b]
+    first_non_source = next(i for i, n in enumerate(order) if net.G.nodes[n]['type'] not in ('Const', 'Parameter'))
+    assert all(net.G.nodes[n]['type'] in ('Const', 'Parameter') for n in order[:first_non_source])
+    # Conv -> Add(bias) -> ReLU chains are planned as single launches
+    assert set(ex._fusion) == {2, 8, 14} and ex._fused_away == {4, 5, 10, 11, 16, 17}
+    with pytest.raises(Exception):
+        ie.read_network(os.path.join(MODELS, 'does_not_exist.xml'))
+
+
+def test_set_batch_rewrites_only_activation_ports():
+    from pyopenvino_amd import IECore
+    ie = IECore()
+    net = ie.read_network(os.path.join(MODELS, 'googlenet-v1.xml'), weights=bytes(28 << 20))
+    net.set_batch(256)
+    G = net.G
+    assert net.inputs[0]['data']['shape'] == (256, 3, 224, 224)
+    assert net.outputs[0]['input'][0]['dims'] == (256, 1000)
+    for nid in G.nodes:
+        node = G.nodes[nid]
+        if node['type'] == 'Const':
+            assert node['output'][0]['dims'] == tuple(node['data']['shape'])
+        if node['type'] == 'Convolution':
+            assert node['input'][0]['dims'][0] == 256 and node['output'][2]['dims'][0] == 256
+            assert node['input'][1]['dims'][0] != 256 or node['input'][1]['dims'] == node['input'][1]['dims']
+    lrn = G.nodes[10]
+    assert lrn['input'][1]['dims'] == (1,)                       # axes operand untouched
+    with pytest.raises(ValueError):
+        net.set_batch(0)
+
+
+def test_broadcast_stride_resolution():
+    from pyopenvino_amd.op_plugins._broadcast import strides_for_broadcast as sb
+    assert sb((1, 6, 1, 1), (2, 6, 5, 7)) == [0, 1, 0, 0]
+    assert sb((1, 10), (3, 10)) == [0, 1]
+    assert sb((5,), (2, 3, 4, 5)) == [0, 0, 0, 1]
+    assert sb((2, 3, 4, 5), (2, 3, 4, 5)) == [60, 20, 5, 1]
+    assert sb((1, 1, 1, 1), (2, 3, 4, 5)) == [0, 0, 0, 0]
+    for bad in [((2, 4), (2, 3)), ((2, 3, 4), (3, 4))]:
+        with pytest.raises(ValueError):
+            sb(*bad)
+            np.broadcast_to(np.zeros(bad[0]), bad[1])
+
+
+def test_reshape_dims_and_output_extents_match_oracle():
+    from oracle import ops
+    from pyopenvino_amd import common_def
+    from pyopenvino_amd.op_plugins.Reshape import resolve_dims
+    for shape, target in [((8, 3, 3, 64), [-1, 576]), ((8, 1024, 1, 1), [0, -1]), ((1, 19, 19, 12), [0, 1083, 1, 4]), ((2, 6), [2, 3, -1])]:
+        assert resolve_dims(shape, target) == ops.reshape_dims(shape, target)
+    for size in (7, 14, 28, 56, 112, 224, 300, 13):
+        for k, s, pb, pe in [(3, 2, 0, 0), (3, 1, 1, 1), (7, 2, 3, 3), (2, 2, 0, 0), (3, 2, 0, 1), (5, 1, 2, 2)]:
+            for rounding in ('floor', 'ceil'):
+                for ap in ('explicit', 'valid', 'same_upper'):
+                    for pooling in (False, True):
+                        assert common_def.pooled_extent(size, k, s, pb, pe, rounding, ap, pooling) == \
+                            ops.out_extent(size, k, s, pb, pe, rounding, ap, pooling)
+
+
+def test_synthetic_weights_are_deterministic_and_sane():
+    import hashlib
+    from pyopenvino_amd import synth
+    xml = os.path.join(MODELS, 'googlenet-v1.xml')
+    blob = synth.synth_weights(xml, 1234)
+    assert len(blob) == 27994244
+    assert hashlib.sha256(blob).hexdigest() == hashlib.sha256(synth.synth_weights(xml, 1234)).hexdigest()
+    assert blob != synth.synth_weights(xml, 1235)
+    px = synth.uniform_pixels(7, (2, 3, 8, 8))
+    assert px.dtype == np.float32 and px.min() >= 0 and px.max() <= 255 and np.array_equal(px, np.floor(px))
+    z = synth.normal(3, 1, 200000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+
+
+def test_shard_bounds_cover_the_batch():
+    from pyopenvino_amd.shard import shard_bounds
+    for total in (0, 1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_bench_work_model_matches_survey_totals():
+    """The algorithmic FLOP / byte model bench.py prices the roofline with."""
+    import bench
+    from pyopenvino_amd import IECore
+    ie = IECore()
+    net = ie.read_network(os.path.join(MODELS, 'googlenet-v1.xml'), weights=bytes(28 << 20))
+    work = bench.collect_work(net)
+    conv_flops = sum(f for nid, (f, b) in work.items() if net.G.nodes[nid]['type'] == 'Convolution')
+    assert abs(conv_flops - 3.163295744e9) < 1.0                   # GFLOP per image, SURVEY 8(a) a3
+    pool_bytes = sum(b for nid, (f, b) in work.items() if net.G.nodes[nid]['type'] == 'MaxPool')
+    assert abs(pool_bytes / 1e6 - (11.503 + 5.670)) < 0.01
+    relu_bytes = sum(b for nid, (f, b) in work.items() if net.G.nodes[nid]['type'] == 'ReLU')
+    assert abs(relu_bytes / 1e6 - 2 * 12.905) < 0.01
