@@ -137,12 +137,14 @@ def main():
         ex.device_timing = {'Convolution', 'MatMul', 'MaxPool', 'AvgPool', 'Add', 'Multiply', 'ReLU', 'SoftMax', 'LRN',
                             'Concat', 'Transpose', 'GroupConvolution', 'Clamp', 'Sigmoid'}
     per_node = {}
+    host_dispatch = 0.0
     group.barrier()
     device.synchronize()
     t0 = time.perf_counter()
     ev0 = device.Event().record()
     for _ in range(args.steps):
         out = ex.infer({in_name: x_dev})[out_name]
+        host_dispatch += sum(t[3] for t in ex.last_node_times if t[1] != 'Result')
         if ex.device_timing is not None:
             for nid, typ, name, ms in ex.device_times_ms():
                 per_node.setdefault(nid, [typ, name, 0.0])[2] += ms
@@ -164,6 +166,7 @@ def main():
                        'global_batch': args.batch * world,
                        'parallelism': 'batch shard x{} (one process per GPU), RCCL all-gather of Result'.format(world)},
             'device_ms_per_step': dev_ms / args.steps,
+            'host_dispatch_ms_per_step': 1000.0 * host_dispatch / args.steps,
         }
         roof = None
         if per_node:

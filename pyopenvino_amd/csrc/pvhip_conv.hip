@@ -17,6 +17,7 @@
 //     no padding.  Register-staged double buffering: global loads of step t+1 are issued before the
 //     MFMAs of step t and written to the other LDS buffer after them; one barrier per step.
 #include <climits>
+#include <cstring>
 
 #include "pvhip_common.h"
 
@@ -26,7 +27,9 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBK       = 16;   // reduction rows per LDS stage
+constexpr int kBK       = 16;   // reduction rows per stage
+constexpr int kTabSpare   = 2 * kBK;   // padding rows after the gather table (prefetch / unrolled look-ahead)
+constexpr int kPanelSpare = 2 * kBK;   // zero rows after the weight panel
 constexpr int kKoutAlign = 128;  // packed panel width is a multiple of this
 
 struct ConvArgs {
@@ -37,11 +40,12 @@ struct ConvArgs {
     const float* bias;  // optional [K]
     int N, C, H, W, K, OH, OW;
     int sh, sw, pt, pl, kh, kw;
-    unsigned x_bytes;
+    unsigned x_bytes, wp_bytes;
     int kred_pad, kout_pad;
     int P;              // N*OH*OW
-    int n_mtiles;
+    int n_mtiles, n_ptiles;
     int relu;
+    int y_ctotal, y_coff;   // channels of the tensor y points into, and this convolution's first channel in it
 };
 
 // One gather element of the im2col tile: returns x[n, c, ih0 + r, iw0 + s] or 0 for a padding cell.
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
     float  breg[B_LOADS];
     float4 areg[A_F4];
     int    tko[B_LOADS], trs[B_LOADS];   // table entries of the NEXT stage to gather (scalar registers)
-    const int* __restrict__ tab_rs = a.ktab + a.kred_pad + 2 * kBK;
+    const int* __restrict__ tab_rs = a.ktab + a.kred_pad + kTabSpare;
 
 #define PV_LOAD_ENT(kt_)                                                              \
     {                                                                                 \
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
         if (gp >= a.P) continue;
         const int    n    = gp / OHW;
         const int    rem  = gp - n * OHW;
-        float* __restrict__ yp = a.y + (size_t)n * a.K * OHW + rem;
+        float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff) * OHW + rem;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -257,13 +261,149 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-direct variant: no LDS staging of operands and no barriers in the reduction loop.
+//
+// With one VGPR per fp32 MFMA operand and a wave tile of (32*TM) output channels x (32*TN) pixels, the B
+// (im2col) elements a wave needs are needed by no other wave of the workgroup, so staging them through
+// LDS only adds writes, reads and a barrier per stage.  Here every lane gathers exactly the operand
+// element the MFMA wants from it -- lane l supplies B[k = 2*step + (l>>5)][pixel = l&31] -- straight
+// into registers, and likewise A[k][k_out = l&31] from the packed panel (128-byte runs; the panel is a
+// few hundred KB and lives in L1/L2).  Two register sets alternate (stage t+1 loads are in flight under
+// the MFMAs of stage t); waits are counted vmcnt.  The (byte offset, window bit) table of the reduction
+// rows is copied to LDS once per workgroup and read per lane with ds_read_b64 (both lane halves read one
+// address each: broadcast, conflict-free).  The 4 waves of a workgroup take consecutive output-channel
+// tiles of the same pixel tile, so their B loads hit in L1.
+template <int TM, int TN, bool kMask>
+__global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int2 tab[];   // [kred_pad + kTabSpare] {koff bytes, rs}
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tab_n = a.kred_pad + kTabSpare;
+    for (int i = tid; i < tab_n; i += kBlock) tab[i] = make_int2(a.ktab[i], a.ktab[tab_n + i]);
+    __syncthreads();
+
+    // ---- this wave's tile
+    const long n_tiles = (long)a.n_mtiles * a.n_ptiles;
+    long       t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        t = (long)lid * (kBlock / kWave) + wid;
+    }
+    if (t >= n_tiles) return;   // no barrier after this point
+    const int mt = (int)(t % a.n_mtiles);
+    const int pt = (int)(t / a.n_mtiles);
+    const int m0 = mt * (32 * TM);
+    const int p0 = pt * (32 * TN);
+
+    const int OHW = a.OH * a.OW, HW = a.H * a.W;
+    int                ih0[TN], iw0[TN];
+    unsigned           xoff[TN];
+    unsigned long long inb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gp = p0 + j * 32 + l31;
+        ih0[j] = INT_MIN / 2; iw0[j] = 0; xoff[j] = 0; inb[j] = 0;
+        if (gp < a.P) {
+            const int n   = gp / OHW;
+            const int rem = gp - n * OHW;
+            const int oy  = rem / a.OW;
+            const int ox  = rem - oy * a.OW;
+            ih0[j]        = oy * a.sh - a.pt;
+            iw0[j]        = ox * a.sw - a.pl;
+            xoff[j]       = (unsigned)(n * a.C * HW + ih0[j] * a.W + iw0[j]) * 4u;
+            if (kMask) {
+                for (int r = 0; r < a.kh; ++r)
+                    for (int s = 0; s < a.kw; ++s)
+                        if ((unsigned)(ih0[j] + r) < (unsigned)a.H && (unsigned)(iw0[j] + s) < (unsigned)a.W)
+                            inb[j] |= 1ull << (r * a.kw + s);
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wp_bytes, 0x00020000);
+    const unsigned woff = (unsigned)(lh * a.kout_pad + m0 + l31) * 4u;   // lane part of the panel offset
+    const unsigned wrow = (unsigned)a.kout_pad * 4u;                     // bytes per panel row
+
+    float areg[2][TM][kBK / 2], breg[2][TN][kBK / 2];
+
+#define PV_WLOAD(set_, kt_)                                                                               \
+    {                                                                                                     \
+        const int row0 = (kt_) * kBK;                                                                     \
+        _Pragma("unroll") for (int s = 0; s < kBK / 2; ++s) {                                             \
+            const int2 e = tab[row0 + 2 * s + lh];                                                        \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+                breg[set_][j][s] = gather_one<kMask>(xr, e.x, e.y, inb[j], xoff[j], ih0[j], iw0[j], a.H, a.W); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+                areg[set_][i][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(        \
+                    wr, woff + (unsigned)(i * 128), (unsigned)(row0 + 2 * s) * wrow, 0));                 \
+        }                                                                                                 \
+    }
+#define PV_WMMA(set_)                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < kBK / 2; ++s)                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[set_][i][s], breg[set_][j][s], acc[i][j], 0, 0, 0);
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // Stages are processed in pairs with two register sets; an odd tail runs one stage past the end
+    // (padding rows of the table read as 0, the panel has spare zero stages).
+    const int nk = a.kred_pad / kBK;
+    PV_WLOAD(0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        PV_WLOAD(1, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        PV_WMMA(0);
+        __builtin_amdgcn_sched_barrier(0);
+        PV_WLOAD(0, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        PV_WMMA(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PV_WLOAD
+#undef PV_WMMA
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gp = p0 + j * 32 + l31;
+        if (gp >= a.P) continue;
+        const int n   = gp / OHW;
+        const int rem = gp - n * OHW;
+        float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff) * OHW + rem;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ko = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ko < a.K) {
+                    float v = acc[i][j][r];
+                    if (a.bias != nullptr) v = v + a.bias[ko];
+                    if (a.relu) v = (v < 0.0f) ? 0.0f : v;
+                    yp[(size_t)ko * OHW] = v;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void conv_pack_kernel(const float* __restrict__ w, int* __restrict__ ktab,
                                                             float* __restrict__ wp, int K, int C, int kh, int kw, int H,
                                                             int W, int kred, int kred_pad, int kout_pad) {
-    const size_t total  = (size_t)(kred_pad + kBK) * kout_pad;   // includes the spare zero stage
+    const size_t total  = (size_t)(kred_pad + kPanelSpare) * kout_pad;   // includes the spare zero stages
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const bool   mask   = kh * kw < 64;
-    const int    tab_n  = kred_pad + 2 * kBK;                    // two spare stages for the table prefetch
+    const int    tab_n  = kred_pad + kTabSpare;                  // spare stages of padding rows
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int kr = (int)(e / kout_pad);
         const int ko = (int)(e % kout_pad);
@@ -337,7 +477,7 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     if (k_out <= 0 || c <= 0 || kh <= 0 || kw <= 0) return 0;
     const size_t kred_pad = (size_t)round_up_int(c * kh * kw, kBK);
     const size_t kout_pad = (size_t)round_up_int(k_out, kKoutAlign);
-    return 2 * (kred_pad + 2 * kBK) + (kred_pad + kBK) * kout_pad;   // two tables (+2 spare stages), weight panel (+1 zero stage)
+    return 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
 }
 
 int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw, int h, int w) {
@@ -348,21 +488,24 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_pack_f32: C=%d kh=%d kw=%d H=%d W=%d outside table encoding", c, kh, kw, h, w);
     const int kred = c * kh * kw, kred_pad = round_up_int(kred, kBK), kout_pad = round_up_int(k_out, kKoutAlign);
     int*   ktab = reinterpret_cast<int*>(wpack);
-    float* wp   = wpack + 2 * (kred_pad + 2 * kBK);
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kBK) * kout_pad)), dim3(kBlock), 0, state().stream,
+    float* wp   = wpack + 2 * (kred_pad + kTabSpare);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kPanelSpare) * kout_pad)), dim3(kBlock), 0, state().stream,
                        w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }
 
 int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh, int kw,
-                     int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu) {
+                     int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
+                     int out_channel_offset, int out_channels_total) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && k_out > 0 && kh > 0 && kw > 0 && oh >= 0 && ow >= 0);
     PVHIP_CHECK_ARG(sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0);
     if (kh >= 256 || kw >= 256)
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f32: kh=%d kw=%d outside table encoding", kh, kw);
-    const unsigned long long in_e = (unsigned long long)n * c * h * w, out_e = (unsigned long long)n * k_out * oh * ow;
+    PVHIP_CHECK_ARG(out_channels_total == 0 || (out_channel_offset >= 0 && out_channel_offset + k_out <= out_channels_total));
+    const unsigned long long in_e = (unsigned long long)n * c * h * w,
+                             out_e = (unsigned long long)n * (out_channels_total > 0 ? out_channels_total : k_out) * oh * ow;
     if (in_e >= (1ull << 29) || out_e >= (1ull << 31))
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f32: input exceeds 2^29 elements (buffer offsets below 2^31) or output 2^31");
     if (out_e == 0) return PVHIP_OK;
@@ -373,7 +516,7 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.kout_pad = round_up_int(k_out, kKoutAlign);
     a.x        = x;
     a.ktab     = reinterpret_cast<const int*>(wpack);
-    a.wp       = wpack + 2 * (a.kred_pad + 2 * kBK);
+    a.wp       = wpack + 2 * (a.kred_pad + kTabSpare);
     a.y        = y;
     a.bias     = bias;
     a.N = n; a.C = c; a.H = h; a.W = w; a.K = k_out; a.OH = oh; a.OW = ow;
@@ -381,6 +524,39 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.x_bytes = (unsigned)(in_e * 4ull);
     a.P    = n * oh * ow;
     a.relu = relu;
+    a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
+    a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
+
+    a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
+
+    // ---- wave-direct kernel (PVHIP_CONV_KERNEL=wave, PVHIP_CONV_WTILE=TMxTN in units of 32)
+    const char* kenv = getenv("PVHIP_CONV_KERNEL");
+    const size_t tab_bytes = (size_t)(a.kred_pad + kTabSpare) * sizeof(int2);
+    if (kenv != nullptr && strcmp(kenv, "wave") == 0 && tab_bytes <= 60 * 1024) {
+        int tm = 2, tn = 1;
+        const char* wenv = getenv("PVHIP_CONV_WTILE");
+        if (wenv != nullptr) sscanf(wenv, "%dx%d", &tm, &tn);
+        a.n_mtiles = (k_out + 32 * tm - 1) / (32 * tm);
+        a.n_ptiles = (a.P + 32 * tn - 1) / (32 * tn);
+        const long n_tiles = (long)a.n_mtiles * a.n_ptiles;
+        const int  grid    = (int)((n_tiles + 3) / 4);
+        const bool mask    = kh * kw < 64;
+#define PV_WAVE_LAUNCH(TM_, TN_)                                                                                    \
+    do {                                                                                                            \
+        if (mask) hipLaunchKernelGGL((conv_wave_kernel<TM_, TN_, true>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);  \
+        else hipLaunchKernelGGL((conv_wave_kernel<TM_, TN_, false>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);      \
+    } while (0)
+        if (tm == 1 && tn == 1) PV_WAVE_LAUNCH(1, 1);
+        else if (tm == 1 && tn == 2) PV_WAVE_LAUNCH(1, 2);
+        else if (tm == 2 && tn == 1) PV_WAVE_LAUNCH(2, 1);
+        else if (tm == 2 && tn == 2) PV_WAVE_LAUNCH(2, 2);
+        else if (tm == 4 && tn == 1) PV_WAVE_LAUNCH(4, 1);
+        else if (tm == 1 && tn == 4) PV_WAVE_LAUNCH(1, 4);
+        else return fail(PVHIP_EINVAL, "pvhip_conv2d_f32: unsupported PVHIP_CONV_WTILE %dx%d", tm, tn);
+#undef PV_WAVE_LAUNCH
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
 
     // ---- tile selection (calibrated with scripts/tune_conv.py on the GoogLeNet shapes at batch 256):
     // 128-pixel tiles; 64 output channels per tile when that wastes less than half a tile and still

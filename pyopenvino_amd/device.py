@@ -60,7 +60,7 @@ SIGNATURES = {
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
     'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
-    'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int]),
+    'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_dwconv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 12),
     'pvhip_comm_unique_id': (_c.c_int, [_c.c_void_p]),
     'pvhip_comm_init': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
@@ -274,11 +274,43 @@ class DeviceTensor:
         return 'DeviceTensor(shape={}, dtype={}, ptr=0x{:x})'.format(self.shape, self.dtype.name, self.ptr)
 
 
+class ChannelSlice:
+    """Channels [coff, coff + k) of an NCHW DeviceTensor, as written in place by a producer whose consumer is
+    a channel Concat.  Has the ndarray surface (shape / dtype / numpy()) but is not dense: it is only handed
+    to the Concat it belongs to (which is not dispatched) and to debugging code."""
+    __slots__ = ('base', 'coff', 'shape', 'dtype')
+
+    def __init__(self, base: DeviceTensor, coff: int, k: int):
+        self.base, self.coff = base, int(coff)
+        self.shape = (base.shape[0], int(k)) + tuple(base.shape[2:])
+        self.dtype = base.dtype
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    def numpy(self):
+        return np.ascontiguousarray(self.base.numpy()[:, self.coff:self.coff + self.shape[1]])
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+
 def as_device(data, dtype=np.float32) -> DeviceTensor:
     """Accept what a predecessor plugin handed over: a DeviceTensor (ours) or an ndarray (when our
     plugins are mixed with host plugins, e.g. under the reference's own engine)."""
     if isinstance(data, DeviceTensor):
         return data
+    if isinstance(data, ChannelSlice):
+        return DeviceTensor.from_numpy(data.numpy())     # densify (debug paths only)
     return DeviceTensor.from_numpy(np.asarray(data), dtype=dtype)
 
 

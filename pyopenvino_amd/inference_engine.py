@@ -233,6 +233,8 @@ class Executable_Network:
         self.fuse_epilogues = True      # run Convolution -> Add(per-channel const) -> ReLU chains as one launch
         self._fusion = {}               # conv node id -> {'bias': const id, 'add': id, 'relu': id or None}
         self._fused_away = set()        # node ids whose compute() is folded into their producer
+        self._concat_direct = {}        # Concat node id -> total channels, when every input is written in place
+        self._infer_serial = 0
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
 
     def schedule_tasks(self):
@@ -296,10 +298,40 @@ class Executable_Network:
             asucc = list(G.successors(aid))
             if len(asucc) == 1 and G.nodes[asucc[0]]['type'] == 'ReLU':
                 rid = asucc[0]
-            self._fusion[cid] = {'bias': bid, 'add': aid, 'relu': rid}
+            self._fusion[cid] = {'bias': bid, 'add': aid, 'relu': rid, 'into': None}
             self._fused_away.add(aid)
             if rid is not None:
                 self._fused_away.add(rid)
+        # Second peephole: a channel Concat (axis 1, NCHW) all of whose inputs are ends of fused convolution
+        # chains with no other consumer is not dispatched either: each producing convolution writes its
+        # channels straight into the Concat's output tensor (Concat.py:9-13 becomes a store pattern).
+        self._concat_direct = {}
+        tail_of = {}
+        for cid, f in self._fusion.items():
+            tail_of[f['relu'] if f['relu'] is not None else f['add']] = cid
+        for nid in G.nodes:
+            node = G.nodes[nid]
+            if node['type'] != 'Concat' or int(node['data']['axis']) != 1:
+                continue
+            out_dims = next(iter(node['output'].values()))['dims']
+            preds = list(G.pred[nid])
+            if len(out_dims) != 4 or len(preds) < 2 or len(preds) != len(node['input']):
+                continue
+            plan, coff, ok = [], 0, True
+            for pred in preds:                       # edge order == np.concatenate order (Concat.py:11-12)
+                cid = tail_of.get(pred)
+                if cid is None or len(list(G.successors(pred))) != 1:
+                    ok = False
+                    break
+                k = next(iter(G.nodes[cid]['output'].values()))['dims'][1]
+                plan.append((cid, coff))
+                coff += k
+            if not ok or coff != out_dims[1]:
+                continue
+            for cid, off in plan:
+                self._fusion[cid]['into'] = (nid, off)
+            self._concat_direct[nid] = coff
+            self._fused_away.add(nid)
 
     def prepare_inputs_for_task(self, task) -> dict:
         """{sink port: tensor} gathered from the predecessors' output ports, in edge order."""
@@ -314,6 +346,7 @@ class Executable_Network:
         G = self.ienet.G
         registry = self.ienet.ie.plugins.plugins
         times = []
+        self._infer_serial += 1
         self._recycle_events()
         for task in self.task_list:
             if task in self._fused_away:
@@ -322,9 +355,12 @@ class Executable_Network:
             node_type = node['type']
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
             fusion = self._fusion.get(task)
+            node.pop('_out_into', None)
             if fusion is not None:
                 node['_fuse_bias'] = G.nodes[fusion['bias']]['output'][0]['data']
                 node['_fuse_relu'] = fusion['relu'] is not None
+                if fusion['into'] is not None:
+                    node['_out_into'] = (self._concat_buffer(fusion['into'][0]), fusion['into'][1])
             else:
                 node.pop('_fuse_bias', None)
                 node.pop('_fuse_relu', None)
@@ -358,6 +394,16 @@ class Executable_Network:
                             out = G.nodes[nid]['output']
                             out[next(iter(out))]['data'] = fused
         self.last_node_times = times
+
+    def _concat_buffer(self, cat_id):
+        """Output tensor of a Concat whose producers write in place; one fresh tensor per infer."""
+        from . import device
+        node = self.ienet.G.nodes[cat_id]
+        port = next(iter(node['output']))
+        if node.get('_buf_serial') != self._infer_serial:
+            node['output'][port]['data'] = device.DeviceTensor.empty(node['output'][port]['dims'])
+            node['_buf_serial'] = self._infer_serial
+        return node['output'][port]['data']
 
     # ---- device-side per-node timing (hipEvents on the compute stream; cf. the time.time() bracket :279-283)
     def _event(self):

@@ -11,7 +11,9 @@ from .. import device as dev
 
 
 # The engine may hand over a Convolution -> Add(per-channel Const) -> ReLU chain as one call: node['_fuse_bias']
-# (DeviceTensor of K values) and node['_fuse_relu'] are then applied in the kernel epilogue.
+# (DeviceTensor of K values) and node['_fuse_relu'] are then applied in the kernel epilogue; node['_out_into'] =
+# (tensor, channel offset) makes the kernel write its channels straight into the output of the channel Concat
+# that consumes it.
 SUPPORTS_FUSED_EPILOGUE = True
 
 
@@ -39,7 +41,7 @@ def packed_weights(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
     return wpack
 
 
-def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, relu=False):
+def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, relu=False, into=None):
     n, c, h, wd = x.shape
     kn, kc, kh, kw = w.shape
     if kc != c:
@@ -50,11 +52,18 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, relu=
         # the strided slice of the padded image is shorter than (oh, ow): numpy refuses the assignment (:68)
         raise ValueError('could not broadcast input array: window exceeds the padded input '
                          '({}x{} padded, kernel {}x{}, stride {}, output {}x{})'.format(hp, wp, kh, kw, strides, oh, ow))
-    y = dev.DeviceTensor.empty((n, kn, oh, ow))
     wpack = packed_weights(node, w, h, wd)
-    dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(y.ptr),
+    if into is None:
+        y, target, coff, ctotal = None, dev.DeviceTensor.empty((n, kn, oh, ow)), 0, 0
+        y = target
+    else:
+        target, coff = into                                  # the Concat's output tensor and our first channel in it
+        ctotal = target.shape[1]
+        assert target.shape[0] == n and tuple(target.shape[2:]) == (oh, ow) and coff + kn <= ctotal
+        y = dev.ChannelSlice(target, coff, kn)
+    dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr),
              n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
-             ctypes.c_void_p(bias.ptr if bias is not None else 0), int(bool(relu)))
+             ctypes.c_void_p(bias.ptr if bias is not None else 0), int(bool(relu)), int(coff), int(ctotal))
     return y
 
 
@@ -74,7 +83,8 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     if bias is not None:
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
-    y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, relu=bool(node.get('_fuse_relu', False)))
+    y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, relu=bool(node.get('_fuse_relu', False)),
+               into=node.get('_out_into'))
     port = common_def.first_output_port(node)
     assert common_def.type_convert_tbl[node['output'][port]['precision']] == np.float32
     return {port: y}

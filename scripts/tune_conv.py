@@ -18,7 +18,7 @@ sys.path.insert(0, REPO)
 from pyopenvino_amd import IECore, device as dev, synth  # noqa: E402
 from pyopenvino_amd import common_def  # noqa: E402
 
-ALL_TILES = ['32x128', '32x256', '64x128', '64x256', '128x128', '128x256']
+ALL_TILES = ['32x128', '64x128', '64x256', 'w1x1', 'w1x2', 'w2x1', 'w2x2', 'w4x1', 'w1x4']   # wAxB = wave-direct kernel, tile in units of 32
 
 
 def conv_shapes(model, batch):
@@ -72,12 +72,16 @@ def main():
 
         def run():
             dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wp.ptr), ctypes.c_void_p(y.ptr),
-                     n, c, h, w, k, kh, kw, oh, ow, sh, sw, pt, pl, ctypes.c_void_p(0), 0)
+                     n, c, h, w, k, kh, kw, oh, ow, sh, sw, pt, pl, ctypes.c_void_p(0), 0, 0, 0)
 
         for tile in tiles + ['auto']:
-            if tile == 'auto':
-                os.environ.pop('PVHIP_CONV_TILE', None)
-            else:
+            for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE'):
+                os.environ.pop(envk, None)
+            if tile.startswith('w'):
+                os.environ['PVHIP_CONV_KERNEL'] = 'wave'
+                os.environ['PVHIP_CONV_WTILE'] = tile[1:]
+            elif tile != 'auto':
+                os.environ['PVHIP_CONV_KERNEL'] = 'lds'
                 os.environ['PVHIP_CONV_TILE'] = tile
             run()
             dev.synchronize()
@@ -87,7 +91,8 @@ def main():
             e1 = dev.Event().record()
             e1.synchronize()
             row['ms'][tile] = e0.elapsed_ms(e1) / args.reps
-        os.environ.pop('PVHIP_CONV_TILE', None)
+        for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE'):
+            os.environ.pop(envk, None)
         best = min(tiles, key=lambda t: row['ms'][t])
         row['best'] = best
         table.append(row)

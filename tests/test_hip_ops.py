@@ -104,6 +104,22 @@ def test_conv_every_tile_config(hip, monkeypatch):
         vs_oracle('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)), 'tile ' + tile)
 
 
+def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
+    """The LDS-free wave-direct kernel, every wave tile, on shapes with ragged edges, padding, stride 2,
+    an odd number of reduction stages and a 7x7 (64-bit mask) window."""
+    monkeypatch.setenv('PVHIP_CONV_KERNEL', 'wave')
+    cases = [((3, 20, 13, 11), (150, 20, 3, 3), (1, 1), (1, 1), (1, 1)),
+             ((2, 48, 7, 7), (24, 48, 1, 1), (1, 1), (0, 0), (0, 0)),
+             ((1, 3, 37, 37), (16, 3, 7, 7), (2, 2), (3, 3), (3, 3)),
+             ((2, 9, 10, 10), (70, 9, 5, 5), (1, 1), (2, 2), (2, 2))]
+    for tile in ('1x1', '1x2', '2x1', '2x2', '4x1', '1x4'):
+        monkeypatch.setenv('PVHIP_CONV_WTILE', tile)
+        for xs, ws, st, pb, pe in cases:
+            x = rnd(sum(xs), xs)
+            w = rnd(sum(ws), ws, 0.1)
+            vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'wave tile {} {}'.format(tile, xs))
+
+
 def test_conv_identity_weights_asymmetric_input(hip):
     """A = I check with asymmetric data: catches a transposed accumulator map (guide section 3)."""
     c = 40
