@@ -1,5 +1,7 @@
 // Pooling kernels (HBM-bound).  NCHW fp32; lanes run along the output row so the window loads of a
 // wave are contiguous (stride sw) segments of input rows and the stores are fully coalesced.
+#include <cstdlib>
+
 #include "pvhip_common.h"
 
 using namespace pvhip;
@@ -77,21 +79,32 @@ struct PoolDivs {
 // are excluded from the max, MaxPool.py:69).  np.max semantics: a NaN in the window wins.
 template <int KH, int KW, bool CLIP>   // KH == 0: run-time window extent
 __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                PoolArgs a, int G, PoolDivs dv) {
+                                                                PoolArgs a, int G, int band_rows, PoolDivs dv) {
+    // blockIdx.x: group of G planes; blockIdx.y: band of `band_rows` output rows (bands > 1 only with G == 1,
+    // for planes too large to stage whole).  The LDS image holds the PADDED rows [py_lo, py_hi) the band needs.
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int kh = KH ? KH : a.kh, kw = KW ? KW : a.kw;
-    const int hw = a.h * a.w, ohw = a.oh * a.ow;
-    const int wl = a.wp, plane_l = a.hp * a.wp;
     const int g0 = blockIdx.x * G;
     const int gn = min(G, a.n_planes - g0);
-    const int n_in = gn * hw, n_out = gn * ohw;
-    const float* __restrict__ xin = x + (size_t)g0 * hw;
-    float* __restrict__ yout      = y + (size_t)g0 * ohw;
-    const bool padded  = (plane_l != hw);
-    const bool aligned = ((((size_t)g0 * hw) & 3) == 0);
+    const int oy0 = blockIdx.y * band_rows;
+    const int oy1 = min(a.oh, oy0 + band_rows);
+    const int py_lo = oy0 * a.sh;
+    const int py_hi = min(a.hp, (oy1 - 1) * a.sh + kh);
+    const int iy_lo = max(0, py_lo - a.pt);
+    const int iy_hi = min(a.h, py_hi - a.pt);
+    const int hb    = iy_hi - iy_lo;                 // input rows of this band actually present in the tensor
+    const int hwb = hb * a.w, obw = (oy1 - oy0) * a.ow;
+    const int wl = a.wp, plane_l = (py_hi - py_lo) * a.wp;
+    const int n_in = gn * hwb, n_out = gn * obw;
+    const size_t in_off = (size_t)g0 * a.h * a.w + (size_t)iy_lo * a.w;
+    const float* __restrict__ xin = x + in_off;
+    float* __restrict__ yout      = y + (size_t)g0 * a.oh * a.ow + (size_t)oy0 * a.ow;
+    const bool whole   = (gridDim.y == 1);           // whole planes: dense runs span planes
+    const bool padded  = (plane_l != hwb);
+    const bool aligned = ((in_off & 3) == 0);
+    const int  row_shift = iy_lo + a.pt - py_lo;     // LDS row of input row iy_lo (0 unless the band starts in the top pad)
 
     if (!padded) {
-        // no padding: the LDS image is the dense run itself
         if (aligned) {
             const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
             float4* t4 = reinterpret_cast<float4*>(tile);
@@ -102,52 +115,43 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __re
             for (int i = threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
         }
     } else {
-        // zero the padded image, then scatter the dense run into its interior
         {
             float4* t4 = reinterpret_cast<float4*>(tile);
             const int n4 = (gn * plane_l + 3) >> 2;   // the allocation is rounded up to 16 bytes
             for (int i = threadIdx.x; i < n4; i += kBlock) t4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
-        if (aligned) {
-            const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
-            const int n4 = n_in >> 2;
-            for (int i = threadIdx.x; i < n4; i += kBlock) {
-                const float4   v = x4[i];
-                const unsigned e = (unsigned)i * 4u;
-                unsigned g  = fdiv(e, dv.hw);
-                unsigned r  = e - g * (unsigned)hw;
-                unsigned iy = fdiv(r, dv.w);
-                unsigned ix = r - iy * (unsigned)a.w;
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+        const int n4 = aligned ? (n_in >> 2) : 0;
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
+        for (int i = threadIdx.x; i < n4; i += kBlock) {
+            const float4   v = x4[i];
+            const unsigned e = (unsigned)i * 4u;
+            unsigned g  = whole ? fdiv(e, dv.hw) : 0u;
+            unsigned r  = e - g * (unsigned)hwb;
+            unsigned iy = fdiv(r, dv.w);
+            unsigned ix = r - iy * (unsigned)a.w;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    tile[g * plane_l + (iy + a.pt) * wl + ix + a.pl] = vv[q];
-                    if (++ix == (unsigned)a.w) { ix = 0; if (++iy == (unsigned)a.h) { iy = 0; ++g; } }
-                }
+            for (int q = 0; q < 4; ++q) {
+                tile[g * plane_l + (iy + row_shift) * wl + ix + a.pl] = vv[q];
+                if (++ix == (unsigned)a.w) { ix = 0; if (++iy == (unsigned)hb) { iy = 0; ++g; } }
             }
-            for (int e = (n4 << 2) + threadIdx.x; e < n_in; e += kBlock) {
-                const unsigned g = fdiv((unsigned)e, dv.hw), r = (unsigned)e - g * (unsigned)hw;
-                const unsigned iy = fdiv(r, dv.w), ix = r - iy * (unsigned)a.w;
-                tile[g * plane_l + (iy + a.pt) * wl + ix + a.pl] = xin[e];
-            }
-        } else {
-            for (int e = threadIdx.x; e < n_in; e += kBlock) {
-                const unsigned g = fdiv((unsigned)e, dv.hw), r = (unsigned)e - g * (unsigned)hw;
-                const unsigned iy = fdiv(r, dv.w), ix = r - iy * (unsigned)a.w;
-                tile[g * plane_l + (iy + a.pt) * wl + ix + a.pl] = xin[e];
-            }
+        }
+        for (int e = (n4 << 2) + threadIdx.x; e < n_in; e += kBlock) {
+            const unsigned g = whole ? fdiv((unsigned)e, dv.hw) : 0u, r = (unsigned)e - g * (unsigned)hwb;
+            const unsigned iy = fdiv(r, dv.w), ix = r - iy * (unsigned)a.w;
+            tile[g * plane_l + (iy + row_shift) * wl + ix + a.pl] = xin[e];
         }
     }
     __syncthreads();
 
     for (int o = threadIdx.x; o < n_out; o += kBlock) {
-        const unsigned g   = fdiv((unsigned)o, dv.ohw);
-        const unsigned rem = (unsigned)o - g * (unsigned)ohw;
-        const unsigned oy  = fdiv(rem, dv.ow);
-        const unsigned ox  = rem - oy * (unsigned)a.ow;
-        const int py0 = (int)oy * a.sh, px0 = (int)ox * a.sw;
-        const float* __restrict__ tp = tile + g * plane_l + py0 * wl + px0;
+        const unsigned g   = whole ? fdiv((unsigned)o, dv.ohw) : 0u;
+        const unsigned rem = (unsigned)o - g * (unsigned)obw;
+        const unsigned oyl = fdiv(rem, dv.ow);
+        const unsigned ox  = rem - oyl * (unsigned)a.ow;
+        const int py0 = (int)(oy0 + oyl) * a.sh, px0 = (int)ox * a.sw;
+        const float* __restrict__ tp = tile + g * plane_l + (py0 - py_lo) * wl + px0;
         float m      = -INFINITY;
         bool  anynan = false;
         if (KH != 0) {
@@ -230,29 +234,49 @@ int pvhip_maxpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
     // every window must start inside the padded extent (numpy would raise on an empty np.max)
     if ((oh - 1) * sh >= a.hp || (ow - 1) * sw >= a.wp)
         return fail(PVHIP_EINVAL, "pvhip_maxpool2d_f32: window starts outside the padded input");
-    // LDS-staged path when at least one whole padded plane fits in 60 KB of LDS; else the direct kernel.
-    const size_t plane_bytes = (size_t)a.hp * a.wp * sizeof(float);
-    const size_t lds_budget  = 60 * 1024;
-    if (plane_bytes <= lds_budget) {
+    // LDS-staged path.  ~16 KB of LDS per workgroup (8-10 workgroups per CU overlap each other's load and
+    // compute phases; measured best on the GoogLeNet shapes): several whole planes per workgroup when planes
+    // are small, bands of output rows of one plane when a plane is larger than the budget.
+    size_t group_bytes = 16 * 1024;
+    if (const char* e = getenv("PVHIP_POOL_LDS_KB")) group_bytes = (size_t)atoi(e) * 1024;   // tuning runs only
+    const size_t row_bytes   = (size_t)a.wp * sizeof(float);
+    const size_t plane_bytes = (size_t)a.hp * row_bytes;
+    const size_t min_band    = (size_t)(kh + sh) * row_bytes;       // at least two output rows per band
+    if (min_band <= 60 * 1024) {
         const int planes = n * c;
-        int       G      = (int)(48 * 1024 / plane_bytes);
-        if (G < 1) G = 1;
-        // keep >= 8 workgroups per CU when the tensor allows, and G a multiple of 4 when H*W is not
-        // (so that every group starts 16-byte aligned in HBM)
-        while (G > 4 && (planes + G - 1) / G < 8 * kNumCU) G >>= 1;
-        if ((h * w) % 4 != 0 && G >= 4) G &= ~3;
-        if (G > planes) G = planes;
-        const size_t lds  = (((size_t)G * plane_bytes) + 15) & ~(size_t)15;
-        const int    grid = (planes + G - 1) / G;
-        const bool   clip = ((oh - 1) * sh + kh > a.hp) || ((ow - 1) * sw + kw > a.wp);
+        int G = 1, band_rows = oh, n_bands = 1;
+        if (plane_bytes <= group_bytes) {
+            G = (int)(group_bytes / plane_bytes);
+            while (G > 4 && (planes + G - 1) / G < 8 * kNumCU) G >>= 1;
+            if ((h * w) % 4 != 0 && G >= 4) G &= ~3;     // every group starts 16-byte aligned in HBM
+            if (G > planes) G = planes;
+        } else if (plane_bytes > 60 * 1024 || plane_bytes > group_bytes) {
+            const size_t budget = plane_bytes <= group_bytes ? plane_bytes : (group_bytes > min_band ? group_bytes : min_band);
+            int rows_in = (int)(budget / row_bytes);                 // padded input rows per band
+            band_rows   = (rows_in - kh) / sh + 1;
+            if (band_rows < 1) band_rows = 1;
+            if (band_rows > oh) band_rows = oh;
+            n_bands = (oh + band_rows - 1) / band_rows;
+            band_rows = (oh + n_bands - 1) / n_bands;                // even out the bands
+            n_bands = (oh + band_rows - 1) / band_rows;
+        }
+        const int    rows_l = (n_bands == 1) ? a.hp : ((band_rows - 1) * sh + kh < a.hp ? (band_rows - 1) * sh + kh : a.hp);
+        const size_t lds    = (((size_t)G * rows_l * row_bytes) + 15) & ~(size_t)15;
+        if (lds > 64 * 1024 || n_bands > 65535) {
+            hipLaunchKernelGGL(maxpool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, x, y, a, total);
+            PVHIP_LAUNCH_CHECK();
+            return PVHIP_OK;
+        }
+        const dim3 grid((planes + G - 1) / G, n_bands);
+        const bool clip = ((oh - 1) * sh + kh > a.hp) || ((ow - 1) * sw + kw > a.wp);
         PoolDivs dv{make_fastdiv((unsigned)(h * w)), make_fastdiv((unsigned)w), make_fastdiv((unsigned)(oh * ow)),
                     make_fastdiv((unsigned)ow)};
 #define PV_POOL_LAUNCH(KH_, KW_)                                                                              \
     do {                                                                                                      \
         if (clip)                                                                                             \
-            hipLaunchKernelGGL((maxpool2d_lds_kernel<KH_, KW_, true>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G, dv);  \
+            hipLaunchKernelGGL((maxpool2d_lds_kernel<KH_, KW_, true>), grid, dim3(kBlock), lds, state().stream, x, y, a, G, band_rows, dv);  \
         else                                                                                                  \
-            hipLaunchKernelGGL((maxpool2d_lds_kernel<KH_, KW_, false>), dim3(grid), dim3(kBlock), lds, state().stream, x, y, a, G, dv); \
+            hipLaunchKernelGGL((maxpool2d_lds_kernel<KH_, KW_, false>), grid, dim3(kBlock), lds, state().stream, x, y, a, G, band_rows, dv); \
     } while (0)
         if (kh == 3 && kw == 3) PV_POOL_LAUNCH(3, 3);
         else if (kh == 2 && kw == 2) PV_POOL_LAUNCH(2, 2);

@@ -173,6 +173,9 @@ POOL_CASES = [
     ((3, 832, 14, 14), (3, 3), (2, 2), (0, 0), (0, 0), 'ceil'),
     ((8, 32, 26, 26), (2, 2), (2, 2), (0, 0), (0, 0), 'floor'),
     ((2, 3, 11, 9), (3, 2), (2, 3), (1, 0), (0, 2), 'ceil'),
+    ((1, 2, 80, 90), (3, 3), (1, 1), (1, 1), (1, 1), 'ceil'),      # plane larger than the LDS group: row bands + padding
+    ((2, 3, 97, 101), (3, 3), (2, 2), (1, 1), (0, 0), 'ceil'),     # row bands, stride 2, asymmetric pad, odd width (scalar loads)
+    ((1, 1, 300, 300), (5, 4), (3, 2), (2, 1), (1, 2), 'floor'),   # run-time window extent, bands
 ]
 
 
