@@ -67,75 +67,68 @@ __device__ __forceinline__ float lrn_pow(float d, float beta, int beta_mode) {
     return powf(d, beta);
 }
 
-// One lane owns VEC adjacent pixels of one image and walks the channel axis keeping the last SIZE
-// inputs in registers: every element is read once and written once.  Window for channel c is
-// [c - SIZE/2, c + SIZE/2] clipped to [0, C); squares are summed in ascending channel order, the
-// order np.sum(axis=1) uses (LRN.py:19).
+// One lane owns VEC adjacent pixels of one image and walks the channel axis in chunks of T channels: the
+// loads of chunk k+1 are issued before the outputs of chunk k are computed (T independent 16-byte loads in
+// flight per lane), every element is read once and written once.  The outputs computed after chunk k has
+// landed are those whose whole window lies in chunks <= k, i.e. channels [T*k - HALF, T*k + T - HALF).
+// Window for channel c is [c - SIZE/2, c + SIZE/2] clipped to [0, C); squares are summed in ascending
+// channel order, the order np.sum(axis=1) uses (LRN.py:19); out-of-range channels contribute an exact 0.
 template <int SIZE, int VEC>
 __global__ __launch_bounds__(kBlock) void lrn_window_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
                                                              int c, int hw, float alpha, float beta, float bias,
                                                              int beta_mode) {
     constexpr int HALF = SIZE / 2;
-    const int     cols_per_img = hw / VEC;
-    const unsigned total       = (unsigned)n * (unsigned)cols_per_img;
-    const unsigned stride      = gridDim.x * blockDim.x;
+    constexpr int T    = 8;                 // channels per chunk
+    static_assert(2 * HALF <= T, "window halo must fit in one chunk");
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int      cols_per_img = hw / VEC;
+    const unsigned total        = (unsigned)n * (unsigned)cols_per_img;
+    const unsigned stride       = gridDim.x * blockDim.x;
+    const int      n_chunks     = (c + T - 1) / T;
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const unsigned img = t / (unsigned)cols_per_img;
-        const unsigned col = t - img * (unsigned)cols_per_img;
+        const unsigned img  = t / (unsigned)cols_per_img;
+        const unsigned col  = t - img * (unsigned)cols_per_img;
         const size_t   base = (size_t)img * c * hw + (size_t)col * VEC;
-        float win[SIZE][VEC];
+        const vec_t* __restrict__ xv = reinterpret_cast<const vec_t*>(x + base);
+        vec_t* __restrict__       yv = reinterpret_cast<vec_t*>(y + base);
+        const size_t cstride = (size_t)hw / VEC;   // channel stride in vec_t units
+        // win[0 .. 2*HALF-1]: last 2*HALF channels of the previous chunks; cur[]: chunk k; nxt[]: chunk k+1
+        vec_t win[2 * HALF], cur[T], nxt[T];
 #pragma unroll
-        for (int j = 0; j < SIZE; ++j)
+        for (int j = 0; j < 2 * HALF; ++j) win[j] = (vec_t)(0.0f);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) win[j][v] = 0.0f;
-        // preload channels 0 .. HALF-1 into the upper part of the window
+        for (int j = 0; j < T; ++j) cur[j] = (j < c) ? xv[(size_t)j * cstride] : (vec_t)(0.0f);
+        for (int k = 0; k <= n_chunks; ++k) {
+            // issue chunk k+1 (zeros past the last channel)
+            const int c1 = (k + 1) * T;
 #pragma unroll
-        for (int j = 0; j < HALF; ++j) {
-            if (j < c) {
-                if (VEC == 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(x + base + (size_t)j * hw);
-                    win[HALF + 1 + j][0] = q.x; win[HALF + 1 + j][1] = q.y;
-                    win[HALF + 1 + j][2] = q.z; win[HALF + 1 + j][3] = q.w;
-                } else {
-                    win[HALF + 1 + j][0] = x[base + (size_t)j * hw];
+            for (int j = 0; j < T; ++j) nxt[j] = (c1 + j < c) ? xv[(size_t)(c1 + j) * cstride] : (vec_t)(0.0f);
+            // outputs [T*k - HALF, T*k + T - HALF): inputs win[] ++ cur[] form channels [T*k - 2*HALF, T*k + T)
+            vec_t ext[2 * HALF + T];
+#pragma unroll
+            for (int j = 0; j < 2 * HALF; ++j) ext[j] = win[j];
+#pragma unroll
+            for (int j = 0; j < T; ++j) ext[2 * HALF + j] = cur[j];
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const int ch = k * T - HALF + j;       // centre channel = ext[j + HALF]
+                if (ch >= 0 && ch < c) {
+                    vec_t s = ext[j] * ext[j];
+#pragma unroll
+                    for (int q = 1; q < SIZE; ++q) s = s + ext[j + q] * ext[j + q];
+                    vec_t o;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float d = bias + alpha * s[v];
+                        o[v]          = ext[j + HALF][v] / lrn_pow(d, beta, beta_mode);
+                    }
+                    yv[(size_t)ch * cstride] = o;
                 }
             }
-        }
-        for (int ch = 0; ch < c; ++ch) {
-            // shift: win[j] <- win[j+1]; then bring in channel ch + HALF
 #pragma unroll
-            for (int j = 0; j < SIZE - 1; ++j)
+            for (int j = 0; j < 2 * HALF; ++j) win[j] = cur[T - 2 * HALF + j];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) win[j][v] = win[j + 1][v];
-            const int cin = ch + HALF;
-            if (cin < c) {
-                if (VEC == 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(x + base + (size_t)cin * hw);
-                    win[SIZE - 1][0] = q.x; win[SIZE - 1][1] = q.y; win[SIZE - 1][2] = q.z; win[SIZE - 1][3] = q.w;
-                } else {
-                    win[SIZE - 1][0] = x[base + (size_t)cin * hw];
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) win[SIZE - 1][v] = 0.0f;
-            }
-            float o[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                // out-of-range channels hold 0 and add exactly 0 to the sum
-                float s = 0.0f;
-#pragma unroll
-                for (int j = 0; j < SIZE; ++j) {
-                    const float sq = win[j][v] * win[j][v];
-                    s              = (j == 0) ? sq : s + sq;
-                }
-                const float d = bias + alpha * s;
-                o[v]          = win[HALF][v] / lrn_pow(d, beta, beta_mode);
-            }
-            if (VEC == 4)
-                *reinterpret_cast<float4*>(y + base + (size_t)ch * hw) = make_float4(o[0], o[1], o[2], o[3]);
-            else
-                y[base + (size_t)ch * hw] = o[0];
+            for (int j = 0; j < T; ++j) cur[j] = nxt[j];
         }
     }
 }

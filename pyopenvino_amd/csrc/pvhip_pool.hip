@@ -88,8 +88,9 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __re
     const int gn = min(G, a.n_planes - g0);
     const int oy0 = blockIdx.y * band_rows;
     const int oy1 = min(a.oh, oy0 + band_rows);
+    const bool whole = (gridDim.y == 1);             // whole planes: the dense run spans planes, so stage every row
     const int py_lo = oy0 * a.sh;
-    const int py_hi = min(a.hp, (oy1 - 1) * a.sh + kh);
+    const int py_hi = whole ? a.hp : min(a.hp, (oy1 - 1) * a.sh + kh);
     const int iy_lo = max(0, py_lo - a.pt);
     const int iy_hi = min(a.h, py_hi - a.pt);
     const int hb    = iy_hi - iy_lo;                 // input rows of this band actually present in the tensor
@@ -99,7 +100,6 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __re
     const size_t in_off = (size_t)g0 * a.h * a.w + (size_t)iy_lo * a.w;
     const float* __restrict__ xin = x + in_off;
     float* __restrict__ yout      = y + (size_t)g0 * a.oh * a.ow + (size_t)oy0 * a.ow;
-    const bool whole   = (gridDim.y == 1);           // whole planes: dense runs span planes
     const bool padded  = (plane_l != hwb);
     const bool aligned = ((in_off & 3) == 0);
     const int  row_shift = iy_lo + a.pt - py_lo;     // LDS row of input row iy_lo (0 unless the band starts in the top pad)
@@ -206,6 +206,48 @@ __global__ __launch_bounds__(kBlock) void avgpool2d_kernel(const float* __restri
     }
 }
 
+// LDS-staged AvgPool for small planes (the 7x7 global pool of the classifiers): a workgroup streams G whole
+// planes (one dense run) into LDS with 16-byte loads, then one lane per output averages its window from LDS.
+// Same window rule as avgpool2d_kernel (AvgPool.py:56), same sequential fp32 sum.
+__global__ __launch_bounds__(kBlock) void avgpool2d_lds_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                PoolArgs a, int G, PoolDivs dv) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+    const int g0 = blockIdx.x * G;
+    const int gn = min(G, a.n_planes - g0);
+    const int n_in = gn * hw, n_out = gn * ohw;
+    const float* __restrict__ xin = x + (size_t)g0 * hw;
+    if ((((size_t)g0 * hw) & 3) == 0) {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
+        float4* t4 = reinterpret_cast<float4*>(tile);
+        const int n4 = n_in >> 2;
+        for (int i = threadIdx.x; i < n4; i += kBlock) t4[i] = x4[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+    } else {
+        for (int i = threadIdx.x; i < n_in; i += kBlock) tile[i] = xin[i];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < n_out; o += kBlock) {
+        const unsigned g   = fdiv((unsigned)o, dv.ohw);
+        const unsigned rem = (unsigned)o - g * (unsigned)ohw;
+        const unsigned oy  = fdiv(rem, dv.ow);
+        const unsigned ox  = rem - oy * (unsigned)a.ow;
+        const float* __restrict__ tp = tile + g * hw;
+        const int y0 = (int)oy * a.sh, x0 = (int)ox * a.sw;
+        int       y1 = y0 + a.kh, x1 = x0 + a.kw;
+        if (y1 > a.h - 1) y1 = a.h - 1;
+        if (x1 > a.w - 1) x1 = a.w - 1;
+        float sum = 0.0f;
+        int   cnt = 0;
+        for (int iy = y0; iy < y1; ++iy)
+            for (int ix = x0; ix < x1; ++ix) {
+                sum += tp[iy * a.w + ix];
+                ++cnt;
+            }
+        y[(size_t)g0 * ohw + o] = (cnt > 0) ? sum / (float)cnt : NAN;
+    }
+}
+
 int check_pool_dims(const char* who, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw) {
     if (n < 0 || c < 0 || h <= 0 || w <= 0 || oh < 0 || ow < 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0)
         return fail(PVHIP_EINVAL, "%s: bad dims n=%d c=%d h=%d w=%d oh=%d ow=%d k=%dx%d s=%dx%d", who, n, c, h, w, oh, ow,
@@ -298,7 +340,20 @@ int pvhip_avgpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
     if (total == 0) return PVHIP_OK;
     PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
     PoolArgs a{n * c, h, w, oh, ow, kh, kw, sh, sw, 0, 0, h, w};
-    hipLaunchKernelGGL(avgpool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, x, y, a, total);
+    const size_t plane_bytes = (size_t)h * w * sizeof(float);
+    if (plane_bytes <= 16 * 1024) {
+        const int planes = n * c;
+        int       G      = (int)(16 * 1024 / plane_bytes);
+        while (G > 4 && (planes + G - 1) / G < 8 * kNumCU) G >>= 1;
+        if ((h * w) % 4 != 0 && G >= 4) G &= ~3;
+        if (G > planes) G = planes;
+        const size_t lds = (((size_t)G * plane_bytes) + 15) & ~(size_t)15;
+        PoolDivs dv{make_fastdiv((unsigned)(h * w)), make_fastdiv((unsigned)w), make_fastdiv((unsigned)(oh * ow)),
+                    make_fastdiv((unsigned)ow)};
+        hipLaunchKernelGGL(avgpool2d_lds_kernel, dim3((planes + G - 1) / G), dim3(kBlock), lds, state().stream, x, y, a, G, dv);
+    } else {
+        hipLaunchKernelGGL(avgpool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, x, y, a, total);
+    }
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

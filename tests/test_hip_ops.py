@@ -172,6 +172,8 @@ POOL_CASES = [
     ((9, 832, 7, 7), (3, 3), (1, 1), (1, 1), (1, 1), 'ceil'),
     ((3, 832, 14, 14), (3, 3), (2, 2), (0, 0), (0, 0), 'ceil'),
     ((8, 32, 26, 26), (2, 2), (2, 2), (0, 0), (0, 0), 'floor'),
+    ((5, 64, 11, 11), (2, 2), (2, 2), (0, 0), (0, 0), 'floor'),     # floor mode leaves the last input row/column unused (mnist)
+    ((3, 7, 10, 13), (3, 3), (3, 3), (0, 0), (0, 0), 'floor'),
     ((2, 3, 11, 9), (3, 2), (2, 3), (1, 0), (0, 2), 'ceil'),
     ((1, 2, 80, 90), (3, 3), (1, 1), (1, 1), (1, 1), 'ceil'),      # plane larger than the LDS group: row bands + padding
     ((2, 3, 97, 101), (3, 3), (2, 2), (1, 1), (0, 0), 'ceil'),     # row bands, stride 2, asymmetric pad, odd width (scalar loads)
