@@ -67,70 +67,90 @@ __device__ __forceinline__ float lrn_pow(float d, float beta, int beta_mode) {
     return powf(d, beta);
 }
 
-// One lane owns VEC adjacent pixels of one image and walks the channel axis in chunks of T channels: the
-// loads of chunk k+1 are issued before the outputs of chunk k are computed (T independent 16-byte loads in
-// flight per lane), every element is read once and written once.  The outputs computed after chunk k has
-// landed are those whose whole window lies in chunks <= k, i.e. channels [T*k - HALF, T*k + T - HALF).
-// Window for channel c is [c - SIZE/2, c + SIZE/2] clipped to [0, C); squares are summed in ascending
-// channel order, the order np.sum(axis=1) uses (LRN.py:19); out-of-range channels contribute an exact 0.
-template <int SIZE, int VEC>
+// One lane owns VEC adjacent pixels of one image and walks the channel axis in chunks of T = 8 channels
+// (C must be a multiple of 8; other channel counts take the generic kernel).  The T loads of chunk k+1 are
+// issued before the outputs that chunk k completes are computed, so T independent 16-byte loads per lane are
+// in flight; every element is read once and written once.  After chunk k has landed the computable outputs
+// are channels [T*k - HALF, T*k + T - HALF).  The loop body is branch-free: the first chunk, the last chunk and
+// the trailing HALF outputs are peeled.  Window for channel c is [c - SIZE/2, c + SIZE/2] clipped to [0, C);
+// squares are summed in ascending channel order, the order np.sum(axis=1) uses (LRN.py:19); channels outside
+// the tensor contribute an exact 0.
+template <int SIZE, int VEC, int BETA_MODE>
 __global__ __launch_bounds__(kBlock) void lrn_window_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
-                                                             int c, int hw, float alpha, float beta, float bias,
-                                                             int beta_mode) {
+                                                             int c, int hw, float alpha, float beta, float bias) {
+    constexpr int beta_mode = BETA_MODE;   // compile-time: keeps the per-element path branch-free
     constexpr int HALF = SIZE / 2;
-    constexpr int T    = 8;                 // channels per chunk
+    constexpr int T    = 8;
+    constexpr int E    = 2 * HALF + T;      // ext[]: channels [T*k - 2*HALF, T*k + T)
     static_assert(2 * HALF <= T, "window halo must fit in one chunk");
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const int      cols_per_img = hw / VEC;
     const unsigned total        = (unsigned)n * (unsigned)cols_per_img;
     const unsigned stride       = gridDim.x * blockDim.x;
-    const int      n_chunks     = (c + T - 1) / T;
+    const int      n_chunks     = c / T;
+    const size_t   cstride      = (size_t)hw / VEC;   // channel stride in vec_t units
+
+    // one output: centre ext[j + HALF], window ext[j .. j + SIZE)
+#define PV_LRN_OUT(j_, ch_)                                                                    \
+    {                                                                                          \
+        vec_t s_ = ext[(j_)] * ext[(j_)];                                                      \
+        _Pragma("unroll") for (int q = 1; q < SIZE; ++q) s_ = s_ + ext[(j_) + q] * ext[(j_) + q]; \
+        vec_t o_;                                                                              \
+        _Pragma("unroll") for (int v = 0; v < VEC; ++v) {                                      \
+            const float d_ = bias + alpha * s_[v];                                             \
+            o_[v]          = ext[(j_) + HALF][v] / lrn_pow(d_, beta, beta_mode);               \
+        }                                                                                      \
+        yv[(size_t)(ch_) * cstride] = o_;                                                      \
+    }
+
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const unsigned img  = t / (unsigned)cols_per_img;
         const unsigned col  = t - img * (unsigned)cols_per_img;
         const size_t   base = (size_t)img * c * hw + (size_t)col * VEC;
         const vec_t* __restrict__ xv = reinterpret_cast<const vec_t*>(x + base);
         vec_t* __restrict__       yv = reinterpret_cast<vec_t*>(y + base);
-        const size_t cstride = (size_t)hw / VEC;   // channel stride in vec_t units
-        // win[0 .. 2*HALF-1]: last 2*HALF channels of the previous chunks; cur[]: chunk k; nxt[]: chunk k+1
-        vec_t win[2 * HALF], cur[T], nxt[T];
+        vec_t ext[E], nxt[T];
 #pragma unroll
-        for (int j = 0; j < 2 * HALF; ++j) win[j] = (vec_t)(0.0f);
+        for (int j = 0; j < 2 * HALF; ++j) ext[j] = (vec_t)(0.0f);
 #pragma unroll
-        for (int j = 0; j < T; ++j) cur[j] = (j < c) ? xv[(size_t)j * cstride] : (vec_t)(0.0f);
-        for (int k = 0; k <= n_chunks; ++k) {
-            // issue chunk k+1 (zeros past the last channel)
-            const int c1 = (k + 1) * T;
+        for (int j = 0; j < T; ++j) ext[2 * HALF + j] = xv[(size_t)j * cstride];
+        // chunks 0 .. n_chunks-2: prefetch the next chunk, emit what this one completes
+        for (int k = 0; k + 1 < n_chunks; ++k) {
+            const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
 #pragma unroll
-            for (int j = 0; j < T; ++j) nxt[j] = (c1 + j < c) ? xv[(size_t)(c1 + j) * cstride] : (vec_t)(0.0f);
-            // outputs [T*k - HALF, T*k + T - HALF): inputs win[] ++ cur[] form channels [T*k - 2*HALF, T*k + T)
-            vec_t ext[2 * HALF + T];
+            for (int j = 0; j < T; ++j) nxt[j] = xn[(size_t)j * cstride];
+            if (k == 0) {
 #pragma unroll
-            for (int j = 0; j < 2 * HALF; ++j) ext[j] = win[j];
+                for (int j = HALF; j < T; ++j) PV_LRN_OUT(j, j - HALF)
+            } else {
+                const int ch0 = k * T - HALF;
 #pragma unroll
-            for (int j = 0; j < T; ++j) ext[2 * HALF + j] = cur[j];
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-                const int ch = k * T - HALF + j;       // centre channel = ext[j + HALF]
-                if (ch >= 0 && ch < c) {
-                    vec_t s = ext[j] * ext[j];
-#pragma unroll
-                    for (int q = 1; q < SIZE; ++q) s = s + ext[j + q] * ext[j + q];
-                    vec_t o;
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const float d = bias + alpha * s[v];
-                        o[v]          = ext[j + HALF][v] / lrn_pow(d, beta, beta_mode);
-                    }
-                    yv[(size_t)ch * cstride] = o;
-                }
+                for (int j = 0; j < T; ++j) PV_LRN_OUT(j, ch0 + j)
             }
 #pragma unroll
-            for (int j = 0; j < 2 * HALF; ++j) win[j] = cur[T - 2 * HALF + j];
+            for (int j = 0; j < 2 * HALF; ++j) ext[j] = ext[T + j];
 #pragma unroll
-            for (int j = 0; j < T; ++j) cur[j] = nxt[j];
+            for (int j = 0; j < T; ++j) ext[2 * HALF + j] = nxt[j];
+        }
+        // last chunk (no prefetch), then the trailing HALF channels whose windows run past the tensor
+        {
+            const int k = n_chunks - 1, ch0 = k * T - HALF;
+            if (k == 0) {
+#pragma unroll
+                for (int j = HALF; j < T; ++j) PV_LRN_OUT(j, j - HALF)
+            } else {
+#pragma unroll
+                for (int j = 0; j < T; ++j) PV_LRN_OUT(j, ch0 + j)
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * HALF; ++j) ext[j] = ext[T + j];
+#pragma unroll
+            for (int j = 0; j < T; ++j) ext[2 * HALF + j] = (vec_t)(0.0f);
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) PV_LRN_OUT(j, c - HALF + j)
         }
     }
+#undef PV_LRN_OUT
 }
 
 // Fallback for window sizes without a register-window instantiation: every lane re-reads its window.
@@ -158,17 +178,26 @@ __global__ __launch_bounds__(kBlock) void lrn_generic_kernel(const float* __rest
     }
 }
 
-template <int SIZE>
-void launch_lrn_window(const float* x, float* y, int n, int c, int hw, float alpha, float beta, float bias, int bm) {
-    const bool vec4 = (hw % 4 == 0);
-    if (vec4) {
+template <int SIZE, int BETA_MODE>
+void launch_lrn_window_b(const float* x, float* y, int n, int c, int hw, float alpha, float beta, float bias) {
+    if (hw % 4 == 0) {
         const size_t cols = (size_t)n * (hw / 4);
-        hipLaunchKernelGGL((lrn_window_kernel<SIZE, 4>), dim3(grid_for(cols)), dim3(kBlock), 0, state().stream, x, y, n, c,
-                           hw, alpha, beta, bias, bm);
+        hipLaunchKernelGGL((lrn_window_kernel<SIZE, 4, BETA_MODE>), dim3(grid_for(cols)), dim3(kBlock), 0, state().stream, x, y,
+                           n, c, hw, alpha, beta, bias);
     } else {
         const size_t cols = (size_t)n * hw;
-        hipLaunchKernelGGL((lrn_window_kernel<SIZE, 1>), dim3(grid_for(cols)), dim3(kBlock), 0, state().stream, x, y, n, c,
-                           hw, alpha, beta, bias, bm);
+        hipLaunchKernelGGL((lrn_window_kernel<SIZE, 1, BETA_MODE>), dim3(grid_for(cols)), dim3(kBlock), 0, state().stream, x, y,
+                           n, c, hw, alpha, beta, bias);
+    }
+}
+
+template <int SIZE>
+void launch_lrn_window(const float* x, float* y, int n, int c, int hw, float alpha, float beta, float bias, int bm) {
+    switch (bm) {
+        case 1: launch_lrn_window_b<SIZE, 1>(x, y, n, c, hw, alpha, beta, bias); break;
+        case 2: launch_lrn_window_b<SIZE, 2>(x, y, n, c, hw, alpha, beta, bias); break;
+        case 3: launch_lrn_window_b<SIZE, 3>(x, y, n, c, hw, alpha, beta, bias); break;
+        default: launch_lrn_window_b<SIZE, 0>(x, y, n, c, hw, alpha, beta, bias); break;
     }
 }
 
@@ -198,7 +227,7 @@ int pvhip_lrn_f32(const float* x, float* y, int n, int c, int hw, int size, floa
     if (beta == 0.75f) bm = 1;
     else if (beta == 0.5f) bm = 2;
     else if (beta == 1.0f) bm = 3;
-    switch (size) {
+    switch ((c % 8 == 0 && c >= 8) ? size : 0) {
         case 3: launch_lrn_window<3>(x, y, n, c, hw, alpha, beta, bias, bm); break;
         case 5: launch_lrn_window<5>(x, y, n, c, hw, alpha, beta, bias, bm); break;
         case 7: launch_lrn_window<7>(x, y, n, c, hw, alpha, beta, bias, bm); break;
