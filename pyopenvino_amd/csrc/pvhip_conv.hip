@@ -262,6 +262,210 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// (r,s)-major variant of the LDS-tiled kernel, used whenever C is a multiple of the stage depth (16).
+//
+// On gfx950 the fp32 MFMA executes on the SIMD's vector FMA lanes: VALU instructions do not co-issue with
+// it (SQ_VALU_MFMA_COEXEC_CYCLES == 0 on this kernel family), so every VALU instruction in the reduction
+// loop is MFMA time lost.  The c-major reduction order needs ~5 VALU per gathered element (window-bit
+// test, offset add, select).  Ordering the reduction (r,s)-major instead -- row = (r*kw + s)*C + c, the
+// weight panel is packed to match -- makes the window tap constant over the C/16 stages of one (r,s):
+// the lane's byte offset `voff` (or the out-of-range sentinel when the tap falls in the padding) is
+// computed once per tap, and the 16 channel rows of a stage differ only by a wave-uniform soffset
+// c*H*W*4 handled by the scalar unit.  The gather is then buffer_load_dword voff, soffset with ZERO
+// VALU instructions per element.  Everything else (LDS staging, stage order, tiles) is as in
+// conv_igemm_kernel.  Epilogue: bias is fetched with range-checked buffer loads (no per-element bounds code).
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
+    static_assert(WAVES_M * WAVES_N == kBlock / kWave, "4 waves per workgroup");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of 32x32");
+    static_assert(BN % kWave == 0 && kBlock % BN == 0, "a wave gathers whole reduction rows");
+    constexpr int B_LOADS    = kBK * BN / kBlock;
+    constexpr int A_F4_TOTAL = kBK * BM / 4;
+    constexpr int A_F4       = (A_F4_TOTAL + kBlock - 1) / kBlock;
+    constexpr int KK         = kBK / 2;
+    constexpr unsigned kOob  = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) float As[2][kBK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBK][BN];
+
+    const int nwg = gridDim.x;
+    int       lid;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt    = lid % a.n_mtiles;
+    const int ptile = lid / a.n_mtiles;
+    const int m0    = mt * BM;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
+
+    const int OHW = a.OH * a.OW;
+    const int HW  = a.H * a.W;
+    const int pc  = tid % BN;
+    const int prow0 = __builtin_amdgcn_readfirstlane(tid / BN) * B_LOADS;
+    unsigned           xoff = 0;
+    unsigned long long inb  = 0;     // bit (r*kw + s): tap inside the image for this lane's pixel
+    {
+        const int gp = ptile * BN + pc;
+        if (gp < a.P) {
+            const int n   = gp / OHW;
+            const int rem = gp - n * OHW;
+            const int oy  = rem / a.OW;
+            const int ox  = rem - oy * a.OW;
+            const int ih0 = oy * a.sh - a.pt;
+            const int iw0 = ox * a.sw - a.pl;
+            xoff          = (unsigned)(n * a.C * HW + ih0 * a.W + iw0) * 4u;
+            for (int r = 0; r < a.kh; ++r)
+                for (int s = 0; s < a.kw; ++s)
+                    if ((unsigned)(ih0 + r) < (unsigned)a.H && (unsigned)(iw0 + s) < (unsigned)a.W)
+                        inb |= 1ull << (r * a.kw + s);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const int* __restrict__ rstab = a.ktab;            // [kh*kw + spare]: (r*W + s)*4
+    const int      ncs        = a.C / kBK;              // channel stages per tap
+    const int      nrs        = a.kh * a.kw;
+    const unsigned chan_bytes = (unsigned)HW * 4u;
+
+    float  breg[B_LOADS];
+    float4 areg[A_F4];
+
+    // state of the stage being LOADED (one ahead of the stage being multiplied)
+    int      rs_l = 0, cs_l = 0;
+    unsigned voff = (inb & 1ull) ? xoff + (unsigned)rstab[0] : kOob;
+
+#define PV2_GATHER()                                                                                    \
+    {                                                                                                   \
+        const unsigned sbase = (unsigned)(cs_l * kBK + prow0) * chan_bytes;                             \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                             \
+            breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff, sbase + (unsigned)j * chan_bytes, 0)); \
+    }
+#define PV2_ADVANCE()                                                                                   \
+    if (++cs_l == ncs) {                                                                                \
+        cs_l = 0;                                                                                       \
+        ++rs_l;                                                                                         \
+        const unsigned ro = (unsigned)rstab[rs_l];      /* spare zero entries past the last tap */      \
+        voff = (rs_l < nrs && ((inb >> rs_l) & 1ull)) ? xoff + ro : kOob;                               \
+    }
+#define PV2_LOAD_A(kt_)                                                               \
+    _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                \
+        const int f = tid + j * kBlock;                                               \
+        if (A_F4_TOTAL % kBlock == 0 || f < A_F4_TOTAL) {                             \
+            const int arow = f / (BM / 4), ac4 = f % (BM / 4);                        \
+            areg[j] = *reinterpret_cast<const float4*>(a.wp + (size_t)((kt_) * kBK + arow) * a.kout_pad + m0 + ac4 * 4); \
+        }                                                                             \
+    }
+#define PV2_STORE_TILES(buf_)                                                         \
+    {                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j) Bs[buf_][prow0 + j][pc] = breg[j]; \
+        _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                            \
+            const int f = tid + j * kBlock;                                           \
+            if (A_F4_TOTAL % kBlock == 0 || f < A_F4_TOTAL) {                         \
+                const int arow = f / (BM / 4), ac4 = f % (BM / 4);                    \
+                *reinterpret_cast<float4*>(&As[buf_][arow][ac4 * 4]) = areg[j];       \
+            }                                                                         \
+        }                                                                             \
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int wm  = wid / WAVES_N, wn = wid % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int a_col = wm * WM + l31;
+    const int b_col = wn * WN + l31;
+
+    const int nk = nrs * ncs;
+    PV2_GATHER();
+    PV2_ADVANCE();
+    PV2_LOAD_A(0);
+    PV2_STORE_TILES(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lh][a_col + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bs[buf][lh][b_col + j * 32];
+        PV2_LOAD_A(kt + 1);
+        PV2_GATHER();           // stage kt+1 (past the end: every lane reads the out-of-range sentinel -> 0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nxt][i] = As[buf][2 * (kk + 1) + lh][a_col + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[buf][2 * (kk + 1) + lh][b_col + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            if (kk + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PV2_STORE_TILES(buf ^ 1);
+        PV2_ADVANCE();
+        __syncthreads();
+    }
+#undef PV2_GATHER
+#undef PV2_ADVANCE
+#undef PV2_LOAD_A
+#undef PV2_STORE_TILES
+
+    // ---- epilogue: accumulator register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
+                                                                        a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row0 = m0 + wm * WM + i * 32 + 4 * lh;      // this lane's rows: row0 + (r&3) + 8*(r>>2)
+        float     bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // range-checked dword loads: channels >= K (and a null bias: 0 records) read as 0.  (16-byte buffer
+            // loads through this descriptor return the first dword in all four lanes of the result on gfx950.)
+            bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                br, (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * 4u, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gp = ptile * BN + wn * WN + j * 32 + l31;
+            if (gp >= a.P) continue;
+            const int n   = gp / OHW;
+            const int rem = gp - n * OHW;
+            float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff + row0) * OHW + rem;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (row0 + dr < a.K) {
+                    float v = acc[i][j][r];
+                    if (a.bias != nullptr) v = v + bv[r];
+                    if (a.relu) v = (v < 0.0f) ? 0.0f : v;
+                    yp[(size_t)dr * OHW] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Wave-direct variant: no LDS staging of operands and no barriers in the reduction loop.
 //
 // With one VGPR per fp32 MFMA operand and a wave tile of (32*TM) output channels x (32*TN) pixels, the B
@@ -274,7 +478,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
 // rows is copied to LDS once per workgroup and read per lane with ds_read_b64 (both lane halves read one
 // address each: broadcast, conflict-free).  The 4 waves of a workgroup take consecutive output-channel
 // tiles of the same pixel tile, so their B loads hit in L1.
-template <int TM, int TN, bool kMask>
+template <int TM, int TN, bool kMask, int ABLATE = 0>   // ABLATE (diagnostic builds only): 1 = no B gather, 2 = no A loads
 __global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) int2 tab[];   // [kred_pad + kTabSpare] {koff bytes, rs}
     const int tid  = threadIdx.x;
@@ -337,9 +541,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
         _Pragma("unroll") for (int s = 0; s < kBK / 2; ++s) {                                             \
             const int2 e = tab[row0 + 2 * s + lh];                                                        \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
-                breg[set_][j][s] = gather_one<kMask>(xr, e.x, e.y, inb[j], xoff[j], ih0[j], iw0[j], a.H, a.W); \
+                breg[set_][j][s] = (ABLATE & 1) ? __builtin_bit_cast(float, (xoff[j] & 0xffffu) | 0x3f800000u) \
+                                                : gather_one<kMask>(xr, e.x, e.y, inb[j], xoff[j], ih0[j], iw0[j], a.H, a.W); \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
-                areg[set_][i][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(        \
+                areg[set_][i][s] = (ABLATE & 2) ? __builtin_bit_cast(float, (woff & 0xffffu) | 0x3f800000u)   \
+                                                : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(        \
                     wr, woff + (unsigned)(i * 128), (unsigned)(row0 + 2 * s) * wrow, 0));                 \
         }                                                                                                 \
     }
@@ -397,31 +603,51 @@ __global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
     }
 }
 
+// Is the (r,s)-major reduction order (conv_igemm_rs_kernel) used for this weight shape?
+inline bool rs_major(int c, int kh, int kw) { return c % kBK == 0 && kh * kw < 64; }
+
 __global__ __launch_bounds__(kBlock) void conv_pack_kernel(const float* __restrict__ w, int* __restrict__ ktab,
                                                             float* __restrict__ wp, int K, int C, int kh, int kw, int H,
-                                                            int W, int kred, int kred_pad, int kout_pad) {
+                                                            int W, int kred, int kred_pad, int kout_pad, int rsmajor) {
     const size_t total  = (size_t)(kred_pad + kPanelSpare) * kout_pad;   // includes the spare zero stages
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const bool   mask   = kh * kw < 64;
     const int    tab_n  = kred_pad + kTabSpare;                  // spare stages of padding rows
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int kr = (int)(e / kout_pad);
+        const int kr = (int)(e / kout_pad);   // panel row
         const int ko = (int)(e % kout_pad);
-        wp[e]        = (kr < kred && ko < K) ? w[(size_t)ko * kred + kr] : 0.0f;
-    }
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)tab_n; e += stride) {
-        const int kr = (int)e;
-        int koff = 0, rs = mask ? 63 : (0x7fff << 8);
-        if (kr < kred) {
-            const int s = kr % kw;
-            const int t = kr / kw;
-            const int r = t % kh;
-            const int c = t / kh;
-            koff        = (c * H * W + r * W + s) * 4;
-            rs          = mask ? (r * kw + s) : ((r << 8) | s);
+        float     v  = 0.0f;
+        if (kr < kred && ko < K) {
+            // source reduction index in OIHW order is (c*kh + r)*kw + s
+            int src = kr;
+            if (rsmajor) {                    // panel row = (r*kw + s)*C + c
+                const int rs = kr / C, c = kr - rs * C;
+                src          = c * (kh * kw) + rs;
+            }
+            v = w[(size_t)ko * kred + src];
         }
-        ktab[kr]         = koff;
-        ktab[tab_n + kr] = rs;
+        wp[e] = v;
+    }
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)(2 * tab_n); e += stride) {
+        const int i = (int)e;
+        int       v = 0;
+        if (rsmajor) {
+            // table[rs] = byte offset of tap (r, s) inside one channel plane; zeros after the last tap
+            if (i < kh * kw) v = ((i / kw) * W + (i % kw)) * 4;
+        } else if (i < tab_n) {
+            if (i < kred) {
+                const int s = i % kw, t = i / kw, r = t % kh, c = t / kh;
+                v = (c * H * W + r * W + s) * 4;
+            }
+        } else {
+            const int kr = i - tab_n;
+            v            = mask ? 63 : (0x7fff << 8);
+            if (kr < kred) {
+                const int s = kr % kw, r = (kr / kw) % kh;
+                v           = mask ? (r * kw + s) : ((r << 8) | s);
+            }
+        }
+        ktab[i] = v;
     }
 }
 
@@ -461,7 +687,10 @@ inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
-    if (a.kh * a.kw < 64)
+    if (rs_major(a.C, a.kh, a.kw))
+        hipLaunchKernelGGL((conv_igemm_rs_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0,
+                           state().stream, a);
+    else if (a.kh * a.kw < 64)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0,
                            state().stream, a);
     else
@@ -490,7 +719,7 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
     int*   ktab = reinterpret_cast<int*>(wpack);
     float* wp   = wpack + 2 * (kred_pad + kTabSpare);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kPanelSpare) * kout_pad)), dim3(kBlock), 0, state().stream,
-                       w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad);
+                       w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad, rs_major(c, kh, kw) ? 1 : 0);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }
@@ -532,7 +761,7 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     // ---- wave-direct kernel (PVHIP_CONV_KERNEL=wave, PVHIP_CONV_WTILE=TMxTN in units of 32)
     const char* kenv = getenv("PVHIP_CONV_KERNEL");
     const size_t tab_bytes = (size_t)(a.kred_pad + kTabSpare) * sizeof(int2);
-    if (kenv != nullptr && strcmp(kenv, "wave") == 0 && tab_bytes <= 60 * 1024) {
+    if (kenv != nullptr && strcmp(kenv, "wave") == 0 && tab_bytes <= 60 * 1024 && !rs_major(c, kh, kw)) {
         int tm = 2, tn = 1;
         const char* wenv = getenv("PVHIP_CONV_WTILE");
         if (wenv != nullptr) sscanf(wenv, "%dx%d", &tm, &tn);
@@ -546,6 +775,20 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
         if (mask) hipLaunchKernelGGL((conv_wave_kernel<TM_, TN_, true>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);  \
         else hipLaunchKernelGGL((conv_wave_kernel<TM_, TN_, false>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);      \
     } while (0)
+        if (const char* ab = getenv("PVHIP_CONV_ABLATE")) {   // diagnostic: results are wrong on purpose
+            const int v = atoi(ab);
+            if (tm == 2 && tn == 1) {
+                if (v == 1) hipLaunchKernelGGL((conv_wave_kernel<2, 1, true, 1>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
+                else if (v == 2) hipLaunchKernelGGL((conv_wave_kernel<2, 1, true, 2>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
+                else hipLaunchKernelGGL((conv_wave_kernel<2, 1, true, 3>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
+            } else {
+                if (v == 1) hipLaunchKernelGGL((conv_wave_kernel<2, 2, true, 1>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
+                else if (v == 2) hipLaunchKernelGGL((conv_wave_kernel<2, 2, true, 2>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
+                else hipLaunchKernelGGL((conv_wave_kernel<2, 2, true, 3>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
+            }
+            PVHIP_LAUNCH_CHECK();
+            return PVHIP_OK;
+        }
         if (tm == 1 && tn == 1) PV_WAVE_LAUNCH(1, 1);
         else if (tm == 1 && tn == 2) PV_WAVE_LAUNCH(1, 2);
         else if (tm == 2 && tn == 1) PV_WAVE_LAUNCH(2, 1);

@@ -75,9 +75,13 @@ def main():
                      n, c, h, w, k, kh, kw, oh, ow, sh, sw, pt, pl, ctypes.c_void_p(0), 0, 0, 0)
 
         for tile in tiles + ['auto']:
-            for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE'):
+            for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE', 'PVHIP_CONV_ABLATE'):
                 os.environ.pop(envk, None)
-            if tile.startswith('w'):
+            if tile.startswith('a'):     # a<bits>w<tile>: ablated wave kernel (diagnostic)
+                os.environ['PVHIP_CONV_KERNEL'] = 'wave'
+                os.environ['PVHIP_CONV_ABLATE'] = tile[1]
+                os.environ['PVHIP_CONV_WTILE'] = tile[3:]
+            elif tile.startswith('w'):
                 os.environ['PVHIP_CONV_KERNEL'] = 'wave'
                 os.environ['PVHIP_CONV_WTILE'] = tile[1:]
             elif tile != 'auto':
