@@ -274,18 +274,22 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
 // c*H*W*4 handled by the scalar unit.  The gather is then buffer_load_dword voff, soffset with ZERO
 // VALU instructions per element.  Everything else (LDS staging, stage order, tiles) is as in
 // conv_igemm_kernel.  Epilogue: bias is fetched with range-checked buffer loads (no per-element bounds code).
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kPW>   // kPW: pointwise (1x1, stride 1, no padding, H*W % 4 == 0)
 __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
     static_assert(WAVES_M * WAVES_N == kBlock / kWave, "4 waves per workgroup");
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TM >= 1 && TN >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile is a multiple of 32x32");
     static_assert(BN % kWave == 0 && kBlock % BN == 0, "a wave gathers whole reduction rows");
-    constexpr int B_LOADS    = kBK * BN / kBlock;
+    constexpr int B_LOADS    = kBK * BN / kBlock;         // dword gather: rows per lane per stage
+    constexpr int B_LOADS4   = kBK * BN / 4 / kBlock;     // pointwise: 16-byte loads per lane per stage
+    constexpr int QUADS      = BN / 4;                    // pixel quads per tile row
+    constexpr int ROWS_PASS  = kBlock / QUADS;            // tile rows covered by one pass of the workgroup
     constexpr int A_F4_TOTAL = kBK * BM / 4;
     constexpr int A_F4       = (A_F4_TOTAL + kBlock - 1) / kBlock;
     constexpr int KK         = kBK / 2;
     constexpr unsigned kOob  = 0x80000000u;
+    static_assert(QUADS % 32 == 0 || QUADS == 32, "a half wave covers whole tile rows");
 
     __shared__ __attribute__((aligned(16))) float As[2][kBK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK][BN];
@@ -307,8 +311,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
 
     const int OHW = a.OH * a.OW;
     const int HW  = a.H * a.W;
-    const int pc  = tid % BN;
-    const int prow0 = __builtin_amdgcn_readfirstlane(tid / BN) * B_LOADS;
+    const unsigned chan_bytes = (unsigned)HW * 4u;
+    // dword gather: lane <-> one pixel, B_LOADS consecutive rows; pointwise: lane <-> one pixel quad of one row
+    const int pc    = kPW ? (tid % QUADS) * 4 : tid % BN;
+    const int prow0 = kPW ? 0 : __builtin_amdgcn_readfirstlane(tid / BN) * B_LOADS;
+    const int qrow  = tid / QUADS;                       // pointwise: tile row of pass 0 (wave-uniform up to lane>>5)
     unsigned           xoff = 0;
     unsigned long long inb  = 0;     // bit (r*kw + s): tap inside the image for this lane's pixel
     {
@@ -316,32 +323,51 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
         if (gp < a.P) {
             const int n   = gp / OHW;
             const int rem = gp - n * OHW;
-            const int oy  = rem / a.OW;
-            const int ox  = rem - oy * a.OW;
-            const int ih0 = oy * a.sh - a.pt;
-            const int iw0 = ox * a.sw - a.pl;
-            xoff          = (unsigned)(n * a.C * HW + ih0 * a.W + iw0) * 4u;
-            for (int r = 0; r < a.kh; ++r)
-                for (int s = 0; s < a.kw; ++s)
-                    if ((unsigned)(ih0 + r) < (unsigned)a.H && (unsigned)(iw0 + s) < (unsigned)a.W)
-                        inb |= 1ull << (r * a.kw + s);
+            if (kPW) {
+                xoff = (unsigned)(n * a.C * HW + rem) * 4u;
+                inb  = 1ull;
+            } else {
+                const int oy  = rem / a.OW;
+                const int ox  = rem - oy * a.OW;
+                const int ih0 = oy * a.sh - a.pt;
+                const int iw0 = ox * a.sw - a.pl;
+                xoff          = (unsigned)(n * a.C * HW + ih0 * a.W + iw0) * 4u;
+                for (int r = 0; r < a.kh; ++r)
+                    for (int s = 0; s < a.kw; ++s)
+                        if ((unsigned)(ih0 + r) < (unsigned)a.H && (unsigned)(iw0 + s) < (unsigned)a.W)
+                            inb |= 1ull << (r * a.kw + s);
+            }
         }
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const int* __restrict__ rstab = a.ktab;            // [kh*kw + spare]: (r*W + s)*4
     const int      ncs        = a.C / kBK;              // channel stages per tap
     const int      nrs        = a.kh * a.kw;
-    const unsigned chan_bytes = (unsigned)HW * 4u;
 
-    float  breg[B_LOADS];
+    float  breg[kPW ? 1 : B_LOADS];
+    float4 breg4[kPW ? B_LOADS4 : 1];
     float4 areg[A_F4];
 
     // state of the stage being LOADED (one ahead of the stage being multiplied)
     int      rs_l = 0, cs_l = 0;
     unsigned voff = (inb & 1ull) ? xoff + (unsigned)rstab[0] : kOob;
+    // pointwise: the lane's row inside a pass differs between the two half-waves only when a wave spans two
+    // tile rows (QUADS == 32); that lane-constant part is folded into voff, the wave-uniform part is added to
+    // the scalar row base.  Lanes whose pixel quad lies past the tensor read quad 0 (their columns are never
+    // stored): plain global loads have no range check.
+    const int qrow_u = __builtin_amdgcn_readfirstlane(qrow);          // row of lane 0 of this wave
+    if (kPW) voff = ((inb & 1ull) ? xoff : 0u) + (unsigned)(qrow - qrow_u) * chan_bytes;
 
 #define PV2_GATHER()                                                                                    \
-    {                                                                                                   \
+    if (kPW) {                                                                                          \
+        /* plain 16-byte global loads: uniform row base (scalar) + the lane's 32-bit byte offset.  (The     \
+           16-byte raw-buffer-load builtins of this toolchain lower to a single dword load.) */            \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS4; ++j) {                                          \
+            const char* rowp = reinterpret_cast<const char*>(a.x) +                                      \
+                               (size_t)(cs_l * kBK + qrow_u + j * ROWS_PASS) * chan_bytes;               \
+            breg4[j] = *reinterpret_cast<const float4*>(rowp + voff);                                   \
+        }                                                                                               \
+    } else {                                                                                            \
         const unsigned sbase = (unsigned)(cs_l * kBK + prow0) * chan_bytes;                             \
         _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                             \
             breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff, sbase + (unsigned)j * chan_bytes, 0)); \
@@ -350,8 +376,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
     if (++cs_l == ncs) {                                                                                \
         cs_l = 0;                                                                                       \
         ++rs_l;                                                                                         \
-        const unsigned ro = (unsigned)rstab[rs_l];      /* spare zero entries past the last tap */      \
-        voff = (rs_l < nrs && ((inb >> rs_l) & 1ull)) ? xoff + ro : kOob;                               \
+        if (kPW) {                                                                                      \
+            --rs_l;                                     /* single tap: the look-ahead past the end re-reads stage 0 (unused) */ \
+        } else {                                                                                        \
+            const unsigned ro = (unsigned)rstab[rs_l];  /* spare zero entries past the last tap */      \
+            voff = (rs_l < nrs && ((inb >> rs_l) & 1ull)) ? xoff + ro : kOob;                           \
+        }                                                                                               \
     }
 #define PV2_LOAD_A(kt_)                                                               \
     _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                                \
@@ -363,7 +393,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
     }
 #define PV2_STORE_TILES(buf_)                                                         \
     {                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j) Bs[buf_][prow0 + j][pc] = breg[j]; \
+        if (kPW) {                                                                    \
+            _Pragma("unroll") for (int j = 0; j < B_LOADS4; ++j)                      \
+                *reinterpret_cast<float4*>(&Bs[buf_][qrow + j * ROWS_PASS][pc]) = breg4[j]; \
+        } else {                                                                      \
+            _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j) Bs[buf_][prow0 + j][pc] = breg[j]; \
+        }                                                                             \
         _Pragma("unroll") for (int j = 0; j < A_F4; ++j) {                            \
             const int f = tid + j * kBlock;                                           \
             if (A_F4_TOTAL % kBlock == 0 || f < A_F4_TOTAL) {                         \
@@ -687,9 +722,18 @@ inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
-    if (rs_major(a.C, a.kh, a.kw))
-        hipLaunchKernelGGL((conv_igemm_rs_kernel<BM, BN, WAVES_M, WAVES_N>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0,
-                           state().stream, a);
+    if (rs_major(a.C, a.kh, a.kw)) {
+        const bool pointwise = a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
+                               a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && getenv("PVHIP_CONV_PW") != nullptr;   // 16-byte gather measured slower: opt-in
+        const char* pad = getenv("PVHIP_CONV_LDS_PAD_KB");     // diagnostic: extra dynamic LDS caps workgroups per CU
+        const size_t dyn = pad ? (size_t)atoi(pad) * 1024 : 0;
+        if (pointwise)
+            hipLaunchKernelGGL((conv_igemm_rs_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock),
+                               dyn, state().stream, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_rs_kernel<BM, BN, WAVES_M, WAVES_N, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock),
+                               dyn, state().stream, a);
+    }
     else if (a.kh * a.kw < 64)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0,
                            state().stream, a);

@@ -77,7 +77,12 @@ def main():
         for tile in tiles + ['auto']:
             for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE', 'PVHIP_CONV_ABLATE'):
                 os.environ.pop(envk, None)
-            if tile.startswith('a'):     # a<bits>w<tile>: ablated wave kernel (diagnostic)
+            os.environ.pop('PVHIP_CONV_LDS_PAD_KB', None)
+            if tile.startswith('p'):     # p<KB>:<tile>: LDS kernel with extra dynamic LDS (occupancy cap)
+                kb, tl = tile[1:].split(':')
+                os.environ['PVHIP_CONV_LDS_PAD_KB'] = kb
+                os.environ['PVHIP_CONV_TILE'] = tl
+            elif tile.startswith('a'):     # a<bits>w<tile>: ablated wave kernel (diagnostic)
                 os.environ['PVHIP_CONV_KERNEL'] = 'wave'
                 os.environ['PVHIP_CONV_ABLATE'] = tile[1]
                 os.environ['PVHIP_CONV_WTILE'] = tile[3:]
