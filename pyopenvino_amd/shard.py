@@ -88,7 +88,8 @@ class BatchShardComm:
         self.group = group
         self.rank = group.rank
         self.world = group.world
-        self.use_rccl = bool(use_rccl) and self.world > 1
+        # PVHIP_NO_RCCL=1 forces the host (gloo) gather: for rehearsing the multi-rank path on one GPU
+        self.use_rccl = bool(use_rccl) and self.world > 1 and os.environ.get('PVHIP_NO_RCCL') != '1'
         self._rccl_ready = False
 
     def shard(self, total: int):

@@ -143,3 +143,21 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
         port = next(iter(net_f.G.nodes[cat]['output']))
         helpers.assert_bit_exact(np.asarray(net_f.G.nodes[cat]['output'][port]['data']),
                                  np.asarray(net_u.G.nodes[cat]['output'][port]['data']), 'concat {}'.format(cat))
+
+
+def test_rccl_binding_single_rank(hip):
+    """The RCCL path of the C ABI (dlopen, unique id, communicator, all-gather, destroy) with one rank:
+    exercises every call the multi-GPU Result gather makes; with world == 1 the gather is a device copy."""
+    import ctypes
+    buf = ctypes.create_string_buffer(hip.UNIQUE_ID_BYTES)
+    hip.call('pvhip_comm_unique_id', buf)
+    assert any(b != 0 for b in buf.raw)
+    hip.call('pvhip_comm_init', ctypes.c_char_p(buf.raw), 0, 1)
+    try:
+        x = np.arange(256 * 1000, dtype=np.float32).reshape(256, 1000) * 0.5
+        send = hip.DeviceTensor.from_numpy(x)
+        recv = hip.DeviceTensor.empty(x.shape)
+        hip.call('pvhip_comm_allgather_f32', ctypes.c_void_p(send.ptr), ctypes.c_void_p(recv.ptr), x.size)
+        helpers.assert_bit_exact(np.asarray(recv), x, 'single-rank all-gather')
+    finally:
+        hip.call('pvhip_comm_destroy')
