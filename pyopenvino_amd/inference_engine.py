@@ -425,6 +425,44 @@ class Executable_Network:
             out.append((task, node_type, name, e0.elapsed_ms(e1)))
         return out
 
+    def infer_until(self, inputs: dict, node_names) -> dict:
+        """Run only what is needed to produce the outputs of the named nodes (e.g. the SSD backbone up to its
+        box / class heads, whose host-side PriorBox / DetectionOutput consumers are out of scope) and return
+        {node name: tensor of its first output port} -- device tensors are returned as they are."""
+        G = self.ienet.G
+        by_name = {G.nodes[n]['name']: n for n in G.nodes}
+        targets = [by_name[name] for name in node_names]
+        needed = set(targets)
+        for t in targets:
+            needed.update(nx.ancestors(G, t))
+        for node_name, val in inputs.items():
+            if node_name in by_name:
+                G.nodes[by_name[node_name]]['param'] = val
+        full, fa = self.task_list, self._fused_away
+        try:
+            self.task_list = [t for t in full if t in needed]
+            # a fused chain must be wholly inside the sub-graph, or be run unfused
+            keep = {}
+            for cid, f in self._fusion.items():
+                chain = [cid, f['add']] + ([f['relu']] if f['relu'] is not None else [])
+                if all(c in needed for c in chain):
+                    keep[cid] = dict(f, into=None)      # Concat elimination is not applied to sub-graphs
+            saved = (self._fusion, self._fused_away, self._concat_direct)
+            self._fusion = {c: f for c, f in keep.items()}
+            self._fused_away = {n for f in self._fusion.values() for n in (f['add'], f['relu']) if n is not None}
+            self._concat_direct = {}
+            try:
+                self.run_tasks(False)
+            finally:
+                self._fusion, self._fused_away, self._concat_direct = saved
+        finally:
+            self.task_list = full
+        out = {}
+        for name, t in zip(node_names, targets):
+            ports = G.nodes[t]['output']
+            out[name] = ports[next(iter(ports))]['data']
+        return out
+
     def infer(self, inputs: dict, verbose: bool = False) -> dict:
         G = self.ienet.G
         by_name = {G.nodes[n]['name']: n for n in G.nodes}

@@ -15,7 +15,7 @@ reference's un-shifted SoftMax stays finite):
   Add constants                 N(0, 0.05^2); a (1,3,1,1) Add straight on the Parameter is the mean
                                 (-104, -117, -123);
   Multiply constants            1 + N(0, 0.1^2) (folded BatchNorm scale); a scalar one on the Parameter is 1/127.5;
-  I64 constants                 real values: LRN axes [1]; Reshape target [0, out dims 1..]; Transpose
+  I64 constants                 real values: LRN axes [1]; Reshape target [0, -1, out dims 2..]; Transpose
                                 permutation NCHW -> NHWC; others zero.
 """
 import xml.etree.ElementTree as et
@@ -121,7 +121,11 @@ def synth_weights(xml_path: str, seed: int = 1234) -> bytes:
                 vals[:] = 1
             elif dtype_name == 'Reshape':
                 out_dims = next(v for (tag, _), v in layers[dst]['ports'].items() if tag == 'output')
+                # batch-agnostic target, and identical for layers that share one constant in the blob (the SSD
+                # heads do): copy the batch axis, infer the first remaining axis, keep the others
                 tgt = [0] + list(out_dims[1:])
+                if len(tgt) > 1:
+                    tgt[1] = -1
                 vals[:] = np.array(tgt[:count], dtype=width)
             elif dtype_name == 'Transpose':
                 in_dims = layers[dst]['ports'][('input', 0)]

@@ -18,6 +18,8 @@ Fixtures
   googlenet_e2e.npz        models/googlenet-v1 on synthetic weights (pyopenvino_amd.synth, seed 1234): 2 seeded
                            images, (2,1000) outputs stacked from two N=1 runs, per-layer sums of image 0
   mnist_bn_e2e.npz         models/mnist_bn on synthetic weights, 2 images
+  ssd_backbone_e2e.npz     models/ssd_mobilenet_v1_coco backbone + heads (up to 'concat', 'concat_1', the Sigmoid) on
+                           synthetic weights, 1 image: 'concat' in full, the two class tensors subsampled + float64 sums
   conv_node6_crop.npz      the reference's own single-node fixture resources/node_args_6.pickle (SSD Conv2d_0,
                            3x3 stride 2 same_upper pads (0,0)/(1,1)), input cropped to 64x64 and cast to fp32
 """
@@ -234,6 +236,51 @@ def model_cases(IECore):
         print('  out', out.shape, 'row sums', out.sum(axis=1), 'argmax', out.argmax(axis=1))
 
 
+def ssd_backbone_case(IECore):
+    """SSD-MobileNet backbone + box/class heads on synthetic weights, ONE image, through the reference's own
+    scheduler loop restricted to the ancestors of 'concat' / 'concat_1' / the Sigmoid (its PriorBox /
+    DetectionOutput tail is host-side glue outside the path).  GroupConvolution 'special' == its numpy loops."""
+    import networkx as nx
+    print('ssd_mobilenet_v1_coco backbone on synthetic weights (seed 1234), 1 image -- slow (python loops)')
+    tmp = '/tmp/pv_golden_models'
+    os.makedirs(tmp, exist_ok=True)
+    xml = os.path.join(REF, 'models', 'ssd_mobilenet_v1_coco.xml')
+    stem = os.path.join(tmp, 'ssd_mobilenet_v1_coco')
+    with open(stem + '.bin', 'wb') as f:
+        f.write(synth.synth_weights(xml, 1234))
+    if not os.path.exists(stem + '.xml'):
+        os.symlink(xml, stem + '.xml')
+    ie = IECore()
+    net = ie.read_network(stem + '.xml', stem + '.bin')
+    ex = ie.load_network(net, 'CPU')
+    G = net.G
+    names = ['concat', 'concat_1', 'do_ExpandDims_conf/sigmoid']
+    by_name = {G.nodes[n]['name']: n for n in G.nodes}
+    needed = set()
+    for nm in names:
+        needed.add(by_name[nm])
+        needed.update(nx.ancestors(G, by_name[nm]))
+    x = synth.uniform_pixels(700, (1, 3, 300, 300))
+    G.nodes[by_name[net.inputs[0]['name']]]['param'] = x
+    plugins = ie.plugins.plugins
+    for task in ex.task_list:
+        if task not in needed:
+            continue
+        node = G.nodes[task]
+        inputs = ex.prepare_inputs_for_task(task) if 'input' in node else {}
+        res = plugins[node['type']].compute(node, inputs, kernel_type='special', debug=False)
+        if len(res) > 0:
+            for port_id, data in res.items():
+                node['output'][port_id]['data'] = data
+    outs = {nm: np.ascontiguousarray(next(iter(G.nodes[by_name[nm]]['output'].values()))['data']) for nm in names}
+    np.savez_compressed(os.path.join(HERE, 'ssd_backbone_e2e.npz'), image_seed=np.array(700), weight_seed=np.array(1234),
+                        concat=outs['concat'], concat_1_sub=outs['concat_1'][:, ::3, ::5],
+                        concat_1_sum=np.array(outs['concat_1'].astype(np.float64).sum()),
+                        sigmoid_sub=outs['do_ExpandDims_conf/sigmoid'][:, :, ::3, ::5],
+                        sigmoid_sum=np.array(outs['do_ExpandDims_conf/sigmoid'].astype(np.float64).sum()))
+    print('  concat', outs['concat'].shape, 'concat_1', outs['concat_1'].shape, 'sum', float(outs['concat_1'].sum()))
+
+
 def node6_case(plugins):
     print('reference single-node fixture resources/node_args_6.pickle (cropped, fp32)')
     with open(os.path.join(REF, 'resources', 'node_args_6.pickle'), 'rb') as f:
@@ -247,9 +294,13 @@ def node6_case(plugins):
 def main():
     IECore = import_reference()
     plugins = IECore().plugins.plugins
+    if 'ssd' in sys.argv[1:]:            # only (re)generate the slow SSD backbone fixture
+        ssd_backbone_case(IECore)
+        return
     op_cases(plugins)
     node6_case(plugins)
     model_cases(IECore)
+    ssd_backbone_case(IECore)
     print('done')
 
 

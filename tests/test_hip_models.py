@@ -161,3 +161,18 @@ def test_rccl_binding_single_rank(hip):
         helpers.assert_bit_exact(np.asarray(recv), x, 'single-rank all-gather')
     finally:
         hip.call('pvhip_comm_destroy')
+
+
+def test_ssd_backbone_vs_reference_and_oracle(hip):
+    """BASELINE config 5: SSD-MobileNet backbone + box/class heads (Convolution, depthwise GroupConvolution,
+    Clamp, Add, Multiply, Transpose, Reshape, Concat, Sigmoid) on the GPU; image 0 against the reference's
+    recorded output, a second image against the oracle."""
+    from pyopenvino_amd import synth
+    from test_oracle_golden import check_ssd_against_fixture, ssd_backbone
+    z = np.load(os.path.join(GOLDEN, 'ssd_backbone_e2e.npz'))
+    x = np.concatenate([synth.uniform_pixels(int(z['image_seed']), (1, 3, 300, 300)), synth.uniform_pixels(701, (1, 3, 300, 300))], 0)
+    got = ssd_backbone(HIP, 2, x)
+    check_ssd_against_fixture(got, z, helpers.REL_TOL)
+    want = ssd_backbone(ORACLE, 2, x)
+    for k in got:
+        assert_close(got[k], want[k], helpers.REL_TOL, 'ssd ' + k)

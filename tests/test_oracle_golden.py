@@ -64,3 +64,30 @@ def test_oracle_synthetic_models(model, fname, shape):
             sums = layer_sums(net)
             for nid, want in zip(z['layer_ids'], z['layer_sums']):
                 assert abs(sums[int(nid)] - want) <= 2e-5 * max(1.0, abs(want)), 'layer {}'.format(nid)
+
+
+SSD_HEADS = ['concat', 'concat_1', 'do_ExpandDims_conf/sigmoid']
+
+
+def ssd_backbone(plugin_package, batch, x, fuse=True):
+    from pyopenvino_amd import synth
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'ssd_mobilenet_v1_coco.xml'), 1234)
+    _, net, ex = build_network(plugin_package, 'ssd_mobilenet_v1_coco', weights=blob, batch=batch, fuse=fuse)
+    out = ex.infer_until({net.inputs[0]['name']: x}, SSD_HEADS)
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
+def check_ssd_against_fixture(out, z, tol):
+    assert_close(out['concat'][0:1], z['concat'], tol, 'ssd concat (box encodings)')
+    assert_close(out['concat_1'][0:1][:, ::3, ::5], z['concat_1_sub'], tol, 'ssd concat_1 (class logits)')
+    assert_close(out['do_ExpandDims_conf/sigmoid'][0:1][:, :, ::3, ::5], z['sigmoid_sub'], tol, 'ssd sigmoid')
+    s = float(out['concat_1'][0:1].astype(np.float64).sum())
+    assert abs(s - float(z['concat_1_sum'])) <= 10 * tol * max(1.0, abs(float(z['concat_1_sum'])))
+
+
+def test_oracle_ssd_backbone_vs_reference():
+    """BASELINE config 5 (backbone + heads; PriorBox / DetectionOutput are host glue outside the path)."""
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, 'ssd_backbone_e2e.npz'))
+    x = synth.uniform_pixels(int(z['image_seed']), (1, 3, 300, 300))
+    check_ssd_against_fixture(ssd_backbone('oracle.op_plugins', 1, x), z, 2e-5)
