@@ -213,7 +213,7 @@ def main():
                         continue
                 roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': tf / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic,
-                        'kernel': 'conv_igemm_kernel (all instantiations; {} Convolution launches per step, bias+ReLU fused)'.format(n_launch),
+                        'kernel': 'conv_igemm_rs_kernel + conv_igemm_kernel (all instantiations; {} Convolution launches per step, bias+ReLU fused)'.format(n_launch),
                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_launch_ms * 1e3,
                         'algorithmic_bytes_per_launch': conv['bytes'] / n_launch,
                         'traffic_source': traffic_src, 'event_sampled_steps': sampled_steps}

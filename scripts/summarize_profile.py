@@ -38,19 +38,20 @@ def main():
             short = name.replace('(anonymous namespace)::', '').split('(')[0][:70]
             md.append('| `{}` | {} | {:.3f} | {:.2f} | {} |'.format(short, r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                                   float(r['AverageNs']) / 1e3, r['Percentage']))
-            if 'conv_igemm_kernel' in name:
+            if 'conv_igemm' in name:
                 conv_total_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         if conv_calls:
-            md += ['', '**conv_igemm_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+            md += ['', '**conv_igemm_kernel + conv_igemm_rs_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of 57 launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * 57 / 1e6)]
     line = os.path.join(raw, 'bench_line_under_profiler.json')
     if os.path.isfile(line) and os.path.getsize(line):
         b = json.loads(open(line).read())
-        md += ['', 'bench.py line of the profiled run: {:.1f} images/s, {:.3f} ms/step; roofline.achieved {:.2f} TFLOP/s over '
-               '{:.3f} ms of Convolution launches per step (hipEvents).'.format(b['value'], b['ms_per_step'], b['roofline']['achieved'],
-                                                                                b['roofline']['ms_per_step'])]
+        r = b['roofline']
+        md += ['', 'bench.py line of the profiled run: {:.1f} images/s, {:.3f} ms/step; roofline.achieved {:.2f} TFLOP/s = '
+               '{:.3f} GFLOP per launch / {:.2f} us average launch (hipEvents on the compute stream, {} sampled steps).'.format(
+                   b['value'], b['ms_per_step'], r['achieved'], r['flops_per_launch'] / 1e9, r['avg_launch_us'], r.get('event_sampled_steps'))]
     traffic = {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         cc = find(os.path.join(raw, 'pmc_' + counter), '*counter_collection.csv')
@@ -60,7 +61,7 @@ def main():
         for r in csv.DictReader(open(cc)):
             if r['Counter_Name'] != counter:
                 continue
-            fam = 'conv_igemm_kernel' if 'conv_igemm_kernel' in r['Kernel_Name'] else r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('<')[0].replace('void ', '')
+            fam = 'conv_igemm_kernel' if 'conv_igemm' in r['Kernel_Name'] else r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('<')[0].replace('void ', '')
             agg = per_kernel.setdefault(fam, [0.0, 0])
             agg[0] += float(r['Counter_Value'])
             agg[1] += 1
@@ -83,7 +84,7 @@ def main():
     if sq:
         agg = {}
         for r in csv.DictReader(open(sq)):
-            if 'conv_igemm_kernel' in r['Kernel_Name']:
+            if 'conv_igemm' in r['Kernel_Name']:
                 agg[r['Counter_Name']] = agg.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
         if agg.get('GRBM_GUI_ACTIVE'):
             cyc = agg['GRBM_GUI_ACTIVE'] / 8.0
