@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   2
+#define PVHIP_ABI_VERSION   3
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -127,8 +127,8 @@ int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int
  *   kernel streams and build the per-reduction-row gather table (byte offset of (c, r, s) in an h x w
  *   image).  wpack must hold pvhip_conv2d_pack_elems(k_out, c, kh, kw) floats.
  * Step 2: the convolution proper.  (oh, ow) computed by the caller per Convolution.py:21-49.
- *   bias (optional, may be NULL): per-output-channel value added in the epilogue; relu != 0 applies
- *   the ReLU.py:11 rule in the epilogue (used only by the fused Convolution->Add->ReLU path).
+ *   bias (optional, may be NULL): per-output-channel value added in the epilogue; relu == 1 applies the
+ *   ReLU.py:11 rule, relu == 2 the Clamp.py:11 rule with [act_lo, act_hi] (fused Convolution->Add->ReLU/Clamp).
  *   out_channels_total > 0: y points at a tensor [n, out_channels_total, oh, ow] and this convolution
  *   writes channels [out_channel_offset, out_channel_offset + k_out) of it -- the Concat.py:9-13 copy of an
  *   inception output done by the producer; 0 = y is the dense [n, k_out, oh, ow] result.            */
@@ -138,12 +138,15 @@ int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
                         int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
                         int sh, int sw, int pad_top, int pad_left,
                         const float* bias, int relu,
-                        int out_channel_offset, int out_channels_total);
+                        int out_channel_offset, int out_channels_total,
+                        float act_lo, float act_hi);
 
 /* GroupConvolution.py:53-79 kernel_GroupConvolution_numpy, depthwise case only (weights
- * [G,1,1,kh,kw], one input and one output channel per group), applied to every image.           */
+ * [G,1,1,kh,kw], one input and one output channel per group), applied to every image.  bias / act /
+ * act_lo / act_hi: optional fused Add(per-channel Const) and ReLU (1) or Clamp (2), as for pvhip_conv2d_f32. */
 int pvhip_dwconv2d_f32(const float* x, const float* w, float* y, int n, int g, int h, int wdt,
-                       int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left);
+                       int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left,
+                       const float* bias, int act, float act_lo, float act_hi);
 
 /* ---------------------------------------------------------------- multi-GPU gather ---------- */
 /* No reference counterpart (the reference is single-process).  Batch shards are independent; the only

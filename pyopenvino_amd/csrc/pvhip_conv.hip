@@ -1,5 +1,4 @@
-// Convolution as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), plus the
-// depthwise (GroupConvolution) VALU kernel.
+// Convolution as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
 //
 //   D[k_out][pixel] = sum_kred  Wt[kred][k_out] * Col[kred][pixel]
 //
@@ -44,7 +43,8 @@ struct ConvArgs {
     int kred_pad, kout_pad;
     int P;              // N*OH*OW
     int n_mtiles, n_ptiles;
-    int relu;
+    int   relu;             // epilogue activation: 0 none, 1 ReLU (ReLU.py:11), 2 clamp to [act_lo, act_hi] (Clamp.py:11)
+    float act_lo, act_hi;
     int y_ctotal, y_coff;   // channels of the tensor y points into, and this convolution's first channel in it
 };
 
@@ -253,7 +253,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
                 if (ko < a.K) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + a.bias[ko];
-                    if (a.relu) v = (v < 0.0f) ? 0.0f : v;
+                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
+                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
                     yp[(size_t)ko * OHW] = v;
                 }
             }
@@ -492,7 +493,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
                 if (row0 + dr < a.K) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + bv[r];
-                    if (a.relu) v = (v < 0.0f) ? 0.0f : v;
+                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
+                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
                     yp[(size_t)dr * OHW] = v;
                 }
             }
@@ -630,7 +632,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
                 if (ko < a.K) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + a.bias[ko];
-                    if (a.relu) v = (v < 0.0f) ? 0.0f : v;
+                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
+                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
                     yp[(size_t)ko * OHW] = v;
                 }
             }
@@ -686,38 +689,6 @@ __global__ __launch_bounds__(kBlock) void conv_pack_kernel(const float* __restri
     }
 }
 
-struct DwArgs {
-    int G, H, W, OH, OW, kh, kw, sh, sw, pt, pl;
-};
-
-// Depthwise 3x3-style convolution: one lane per output, lanes along the output row.
-__global__ __launch_bounds__(kBlock) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         float* __restrict__ y, DwArgs a, unsigned total) {
-    const unsigned stride = gridDim.x * blockDim.x;
-    const unsigned ohw    = (unsigned)(a.OH * a.OW);
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const unsigned plane = e / ohw;  // n*G + g
-        const unsigned rem   = e - plane * ohw;
-        const int      oy    = (int)(rem / (unsigned)a.OW);
-        const int      ox    = (int)(rem - (unsigned)oy * (unsigned)a.OW);
-        const int      g     = (int)(plane % (unsigned)a.G);
-        const float* __restrict__ xp = x + (size_t)plane * (size_t)(a.H * a.W);
-        const float* __restrict__ wg = w + (size_t)g * (a.kh * a.kw);
-        const int iy0 = oy * a.sh - a.pt, ix0 = ox * a.sw - a.pl;
-        float     sum = 0.0f;
-        for (int r = 0; r < a.kh; ++r) {
-            const int iy = iy0 + r;
-            if ((unsigned)iy >= (unsigned)a.H) continue;
-            for (int s = 0; s < a.kw; ++s) {
-                const int ix = ix0 + s;
-                if ((unsigned)ix >= (unsigned)a.W) continue;
-                sum += xp[iy * a.W + ix] * wg[r * a.kw + s];
-            }
-        }
-        y[e] = sum;
-    }
-}
-
 inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -770,7 +741,7 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
 
 int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh, int kw,
                      int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
-                     int out_channel_offset, int out_channels_total) {
+                     int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && k_out > 0 && kh > 0 && kw > 0 && oh >= 0 && ow >= 0);
     PVHIP_CHECK_ARG(sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0);
@@ -797,6 +768,8 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.x_bytes = (unsigned)(in_e * 4ull);
     a.P    = n * oh * ow;
     a.relu = relu;
+    a.act_lo = act_lo;
+    a.act_hi = act_hi;
     a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
 
@@ -866,23 +839,6 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     else if (bm == 64 && bn == 128) launch_conv<64, 128, 1, 4>(a, n_ptiles);
     else if (bm == 32 && bn == 256) launch_conv<32, 256, 1, 4>(a, n_ptiles);
     else launch_conv<32, 128, 1, 4>(a, n_ptiles);
-    PVHIP_LAUNCH_CHECK();
-    return PVHIP_OK;
-}
-
-int pvhip_dwconv2d_f32(const float* x, const float* w, float* y, int n, int g, int h, int wdt, int kh, int kw, int oh,
-                       int ow, int sh, int sw, int pad_top, int pad_left) {
-    PVHIP_REQUIRE_INIT();
-    PVHIP_CHECK_ARG(n >= 0 && g > 0 && h > 0 && wdt > 0 && kh > 0 && kw > 0 && oh >= 0 && ow >= 0 && sh > 0 && sw > 0);
-    PVHIP_CHECK_ARG(pad_top >= 0 && pad_left >= 0);
-    const unsigned long long in_e = (unsigned long long)n * g * h * wdt, out_e = (unsigned long long)n * g * oh * ow;
-    if (in_e >= (1ull << 31) || out_e >= (1ull << 31))
-        return fail(PVHIP_EUNSUPPORTED, "pvhip_dwconv2d_f32: tensor exceeds 2^31 elements");
-    if (out_e == 0) return PVHIP_OK;
-    PVHIP_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr);
-    DwArgs a{g, h, wdt, oh, ow, kh, kw, sh, sw, pad_top, pad_left};
-    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((size_t)out_e)), dim3(kBlock), 0, state().stream, x, w, y, a,
-                       (unsigned)out_e);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

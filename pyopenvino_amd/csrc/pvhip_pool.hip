@@ -248,6 +248,138 @@ __global__ __launch_bounds__(kBlock) void avgpool2d_lds_kernel(const float* __re
     }
 }
 
+// Depthwise convolution (GroupConvolution.py:53-79, one input and one output channel per group), LDS-staged
+// like MaxPool: a workgroup owns G consecutive (n, channel) planes (or a band of output rows of one plane), the
+// zero-PADDED image in LDS makes every tap an unconditional LDS read, the kh*kw weights of the group's planes sit
+// in LDS too.  Optional fused epilogue: + bias[channel], then ReLU or clamp (the Add / Clamp nodes that follow
+// every depthwise layer of the MobileNet backbone).
+struct DwEpilogue {
+    const float* bias;   // [channels] or nullptr
+    int          act;    // 0 none, 1 ReLU, 2 clamp
+    float        lo, hi;
+};
+
+template <int KH, int KW>   // 0 = run-time extent
+__global__ __launch_bounds__(kBlock) void dwconv2d_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ y, PoolArgs a, int channels, int G,
+                                                               int band_rows, PoolDivs dv, DwEpilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int kh = KH ? KH : a.kh, kw = KW ? KW : a.kw;
+    const int g0 = blockIdx.x * G;
+    const int gn = min(G, a.n_planes - g0);
+    const int oy0 = blockIdx.y * band_rows;
+    const int oy1 = min(a.oh, oy0 + band_rows);
+    const bool whole = (gridDim.y == 1);
+    const int py_lo = oy0 * a.sh;
+    const int py_hi = whole ? a.hp : min(a.hp, (oy1 - 1) * a.sh + kh);
+    const int iy_lo = max(0, py_lo - a.pt);
+    const int iy_hi = min(a.h, py_hi - a.pt);
+    const int hb    = iy_hi - iy_lo;
+    const int hwb = hb * a.w, obw = (oy1 - oy0) * a.ow;
+    const int wl = a.wp, plane_l = (py_hi - py_lo) * a.wp;
+    const int n_in = gn * hwb, n_out = gn * obw;
+    const size_t in_off = (size_t)g0 * a.h * a.w + (size_t)iy_lo * a.w;
+    const float* __restrict__ xin = x + in_off;
+    float* __restrict__ yout      = y + (size_t)g0 * a.oh * a.ow + (size_t)oy0 * a.ow;
+    const bool aligned   = ((in_off & 3) == 0);
+    const int  row_shift = iy_lo + a.pt - py_lo;
+    float* wts = tile + ((gn * plane_l + 3) & ~3);           // [gn][kh*kw] after the images
+
+    {   // zero the padded images, stage the weights of this group's planes
+        float4* t4 = reinterpret_cast<float4*>(tile);
+        const int n4 = (gn * plane_l + 3) >> 2;
+        for (int i = threadIdx.x; i < n4; i += kBlock) t4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int kk = kh * kw;
+        for (int i = threadIdx.x; i < gn * kk; i += kBlock) {
+            const int g = i / kk, t = i - g * kk;
+            wts[i] = w[(size_t)((g0 + g) % channels) * kk + t];
+        }
+    }
+    __syncthreads();
+    {
+        const int n4 = aligned ? (n_in >> 2) : 0;
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xin);
+        for (int i = threadIdx.x; i < n4; i += kBlock) {
+            const float4   v = x4[i];
+            const unsigned e = (unsigned)i * 4u;
+            unsigned g  = whole ? fdiv(e, dv.hw) : 0u;
+            unsigned r  = e - g * (unsigned)hwb;
+            unsigned iy = fdiv(r, dv.w);
+            unsigned ix = r - iy * (unsigned)a.w;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tile[g * plane_l + (iy + row_shift) * wl + ix + a.pl] = vv[q];
+                if (++ix == (unsigned)a.w) { ix = 0; if (++iy == (unsigned)hb) { iy = 0; ++g; } }
+            }
+        }
+        for (int e = (n4 << 2) + threadIdx.x; e < n_in; e += kBlock) {
+            const unsigned g = whole ? fdiv((unsigned)e, dv.hw) : 0u, r = (unsigned)e - g * (unsigned)hwb;
+            const unsigned iy = fdiv(r, dv.w), ix = r - iy * (unsigned)a.w;
+            tile[g * plane_l + (iy + row_shift) * wl + ix + a.pl] = xin[e];
+        }
+    }
+    __syncthreads();
+
+    for (int o = threadIdx.x; o < n_out; o += kBlock) {
+        const unsigned g   = whole ? fdiv((unsigned)o, dv.ohw) : 0u;
+        const unsigned rem = (unsigned)o - g * (unsigned)obw;
+        const unsigned oyl = fdiv(rem, dv.ow);
+        const unsigned ox  = rem - oyl * (unsigned)a.ow;
+        const int py0 = (int)(oy0 + oyl) * a.sh, px0 = (int)ox * a.sw;
+        const float* __restrict__ tp = tile + g * plane_l + (py0 - py_lo) * wl + px0;
+        const float* __restrict__ wg = wts + g * (kh * kw);
+        float sum = 0.0f;
+        if (KH != 0) {
+#pragma unroll
+            for (int ky = 0; ky < (KH ? KH : 1); ++ky)
+#pragma unroll
+                for (int kx = 0; kx < (KW ? KW : 1); ++kx) sum += tp[ky * wl + kx] * wg[ky * (KW ? KW : 1) + kx];
+        } else {
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx) sum += tp[ky * wl + kx] * wg[ky * kw + kx];
+        }
+        if (ep.bias != nullptr) sum = sum + ep.bias[(g0 + (int)g) % channels];
+        if (ep.act == 1) sum = (sum < 0.0f) ? 0.0f : sum;
+        else if (ep.act == 2) { sum = (sum < ep.lo) ? ep.lo : sum; sum = (sum > ep.hi) ? ep.hi : sum; }
+        yout[o] = sum;
+    }
+}
+
+// Direct fallback (planes whose bands do not fit LDS): one lane per output.
+struct DwArgs {
+    int G, H, W, OH, OW, kh, kw, sh, sw, pt, pl;
+};
+__global__ __launch_bounds__(kBlock) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, DwArgs a, unsigned total, DwEpilogue ep) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned ohw    = (unsigned)(a.OH * a.OW);
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const unsigned plane = e / ohw;  // n*G + g
+        const unsigned rem   = e - plane * ohw;
+        const int      oy    = (int)(rem / (unsigned)a.OW);
+        const int      ox    = (int)(rem - (unsigned)oy * (unsigned)a.OW);
+        const int      g     = (int)(plane % (unsigned)a.G);
+        const float* __restrict__ xp = x + (size_t)plane * (size_t)(a.H * a.W);
+        const float* __restrict__ wg = w + (size_t)g * (a.kh * a.kw);
+        const int iy0 = oy * a.sh - a.pt, ix0 = ox * a.sw - a.pl;
+        float     sum = 0.0f;
+        for (int r = 0; r < a.kh; ++r) {
+            const int iy = iy0 + r;
+            if ((unsigned)iy >= (unsigned)a.H) continue;
+            for (int s = 0; s < a.kw; ++s) {
+                const int ix = ix0 + s;
+                if ((unsigned)ix >= (unsigned)a.W) continue;
+                sum += xp[iy * a.W + ix] * wg[r * a.kw + s];
+            }
+        }
+        if (ep.bias != nullptr) sum = sum + ep.bias[g];
+        if (ep.act == 1) sum = (sum < 0.0f) ? 0.0f : sum;
+        else if (ep.act == 2) { sum = (sum < ep.lo) ? ep.lo : sum; sum = (sum > ep.hi) ? ep.hi : sum; }
+        y[e] = sum;
+    }
+}
+
 int check_pool_dims(const char* who, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw) {
     if (n < 0 || c < 0 || h <= 0 || w <= 0 || oh < 0 || ow < 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0)
         return fail(PVHIP_EINVAL, "%s: bad dims n=%d c=%d h=%d w=%d oh=%d ow=%d k=%dx%d s=%dx%d", who, n, c, h, w, oh, ow,
@@ -353,6 +485,68 @@ int pvhip_avgpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
         hipLaunchKernelGGL(avgpool2d_lds_kernel, dim3((planes + G - 1) / G), dim3(kBlock), lds, state().stream, x, y, a, G, dv);
     } else {
         hipLaunchKernelGGL(avgpool2d_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, x, y, a, total);
+    }
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_dwconv2d_f32(const float* x, const float* w, float* y, int n, int g, int h, int wdt, int kh, int kw, int oh,
+                       int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int act, float act_lo,
+                       float act_hi) {
+    PVHIP_REQUIRE_INIT();
+    int rc = check_pool_dims("pvhip_dwconv2d_f32", n, g, h, wdt, oh, ow, kh, kw, sh, sw);
+    if (rc) return rc;
+    PVHIP_CHECK_ARG(pad_top >= 0 && pad_left >= 0 && act >= 0 && act <= 2);
+    const unsigned total = (unsigned)n * g * oh * ow;
+    if (total == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr);
+    DwEpilogue ep{bias, act, act_lo, act_hi};
+    // padded extents: everything the windows touch (cells past the tensor are zeros by definition)
+    int hp = (oh - 1) * sh + kh, wp = (ow - 1) * sw + kw;
+    if (hp < h + pad_top) hp = h + pad_top;
+    if (wp < wdt + pad_left) wp = wdt + pad_left;
+    PoolArgs a{n * g, h, wdt, oh, ow, kh, kw, sh, sw, pad_top, pad_left, hp, wp};
+    const size_t group_bytes = 16 * 1024;
+    const size_t row_bytes   = (size_t)wp * sizeof(float);
+    const size_t plane_bytes = (size_t)hp * row_bytes;
+    const size_t min_band    = (size_t)(kh + sh) * row_bytes;
+    bool         lds_ok      = min_band <= 48 * 1024;
+    int          G = 1, band_rows = oh, n_bands = 1;
+    if (lds_ok) {
+        const int planes = n * g;
+        if (plane_bytes <= group_bytes) {
+            G = (int)(group_bytes / plane_bytes);
+            while (G > 4 && (planes + G - 1) / G < 8 * kNumCU) G >>= 1;
+            if ((h * wdt) % 4 != 0 && G >= 4) G &= ~3;
+            if (G > planes) G = planes;
+        } else {
+            const size_t budget = group_bytes > min_band ? group_bytes : min_band;
+            const int    rows_in = (int)(budget / row_bytes);
+            band_rows = (rows_in - kh) / sh + 1;
+            if (band_rows < 1) band_rows = 1;
+            if (band_rows > oh) band_rows = oh;
+            n_bands   = (oh + band_rows - 1) / band_rows;
+            band_rows = (oh + n_bands - 1) / n_bands;
+            n_bands   = (oh + band_rows - 1) / band_rows;
+        }
+        const int    rows_l = (n_bands == 1) ? hp : ((band_rows - 1) * sh + kh < hp ? (band_rows - 1) * sh + kh : hp);
+        const size_t lds    = ((((size_t)G * rows_l * wp + 3) & ~(size_t)3) + (size_t)G * kh * kw) * sizeof(float);
+        if (lds > 64 * 1024 || n_bands > 65535) lds_ok = false;
+        if (lds_ok) {
+            const dim3 grid((planes + G - 1) / G, n_bands);
+            PoolDivs dv{make_fastdiv((unsigned)(h * wdt)), make_fastdiv((unsigned)wdt), make_fastdiv((unsigned)(oh * ow)),
+                        make_fastdiv((unsigned)ow)};
+            if (kh == 3 && kw == 3)
+                hipLaunchKernelGGL((dwconv2d_lds_kernel<3, 3>), grid, dim3(kBlock), lds, state().stream, x, w, y, a, g, G,
+                                   band_rows, dv, ep);
+            else
+                hipLaunchKernelGGL((dwconv2d_lds_kernel<0, 0>), grid, dim3(kBlock), lds, state().stream, x, w, y, a, g, G,
+                                   band_rows, dv, ep);
+        }
+    }
+    if (!lds_ok) {
+        DwArgs d{g, h, wdt, oh, ow, kh, kw, sh, sw, pad_top, pad_left};
+        hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((size_t)total)), dim3(kBlock), 0, state().stream, x, w, y, d, total, ep);
     }
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;

@@ -60,8 +60,8 @@ SIGNATURES = {
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
     'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
-    'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int]),
-    'pvhip_dwconv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 12),
+    'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
+    'pvhip_dwconv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 12 + [_fp, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_comm_unique_id': (_c.c_int, [_c.c_void_p]),
     'pvhip_comm_init': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     'pvhip_comm_allgather_f32': (_c.c_int, [_fp, _fp, _c.c_size_t]),

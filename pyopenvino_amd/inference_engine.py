@@ -278,8 +278,10 @@ class Executable_Network:
         conv_plugin = self.ienet.ie.plugins.plugins.get('Convolution')
         if conv_plugin is None or not getattr(conv_plugin, 'SUPPORTS_FUSED_EPILOGUE', False):
             return
+        fusable = {t for t in ('Convolution', 'GroupConvolution')
+                   if getattr(self.ienet.ie.plugins.plugins.get(t), 'SUPPORTS_FUSED_EPILOGUE', False)}
         for cid in G.nodes:
-            if G.nodes[cid]['type'] != 'Convolution':
+            if G.nodes[cid]['type'] not in fusable:
                 continue
             succ = list(G.successors(cid))
             if len(succ) != 1 or G.nodes[succ[0]]['type'] != 'Add':
@@ -294,11 +296,14 @@ class Executable_Network:
             k_out = next(iter(G.nodes[cid]['output'].values()))['dims'][1]
             if tuple(G.nodes[bid]['data']['shape']) != (1, k_out, 1, 1) or G.nodes[bid]['data']['element_type'] != 'f32':
                 continue
-            rid = None
+            rid, act = None, None
             asucc = list(G.successors(aid))
             if len(asucc) == 1 and G.nodes[asucc[0]]['type'] == 'ReLU':
+                rid, act = asucc[0], ('relu',)
+            elif len(asucc) == 1 and G.nodes[asucc[0]]['type'] == 'Clamp':
                 rid = asucc[0]
-            self._fusion[cid] = {'bias': bid, 'add': aid, 'relu': rid, 'into': None}
+                act = ('clamp', float(G.nodes[rid]['data']['min']), float(G.nodes[rid]['data']['max']))
+            self._fusion[cid] = {'bias': bid, 'add': aid, 'relu': rid, 'act': act, 'into': None}
             self._fused_away.add(aid)
             if rid is not None:
                 self._fused_away.add(rid)
@@ -358,12 +363,12 @@ class Executable_Network:
             node.pop('_out_into', None)
             if fusion is not None:
                 node['_fuse_bias'] = G.nodes[fusion['bias']]['output'][0]['data']
-                node['_fuse_relu'] = fusion['relu'] is not None
+                node['_fuse_act'] = fusion['act']
                 if fusion['into'] is not None:
                     node['_out_into'] = (self._concat_buffer(fusion['into'][0]), fusion['into'][1])
             else:
                 node.pop('_fuse_bias', None)
-                node.pop('_fuse_relu', None)
+                node.pop('_fuse_act', None)
             plugin = registry.get(node_type)
             if plugin is None:
                 print("ERROR: Operation '{}' (node={}) is not supported.".format(node_type, node['name']))

@@ -11,7 +11,7 @@ from .. import device as dev
 
 
 # The engine may hand over a Convolution -> Add(per-channel Const) -> ReLU chain as one call: node['_fuse_bias']
-# (DeviceTensor of K values) and node['_fuse_relu'] are then applied in the kernel epilogue; node['_out_into'] =
+# (DeviceTensor of K values) and node['_fuse_act'] = ('relu',) | ('clamp', lo, hi) are then applied in the kernel epilogue; node['_out_into'] =
 # (tensor, channel offset) makes the kernel write its channels straight into the output of the channel Concat
 # that consumes it.
 SUPPORTS_FUSED_EPILOGUE = True
@@ -41,7 +41,7 @@ def packed_weights(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
     return wpack
 
 
-def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, relu=False, into=None):
+def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None):
     n, c, h, wd = x.shape
     kn, kc, kh, kw = w.shape
     if kc != c:
@@ -53,6 +53,11 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, relu=
         raise ValueError('could not broadcast input array: window exceeds the padded input '
                          '({}x{} padded, kernel {}x{}, stride {}, output {}x{})'.format(hp, wp, kh, kw, strides, oh, ow))
     wpack = packed_weights(node, w, h, wd)
+    act_code, act_lo, act_hi = 0, 0.0, 0.0
+    if act is not None:
+        act_code = 1 if act[0] == 'relu' else 2
+        if act_code == 2:
+            act_lo, act_hi = float(act[1]), float(act[2])
     if into is None:
         y, target, coff, ctotal = None, dev.DeviceTensor.empty((n, kn, oh, ow)), 0, 0
         y = target
@@ -63,7 +68,7 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, relu=
         y = dev.ChannelSlice(target, coff, kn)
     dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr),
              n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
-             ctypes.c_void_p(bias.ptr if bias is not None else 0), int(bool(relu)), int(coff), int(ctotal))
+             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
     return y
 
 
@@ -83,7 +88,7 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     if bias is not None:
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
-    y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, relu=bool(node.get('_fuse_relu', False)),
+    y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'),
                into=node.get('_out_into'))
     port = common_def.first_output_port(node)
     assert common_def.type_convert_tbl[node['output'][port]['precision']] == np.float32

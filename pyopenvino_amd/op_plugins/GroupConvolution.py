@@ -8,6 +8,10 @@ from .. import common_def
 from .. import device as dev
 
 
+# node['_fuse_bias'] / node['_fuse_act'] (set by the engine's fusion peephole) are applied in the kernel epilogue.
+SUPPORTS_FUSED_EPILOGUE = True
+
+
 def name():
     print('GroupConvolution')
 
@@ -36,7 +40,18 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     hp, wp = h + pads_begin[0] + pads_end[0], wd + pads_begin[1] + pads_end[1]
     if oh > 0 and ow > 0 and ((oh - 1) * strides[0] + kh > hp or (ow - 1) * strides[1] + kw > wp):
         raise ValueError('operands could not be broadcast together: window exceeds the padded input')
+    bias = node.get('_fuse_bias')
+    if bias is not None:
+        bias = dev.as_device(bias)
+        assert bias.size == grp
+    act = node.get('_fuse_act')
+    act_code, act_lo, act_hi = 0, 0.0, 0.0
+    if act is not None:
+        act_code = 1 if act[0] == 'relu' else 2
+        if act_code == 2:
+            act_lo, act_hi = float(act[1]), float(act[2])
     y = dev.DeviceTensor.empty((n, grp, oh, ow))
     dev.call('pvhip_dwconv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(w.ptr), ctypes.c_void_p(y.ptr),
-             n, grp, h, wd, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])
+             n, grp, h, wd, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
+             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, act_lo, act_hi)
     return {common_def.first_output_port(node): y}

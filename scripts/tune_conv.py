@@ -72,7 +72,7 @@ def main():
 
         def run():
             dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wp.ptr), ctypes.c_void_p(y.ptr),
-                     n, c, h, w, k, kh, kw, oh, ow, sh, sw, pt, pl, ctypes.c_void_p(0), 0, 0, 0)
+                     n, c, h, w, k, kh, kw, oh, ow, sh, sw, pt, pl, ctypes.c_void_p(0), 0, 0, 0, 0.0, 0.0)
 
         for tile in tiles + ['auto']:
             for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE', 'PVHIP_CONV_ABLATE'):
