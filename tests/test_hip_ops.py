@@ -120,6 +120,37 @@ def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
             vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'wave tile {} {}'.format(tile, xs))
 
 
+def test_conv_pointwise_16byte_gather_variant(hip, monkeypatch):
+    """The opt-in 16-byte gather of the (r,s)-major kernel for 1x1 / stride 1 / unpadded layers (PVHIP_CONV_PW=1;
+    off by default because it measured slower) stays correct, ragged last pixel tile included."""
+    monkeypatch.setenv('PVHIP_CONV_PW', '1')
+    for xs, ws in [((3, 64, 14, 14), (96, 64, 1, 1)), ((2, 32, 6, 6), (40, 32, 1, 1)), ((5, 192, 28, 28), (16, 192, 1, 1))]:
+        x = rnd(sum(xs), xs)
+        w = rnd(sum(ws), ws, (2.0 / ws[1]) ** 0.5)
+        vs_oracle('Convolution', [x, w], conv_data((1, 1), (0, 0), (0, 0)), 'pointwise {}'.format(xs))
+
+
+def test_conv_fused_bias_and_activation_bit_exact(hip):
+    """Fused epilogues (bias, then ReLU or Clamp) of both convolution kernels and of the depthwise kernel equal
+    the separate Add / ReLU / Clamp launches bit for bit."""
+    cases = [('Convolution', (2, 32, 9, 9), (40, 32, 3, 3)),     # (r,s)-major kernel
+             ('Convolution', (2, 5, 9, 9), (70, 5, 3, 3)),       # c-major kernel
+             ('GroupConvolution', (2, 24, 11, 11), (24, 1, 1, 3, 3))]
+    for type_, xs, ws in cases:
+        x, w = rnd(1, xs), rnd(2, ws, 0.2)
+        b = rnd(3, (1, ws[0], 1, 1))
+        node = make_node(type_, [x, w], conv_data((1, 1), (1, 1), (1, 1), 'same_upper' if type_ == 'GroupConvolution' else 'explicit'))
+        plain = first_out(hip_plugin(type_).compute(node, {0: x, 1: w}))
+        biased = first_out(hip_plugin('Add').compute(make_node('Add', [plain, b]), {0: plain, 1: b}))
+        for act, ref_type, data in ((('relu',), 'ReLU', None), (('clamp', 0.0, 6.0), 'Clamp', {'min': '0', 'max': '6'})):
+            want = first_out(hip_plugin(ref_type).compute(make_node(ref_type, [biased], data), {0: biased}))
+            fused_node = dict(node)
+            fused_node['_fuse_bias'] = hip.DeviceTensor.from_numpy(b)
+            fused_node['_fuse_act'] = act
+            got = first_out(hip_plugin(type_).compute(fused_node, {0: x, 1: w}))
+            assert_bit_exact(got, want, '{} fused bias + {}'.format(type_, act[0]))
+
+
 def test_conv_identity_weights_asymmetric_input(hip):
     """A = I check with asymmetric data: catches a transposed accumulator map (guide section 3)."""
     c = 40
