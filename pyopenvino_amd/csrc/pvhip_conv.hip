@@ -503,6 +503,199 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the (r,s)-major kernel: both tiles go global -> LDS with `buffer_load ... lds`, no
+// staging registers and no ds_write pass.
+//
+// The K-major LDS images make this natural.  One wave-instruction of the im2col gather fills 64
+// consecutive floats of one tile row (lane <-> pixel, per-lane source offset `voff` or the out-of-range
+// sentinel -> the hardware writes 0, wave-uniform channel row in soffset, wave-uniform LDS destination in
+// M0); the weight tile [16][BM] is a dense copy of BM/16 one-KiB pieces (16 bytes per lane).  A stage is
+// 8 gather instructions + at most 2 weight pieces per wave; the loads of stage t+1 are issued before the
+// MFMAs of stage t and waited for only at the end of it.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Global -> LDS loads (LDS-DMA), written as asm statements on purpose: hipcc treats the builtin form as a
+// store to all of LDS and puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialise the
+// loads of stage t+1 with the MFMAs of stage t.  The asm loads are invisible to its counters; the kernel
+// waits for them itself (dma_wait_all) before the barrier that publishes the stage.  `dst` is wave-uniform:
+// lane l's bytes land at dst + l*4 (b32) or dst + l*16 (b128); an out-of-range source offset writes 0.
+__device__ __forceinline__ void dma_b32(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds = (unsigned)(unsigned long)(lds_ptr_t)dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
+}
+__device__ __forceinline__ void dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds = (unsigned)(unsigned long)(lds_ptr_t)dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int BM>
+__global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
+    constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
+    constexpr int A_PIECES = kBK * BM * 4 / 1024;          // 1-KiB wave-instructions per weight tile
+    constexpr int A_PER_WAVE = (A_PIECES + 3) / 4;
+    constexpr int B_LOADS = kBK * BN / kBlock;             // gather instructions per wave per stage
+    constexpr unsigned kOob = 0x80000000u;
+    static_assert(BM % 32 == 0 && A_PIECES >= 1, "weight tile is whole 1-KiB pieces");
+
+    __shared__ __attribute__((aligned(1024))) float As[2][kBK][BM];
+    __shared__ __attribute__((aligned(1024))) float Bs[2][kBK][BN];
+
+    const int nwg = gridDim.x;
+    int       lid;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt    = lid % a.n_mtiles;
+    const int ptile = lid / a.n_mtiles;
+    const int m0    = mt * BM;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
+
+    const int OHW = a.OH * a.OW;
+    const int HW  = a.H * a.W;
+    const unsigned chan_bytes = (unsigned)HW * 4u;
+    const int phalf = (wid & 1) * 64;                      // this wave's 64 pixels of the tile
+    const int prow0 = (wid >> 1) * B_LOADS;                // and its 8 reduction rows of every stage
+    unsigned           xoff = 0;
+    unsigned long long inb  = 0;
+    {
+        const int gp = ptile * BN + phalf + lane;
+        if (gp < a.P) {
+            const int n   = gp / OHW;
+            const int rem = gp - n * OHW;
+            const int oy  = rem / a.OW;
+            const int ox  = rem - oy * a.OW;
+            const int ih0 = oy * a.sh - a.pt;
+            const int iw0 = ox * a.sw - a.pl;
+            xoff          = (unsigned)(n * a.C * HW + ih0 * a.W + iw0) * 4u;
+            for (int r = 0; r < a.kh; ++r)
+                for (int s = 0; s < a.kw; ++s)
+                    if ((unsigned)(ih0 + r) < (unsigned)a.H && (unsigned)(iw0 + s) < (unsigned)a.W)
+                        inb |= 1ull << (r * a.kw + s);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wp_bytes, 0x00020000);
+    const int* __restrict__ rstab = a.ktab;
+    const int ncs = a.C / kBK;
+    const int nrs = a.kh * a.kw;
+
+    // weight pieces of this wave: piece q covers floats [q*256, q*256 + 256) of the [16][BM] image
+    unsigned avoff[A_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < A_PER_WAVE; ++q) {
+        const int f = (wid + 4 * q) * 256 + lane * 4;
+        avoff[q]    = (unsigned)((f / BM) * a.kout_pad + m0 + (f % BM)) * 4u;
+    }
+    const unsigned a_stage_bytes = (unsigned)(kBK * a.kout_pad) * 4u;
+
+    int      rs_l = 0, cs_l = 0, kt_l = 0;      // stage being loaded
+    unsigned voff = (inb & 1ull) ? xoff + (unsigned)rstab[0] : kOob;
+
+#define PV3_ISSUE(buf_)                                                                                   \
+    {                                                                                                     \
+        const unsigned sbase = (unsigned)(cs_l * kBK + prow0) * chan_bytes;                               \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                               \
+            dma_b32(xr, &Bs[buf_][prow0 + j][phalf], voff, sbase + (unsigned)j * chan_bytes);             \
+        _Pragma("unroll") for (int q = 0; q < A_PER_WAVE; ++q)                                            \
+            if (A_PIECES % 4 == 0 || wid + 4 * q < A_PIECES)                                              \
+                dma_b128(wr, &As[buf_][0][0] + (wid + 4 * q) * 256, avoff[q], (unsigned)kt_l * a_stage_bytes); \
+    }
+#define PV3_ADVANCE()                                                                                     \
+    ++kt_l;                                                                                               \
+    if (++cs_l == ncs) {                                                                                  \
+        cs_l = 0;                                                                                         \
+        ++rs_l;                                                                                           \
+        const unsigned ro = (unsigned)rstab[rs_l];  /* spare zero entries past the last tap */            \
+        voff = (rs_l < nrs && ((inb >> rs_l) & 1ull)) ? xoff + ro : kOob;                                 \
+    }
+
+    floatx16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b_col = wid * 32 + l31;
+
+    const int nk = nrs * ncs;
+    PV3_ISSUE(0);
+    PV3_ADVANCE();
+    dma_wait_all();
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        float af[2][TM], bf[2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lh][l31 + i * 32];
+        bf[0] = Bs[buf][lh][b_col];
+        PV3_ISSUE(buf ^ 1);     // stage kt+1 (past the end: the spare zero stages)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nxt][i] = As[buf][2 * (kk + 1) + lh][l31 + i * 32];
+                bf[nxt] = Bs[buf][2 * (kk + 1) + lh][b_col];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur], acc[i], 0, 0, 0);
+            if (kk + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, TM + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PV3_ADVANCE();
+        dma_wait_all();
+        __syncthreads();
+    }
+#undef PV3_ISSUE
+#undef PV3_ADVANCE
+
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
+                                                                        a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row0 = m0 + i * 32 + 4 * lh;
+        float     bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                br, (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * 4u, 0, 0));
+        const int gp = ptile * BN + wid * 32 + l31;
+        if (gp >= a.P) continue;
+        const int n   = gp / OHW;
+        const int rem = gp - n * OHW;
+        float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff + row0) * OHW + rem;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (row0 + dr < a.K) {
+                float v = acc[i][r];
+                if (a.bias != nullptr) v = v + bv[r];
+                if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
+                else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                yp[(size_t)dr * OHW] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Wave-direct variant: no LDS staging of operands and no barriers in the reduction loop.
 //
 // With one VGPR per fp32 MFMA operand and a wave tile of (32*TM) output channels x (32*TN) pixels, the B
@@ -691,9 +884,18 @@ __global__ __launch_bounds__(kBlock) void conv_pack_kernel(const float* __restri
 
 inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
+// The LDS-DMA kernel is the default for (r,s)-major shapes; PVHIP_CONV_KERNEL=lds selects the register-staged
+// conv_igemm_rs_kernel instead (kept as a tested variant and for A/B measurements).
+inline bool dma_enabled() {
+    const char* e = getenv("PVHIP_CONV_KERNEL");
+    return e == nullptr || strcmp(e, "lds") != 0;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
-    if (rs_major(a.C, a.kh, a.kw)) {
+    if (rs_major(a.C, a.kh, a.kw) && BN == 128 && WAVES_M == 1 && dma_enabled()) {
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<BM>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+    } else if (rs_major(a.C, a.kh, a.kw)) {
         const bool pointwise = a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
                                a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && getenv("PVHIP_CONV_PW") != nullptr;   // 16-byte gather measured slower: opt-in
         const char* pad = getenv("PVHIP_CONV_LDS_PAD_KB");     // diagnostic: extra dynamic LDS caps workgroups per CU
@@ -834,6 +1036,7 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     const int n_ptiles = (a.P + bn - 1) / bn;
 
     if (bm == 128 && bn == 256) launch_conv<128, 256, 2, 2>(a, n_ptiles);
+    else if (bm == 128 && bn == 128 && dma_enabled()) launch_conv<128, 128, 1, 4>(a, n_ptiles);
     else if (bm == 128 && bn == 128) launch_conv<128, 128, 2, 2>(a, n_ptiles);
     else if (bm == 64 && bn == 256) launch_conv<64, 256, 1, 4>(a, n_ptiles);
     else if (bm == 64 && bn == 128) launch_conv<64, 128, 1, 4>(a, n_ptiles);

@@ -230,6 +230,8 @@ class Executable_Network:
         self.last_node_times = []       # [(node id, type, name, host seconds)] of the last run_tasks
         self.comm = None                # shard.BatchShardComm when the batch is sharded over ranks
         self.device_timing = None       # None, 'all', or a set of layer types: bracket those nodes with hipEvents
+        self.device_timing_runs = False # True: consecutive bracketed nodes share ONE bracket (a bracket costs ~10-15 us
+                                        # of stream time, which a per-node bracket would add to every launch)
         self.fuse_epilogues = True      # run Convolution -> Add(per-channel const) -> ReLU chains as one launch
         self._fusion = {}               # conv node id -> {'bias': const id, 'add': id, 'relu': id or None}
         self._fused_away = set()        # node ids whose compute() is folded into their producer
@@ -351,6 +353,7 @@ class Executable_Network:
         G = self.ienet.G
         registry = self.ienet.ie.plugins.plugins
         times = []
+        open_run = None
         self._infer_serial += 1
         self._recycle_events()
         for task in self.task_list:
@@ -375,12 +378,16 @@ class Executable_Network:
                 sys.exit(-1)
             timed = self.device_timing is not None and (self.device_timing == 'all' or node_type in self.device_timing)
             if timed:
-                ev0 = self._event().record()
+                if open_run is None:
+                    open_run = [task, node_type, node['name'], self._event().record(), 0]
+                open_run[4] += 1
+            elif open_run is not None and node_type not in self.NO_LAUNCH_TYPES:
+                open_run = self._close_run(open_run)
             t0 = time.time()
             res = plugin.compute(node, inputs, kernel_type=self.kernel_type, debug=False)
             dt = time.time() - t0
-            if timed:
-                self._timed.append((task, node_type, node['name'], ev0, self._event().record()))
+            if timed and not self.device_timing_runs:
+                open_run = self._close_run(open_run)
             times.append((task, node_type, node['name'], dt))
             if verbose:
                 print('{}, {}, {}, {}'.format(task, node_type, node['name'], dt))
@@ -398,6 +405,8 @@ class Executable_Network:
                         if nid is not None:
                             out = G.nodes[nid]['output']
                             out[next(iter(out))]['data'] = fused
+        if open_run is not None:
+            self._close_run(open_run)
         self.last_node_times = times
 
     def _concat_buffer(self, cat_id):
@@ -416,18 +425,28 @@ class Executable_Network:
         pool = self.__dict__.setdefault('_event_pool', [])
         return pool.pop() if pool else device.Event()
 
+    NO_LAUNCH_TYPES = ('Const', 'Parameter', 'Reshape')   # their compute() puts nothing on the stream
+
+    def _close_run(self, run):
+        task, node_type, name, e0, count = run
+        self._timed.append((task, node_type, name, e0, self._event().record(), count))
+        return None
+
     def _recycle_events(self):
         pool = self.__dict__.setdefault('_event_pool', [])
-        for _, _, _, e0, e1 in self._timed:
+        for _, _, _, e0, e1, _ in self._timed:
             pool.extend((e0, e1))
         self._timed = []
 
-    def device_times_ms(self):
-        """[(node id, type, name, milliseconds)] for the nodes bracketed in the last run_tasks (synchronises)."""
+    def device_times_ms(self, with_counts: bool = False):
+        """[(node id, type, name, milliseconds)] for the brackets of the last run_tasks (synchronises).  With
+        `device_timing_runs` a bracket spans a run of consecutive bracketed nodes: id / type / name are those of
+        its first node and `with_counts=True` appends the number of nodes it covers."""
         out = []
-        for task, node_type, name, e0, e1 in self._timed:
+        for task, node_type, name, e0, e1, count in self._timed:
             e1.synchronize()
-            out.append((task, node_type, name, e0.elapsed_ms(e1)))
+            row = (task, node_type, name, e0.elapsed_ms(e1))
+            out.append(row + (count,) if with_counts else row)
         return out
 
     def infer_until(self, inputs: dict, node_names) -> dict:

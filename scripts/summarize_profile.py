@@ -42,7 +42,7 @@ def main():
                 conv_total_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         if conv_calls:
-            md += ['', '**conv_igemm_kernel + conv_igemm_rs_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+            md += ['', '**conv_igemm_dma_kernel + conv_igemm_kernel (+ conv_igemm_rs_kernel), all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of 57 launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * 57 / 1e6)]
     line = os.path.join(raw, 'bench_line_under_profiler.json')

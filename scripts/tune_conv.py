@@ -86,6 +86,9 @@ def main():
                 os.environ['PVHIP_CONV_KERNEL'] = 'wave'
                 os.environ['PVHIP_CONV_ABLATE'] = tile[1]
                 os.environ['PVHIP_CONV_WTILE'] = tile[3:]
+            elif tile.startswith("d"):     # d<tile>: LDS-DMA kernel (the default for (r,s)-major shapes)
+                os.environ['PVHIP_CONV_KERNEL'] = 'dma'
+                os.environ['PVHIP_CONV_TILE'] = tile[1:]
             elif tile.startswith('w'):
                 os.environ['PVHIP_CONV_KERNEL'] = 'wave'
                 os.environ['PVHIP_CONV_WTILE'] = tile[1:]

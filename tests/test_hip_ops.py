@@ -99,9 +99,13 @@ def test_conv_every_tile_config(hip, monkeypatch):
     """Force each (BM, BN) instantiation on one shape that has ragged edges in both tile dimensions."""
     x = rnd(1, (3, 20, 13, 11))
     w = rnd(2, (150, 20, 3, 3), 0.1)
+    x2 = rnd(3, (3, 32, 13, 11))
+    w2 = rnd(4, (150, 32, 3, 3), 0.1)
+    monkeypatch.setenv('PVHIP_CONV_KERNEL', 'lds')      # register-staged kernels: c-major (C=20) and (r,s)-major (C=32)
     for tile in ('32x128', '32x256', '64x128', '64x256', '128x128', '128x256'):
         monkeypatch.setenv('PVHIP_CONV_TILE', tile)
         vs_oracle('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)), 'tile ' + tile)
+        vs_oracle('Convolution', [x2, w2], conv_data((1, 1), (1, 1), (1, 1)), 'rs tile ' + tile)
 
 
 def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
@@ -120,20 +124,40 @@ def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
             vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'wave tile {} {}'.format(tile, xs))
 
 
+def test_conv_lds_dma_kernel_every_tile(hip, monkeypatch):
+    """The LDS-DMA (buffer_load ... lds) kernel on every channel tile: zero padding through the out-of-range
+    sentinel, stride 2, ragged pixel and channel tiles, one and many reduction stages."""
+    cases = [((3, 32, 13, 11), (150, 32, 3, 3), (1, 1), (1, 1), (1, 1)),
+             ((2, 48, 7, 7), (24, 48, 1, 1), (1, 1), (0, 0), (0, 0)),
+             ((1, 16, 37, 37), (16, 16, 7, 7), (2, 2), (3, 3), (3, 3)),
+             ((2, 16, 10, 10), (70, 16, 5, 5), (1, 1), (2, 2), (2, 2)),
+             ((5, 192, 28, 28), (16, 192, 1, 1), (1, 1), (0, 0), (0, 0))]
+    for tile in ('32x128', '64x128', '128x128'):
+        monkeypatch.setenv('PVHIP_CONV_TILE', tile)
+        for xs, ws, st, pb, pe in cases:
+            x = rnd(sum(xs), xs)
+            w = rnd(sum(ws), ws, (2.0 / (ws[1] * ws[2] * ws[3])) ** 0.5)
+            vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'dma tile {} {}'.format(tile, xs))
+
+
 def test_conv_pointwise_16byte_gather_variant(hip, monkeypatch):
     """The opt-in 16-byte gather of the (r,s)-major kernel for 1x1 / stride 1 / unpadded layers (PVHIP_CONV_PW=1;
     off by default because it measured slower) stays correct, ragged last pixel tile included."""
     monkeypatch.setenv('PVHIP_CONV_PW', '1')
+    monkeypatch.setenv('PVHIP_CONV_KERNEL', 'lds')
     for xs, ws in [((3, 64, 14, 14), (96, 64, 1, 1)), ((2, 32, 6, 6), (40, 32, 1, 1)), ((5, 192, 28, 28), (16, 192, 1, 1))]:
         x = rnd(sum(xs), xs)
         w = rnd(sum(ws), ws, (2.0 / ws[1]) ** 0.5)
         vs_oracle('Convolution', [x, w], conv_data((1, 1), (0, 0), (0, 0)), 'pointwise {}'.format(xs))
 
 
-def test_conv_fused_bias_and_activation_bit_exact(hip):
+@pytest.mark.parametrize('kernel', ['default', 'lds'])
+def test_conv_fused_bias_and_activation_bit_exact(hip, monkeypatch, kernel):
     """Fused epilogues (bias, then ReLU or Clamp) of both convolution kernels and of the depthwise kernel equal
     the separate Add / ReLU / Clamp launches bit for bit."""
-    cases = [('Convolution', (2, 32, 9, 9), (40, 32, 3, 3)),     # (r,s)-major kernel
+    if kernel != 'default':
+        monkeypatch.setenv('PVHIP_CONV_KERNEL', kernel)
+    cases = [('Convolution', (2, 32, 9, 9), (40, 32, 3, 3)),     # (r,s)-major kernel (LDS-DMA by default)
              ('Convolution', (2, 5, 9, 9), (70, 5, 3, 3)),       # c-major kernel
              ('GroupConvolution', (2, 24, 11, 11), (24, 1, 1, 3, 3))]
     for type_, xs, ws in cases:
