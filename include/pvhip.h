@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   3
+#define PVHIP_ABI_VERSION   4
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -53,7 +53,17 @@ int         pvhip_memcpy_h2d(void* dst, const void* src, size_t bytes);  /* Para
 int         pvhip_memcpy_d2h(void* dst, const void* src, size_t bytes);  /* Result.py:17 read-back; SYNCHRONISES the stream */
 int         pvhip_memcpy_d2d(void* dst, const void* src, size_t bytes);
 int         pvhip_memset(void* dst, int byte, size_t bytes);
-int         pvhip_sync(void);                           /* hipStreamSynchronize on the compute stream */
+int         pvhip_sync(void);                           /* host-side wait for every compute stream   */
+
+/* Compute streams.  Every launch and copy goes to the CURRENT stream (stream 0 after pvhip_init).  The
+ * scheduler may put independent branches of the graph (inference_engine.py:218-242 orders them serially)
+ * on up to 8 streams and order them with untimed events; blocks freed while a stream other than 0 has been
+ * used are handed out again only after the next full synchronisation (pvhip_sync, or pvhip_memcpy_d2h
+ * issued on stream 0). */
+#define PVHIP_MAX_STREAMS 8
+int         pvhip_stream_select(int index);             /* make stream `index` current (created on first use) */
+int         pvhip_stream_wait_event(void* ev);          /* current stream waits for a recorded event  */
+int         pvhip_event_create_untimed(void** ev);      /* ordering-only event (no timestamps)        */
 
 /* events on the compute stream: replace the per-node time.time() bracket of inference_engine.py:279-283 */
 int         pvhip_event_create(void** ev);

@@ -9,10 +9,15 @@
 
 namespace pvhip {
 
+constexpr int kMaxStreams = 8;
+
 struct State {
     bool        ready  = false;
     int         device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                 // the CURRENT stream: every launch and copy goes here
+    hipStream_t streams[kMaxStreams] = {};        // streams[0] is created by pvhip_init, the others on first select
+    int         current = 0;
+    bool        forked  = false;                  // a stream other than 0 has been used since the last full sync
 };
 State& state();
 

@@ -1,4 +1,5 @@
-// libpvhip runtime plumbing: device selection, one compute stream, a size-bucketed device-memory
+// libpvhip runtime plumbing: device selection, the compute streams (one by default; the scheduler may fork
+// independent branches of a graph onto up to 8), a size-bucketed device-memory
 // pool (the scheduler keeps every activation alive between infer() calls and re-produces the same
 // shapes every call, so exact-size reuse makes steady-state allocation free), copies, events and
 // hipGraph capture of a whole forward pass.
@@ -32,6 +33,7 @@ struct Pool {
     std::mutex                                  mu;
     std::unordered_map<void*, size_t>           live;    // ptr -> rounded bytes
     std::map<size_t, std::vector<void*>>        cached;  // rounded bytes -> free blocks
+    std::vector<std::pair<void*, size_t>>       deferred; // freed while streams were forked: reusable after a full sync
     size_t                                      bytes_live = 0, bytes_cached = 0;
 };
 Pool& pool() {
@@ -41,6 +43,25 @@ Pool& pool() {
 inline size_t round_up(size_t b) {
     const size_t q = 512;
     return b == 0 ? q : (b + q - 1) / q * q;
+}
+
+// Host-side wait for every stream, after which blocks freed while the streams were forked may be reused.
+int sync_all_streams() {
+    State& s = state();
+    for (int i = 0; i < kMaxStreams; ++i)
+        if (s.streams[i] != nullptr) {
+            hipError_t e = hipStreamSynchronize(s.streams[i]);
+            if (e != hipSuccess) return fail(PVHIP_EHIP, "hipStreamSynchronize(stream %d) -> %s", i, hipGetErrorString(e));
+        }
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    for (auto& blk : p.deferred) {
+        p.cached[blk.second].push_back(blk.first);
+        p.bytes_cached += blk.second;
+    }
+    p.deferred.clear();
+    s.forked = s.current != 0;
+    return PVHIP_OK;
 }
 }  // namespace
 }  // namespace pvhip
@@ -76,7 +97,10 @@ int pvhip_init(int device) {
     if (device < 0 || device >= n)
         return fail(PVHIP_EINVAL, "pvhip_init: device %d out of range (%d visible)", device, n);
     PVHIP_HIP(hipSetDevice(device));
-    PVHIP_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    PVHIP_HIP(hipStreamCreateWithFlags(&s.streams[0], hipStreamNonBlocking));
+    s.stream  = s.streams[0];
+    s.current = 0;
+    s.forked  = false;
     s.device = device;
     s.ready  = true;
     return PVHIP_OK;
@@ -84,9 +108,9 @@ int pvhip_init(int device) {
 
 int pvhip_pool_release(void) {
     PVHIP_REQUIRE_INIT();
+    if (int rc = sync_all_streams()) return rc;
     Pool& p = pool();
     std::lock_guard<std::mutex> g(p.mu);
-    PVHIP_HIP(hipStreamSynchronize(state().stream));
     for (auto& kv : p.cached)
         for (void* ptr : kv.second) (void)hipFree(ptr);
     p.cached.clear();
@@ -106,8 +130,14 @@ int pvhip_shutdown(void) {
         p.live.clear();
         p.bytes_live = 0;
     }
-    (void)hipStreamDestroy(s.stream);
-    s.stream = nullptr;
+    for (int i = 0; i < kMaxStreams; ++i)
+        if (s.streams[i] != nullptr) {
+            (void)hipStreamDestroy(s.streams[i]);
+            s.streams[i] = nullptr;
+        }
+    s.stream  = nullptr;
+    s.current = 0;
+    s.forked  = false;
     s.ready  = false;
     s.device = -1;
     return PVHIP_OK;
@@ -139,7 +169,13 @@ int pvhip_malloc(void** ptr, size_t bytes) {
         if (e != hipSuccess) {
             // one retry after dropping the cache
             (void)hipGetLastError();
-            (void)hipStreamSynchronize(state().stream);
+            for (int i = 0; i < kMaxStreams; ++i)
+                if (state().streams[i] != nullptr) (void)hipStreamSynchronize(state().streams[i]);
+            for (auto& blk : p.deferred) {
+                p.cached[blk.second].push_back(blk.first);
+                p.bytes_cached += blk.second;
+            }
+            p.deferred.clear();
             for (auto& kv : p.cached)
                 for (void* c : kv.second) (void)hipFree(c);
             p.cached.clear();
@@ -165,6 +201,11 @@ int pvhip_free(void* ptr) {
     const size_t rb = it->second;
     p.live.erase(it);
     p.bytes_live -= rb;
+    if (state().forked) {
+        // consumers may still be queued on another stream: reusable only after the next full sync
+        p.deferred.emplace_back(ptr, rb);
+        return PVHIP_OK;
+    }
     // Stream-ordered reuse: every consumer of this block was enqueued on the single compute
     // stream before the free, and the next owner's work is enqueued after it.
     p.cached[rb].push_back(ptr);
@@ -196,6 +237,7 @@ int pvhip_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     PVHIP_CHECK_ARG(dst != nullptr && src != nullptr);
     PVHIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, state().stream));
     PVHIP_HIP(hipStreamSynchronize(state().stream));
+    if (state().forked && state().current == 0) return sync_all_streams();
     return PVHIP_OK;
 }
 
@@ -217,7 +259,34 @@ int pvhip_memset(void* dst, int byte, size_t bytes) {
 
 int pvhip_sync(void) {
     PVHIP_REQUIRE_INIT();
-    PVHIP_HIP(hipStreamSynchronize(state().stream));
+    return sync_all_streams();
+}
+
+int pvhip_stream_select(int index) {
+    PVHIP_REQUIRE_INIT();
+    State& s = state();
+    if (index < 0 || index >= kMaxStreams)
+        return fail(PVHIP_EINVAL, "pvhip_stream_select: stream %d outside 0..%d", index, kMaxStreams - 1);
+    if (s.streams[index] == nullptr) PVHIP_HIP(hipStreamCreateWithFlags(&s.streams[index], hipStreamNonBlocking));
+    s.stream  = s.streams[index];
+    s.current = index;
+    if (index != 0) s.forked = true;
+    return PVHIP_OK;
+}
+
+int pvhip_stream_wait_event(void* ev) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(ev != nullptr);
+    PVHIP_HIP(hipStreamWaitEvent(state().stream, (hipEvent_t)ev, 0));
+    return PVHIP_OK;
+}
+
+int pvhip_event_create_untimed(void** ev) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(ev != nullptr);
+    hipEvent_t e;
+    PVHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = (void*)e;
     return PVHIP_OK;
 }
 

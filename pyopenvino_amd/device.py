@@ -37,6 +37,9 @@ SIGNATURES = {
     'pvhip_memcpy_d2d': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
     'pvhip_memset': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t]),
     'pvhip_sync': (_c.c_int, []),
+    'pvhip_stream_select': (_c.c_int, [_c.c_int]),
+    'pvhip_stream_wait_event': (_c.c_int, [_c.c_void_p]),
+    'pvhip_event_create_untimed': (_c.c_int, [_c.POINTER(_c.c_void_p)]),
     'pvhip_event_create': (_c.c_int, [_c.POINTER(_c.c_void_p)]),
     'pvhip_event_destroy': (_c.c_int, [_c.c_void_p]),
     'pvhip_event_record': (_c.c_int, [_c.c_void_p]),
@@ -320,14 +323,25 @@ def i64_array(values):
     return arr
 
 
-class Event:
-    """hipEvent on the compute stream (device-side timing of the hot path)."""
+def select_stream(index: int):
+    """Make compute stream `index` (0..7) the current one: every later launch and copy goes to it."""
+    call('pvhip_stream_select', int(index))
 
-    def __init__(self):
+
+class Event:
+    """hipEvent on the current compute stream: device-side timing of the hot path (`timed=True`), or an
+    ordering-only event that another stream waits for (`timed=False`)."""
+
+    def __init__(self, timed: bool = True):
         ensure_init()
         h = _c.c_void_p(0)
-        call('pvhip_event_create', _c.byref(h))
+        call('pvhip_event_create' if timed else 'pvhip_event_create_untimed', _c.byref(h))
         self.handle = h.value
+
+    def wait(self):
+        """The current stream waits (on the device) until this event's recorded work has finished."""
+        call('pvhip_stream_wait_event', _c.c_void_p(self.handle))
+        return self
 
     def record(self):
         call('pvhip_event_record', _c.c_void_p(self.handle))

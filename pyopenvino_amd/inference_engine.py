@@ -238,6 +238,10 @@ class Executable_Network:
         self._concat_direct = {}        # Concat node id -> total channels, when every input is written in place
         self._infer_serial = 0
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
+        # Independent branches of the graph (the four arms of an inception module) go to separate compute
+        # streams, ordered by untimed events; only for plugin sets whose tensors live on the device.
+        self.compute_streams = int(os.environ.get('PVHIP_STREAMS', '4'))
+        self._stream_plans = {}
 
     def schedule_tasks(self):
         """Static list schedule: sources (Const, Parameter) first, then repeated sweeps in node order
@@ -349,6 +353,59 @@ class Executable_Network:
             inputs[sink_port] = G.nodes[src_node]['output'][src_port]['data']
         return inputs
 
+    def plan_streams(self):
+        """Static stream assignment for the current task list (the reference's list scheduler
+        runs the branches of a module one after the other, :259-292).  A node runs on the stream of the
+        producer of its data input if it is that tensor's first consumer in schedule order; the tensor's
+        j-th consumer goes to the j-th next stream, so the arms of a fan-out run side by side.  Returns
+        (stream of task, tasks to wait for, tasks that must record an event) or None when not applicable."""
+        registry = self.ienet.ie.plugins.plugins
+        n = min(int(self.compute_streams), 8)
+        if n <= 1 or not all(getattr(sys.modules.get(m.__package__), 'DEVICE_STREAMS', False) for m in registry.values()):
+            return None                  # some plugin of the set computes on the host
+        key = (tuple(self.task_list), frozenset(self._fused_away), n)
+        plan = self._stream_plans.get(key)
+        if plan is not None:
+            return plan
+        G = self.ienet.G
+        owner = {}                       # folded-away node -> the dispatched node that writes its tensor
+        for cid, f in self._fusion.items():
+            for nid in (f['add'], f['relu']):
+                if nid is not None:
+                    owner[nid] = cid
+
+        def producers(nid):
+            if nid in self._concat_direct and nid in self._fused_away:
+                return [p for pred in G.pred[nid] for p in producers(pred)]
+            if nid in owner:
+                return [owner[nid]]
+            if G.nodes[nid]['type'] in ('Const', 'Parameter'):
+                return []                # uploads are synchronous (or the tensor is already resident)
+            return [nid]
+
+        stream_of, waits, records, placed = {}, {}, set(), {}
+        for task in self.task_list:
+            if task in self._fused_away or G.nodes[task]['type'] in ('Const', 'Parameter'):
+                continue
+            preds = sorted(G.pred[task], key=lambda p: G.edges[(p, task)]['connection'][3])
+            primary = next((p for p in preds if producers(p)), None)
+            if primary is None:
+                stream_of[task] = 0
+            else:
+                j = placed.get(primary, 0)
+                placed[primary] = j + 1
+                stream_of[task] = (stream_of[producers(primary)[0]] + j) % n
+            deps = []
+            for pred in preds:
+                for p in producers(pred):
+                    if stream_of[p] != stream_of[task] and p not in deps:
+                        deps.append(p)
+            waits[task] = deps
+            records.update(deps)
+        plan = (stream_of, waits, records)
+        self._stream_plans[key] = plan
+        return plan
+
     def run_tasks(self, verbose: bool = False):
         G = self.ienet.G
         registry = self.ienet.ie.plugins.plugins
@@ -356,11 +413,24 @@ class Executable_Network:
         open_run = None
         self._infer_serial += 1
         self._recycle_events()
+        plan = self.plan_streams()
+        if plan is not None:
+            from . import device
+            stream_of, waits, records = plan
+            done_events, spare, current = {}, self.__dict__.setdefault('_order_events', []), 0
+            device.select_stream(1)      # the whole pass counts as forked: blocks freed during it are not
+            device.select_stream(0)      # handed out again before the synchronisation that ends it
         for task in self.task_list:
             if task in self._fused_away:
                 continue
             node = G.nodes[task]
             node_type = node['type']
+            if plan is not None and task in stream_of:
+                if stream_of[task] != current:
+                    current = stream_of[task]
+                    device.select_stream(current)
+                for dep in waits[task]:
+                    done_events[dep].wait()
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
             fusion = self._fusion.get(task)
             node.pop('_out_into', None)
@@ -388,6 +458,8 @@ class Executable_Network:
             dt = time.time() - t0
             if timed and not self.device_timing_runs:
                 open_run = self._close_run(open_run)
+            if plan is not None and task in records:
+                done_events[task] = (spare.pop() if spare else device.Event(timed=False)).record()
             times.append((task, node_type, node['name'], dt))
             if verbose:
                 print('{}, {}, {}, {}'.format(task, node_type, node['name'], dt))
@@ -407,6 +479,19 @@ class Executable_Network:
                             out[next(iter(out))]['data'] = fused
         if open_run is not None:
             self._close_run(open_run)
+        if plan is not None:
+            # join: stream 0 continues after everything the other streams were given, then the host waits
+            # (infer() has read the Result back by now, so this costs nothing) and freed blocks become reusable
+            joins = []
+            for st in sorted(set(stream_of.values()) - {0}):
+                device.select_stream(st)
+                joins.append((spare.pop() if spare else device.Event(timed=False)).record())
+            device.select_stream(0)
+            for ev in joins:
+                ev.wait()
+            device.synchronize()
+            spare.extend(joins)
+            spare.extend(done_events.values())
         self.last_node_times = times
 
     def _concat_buffer(self, cat_id):

@@ -1,1 +1,5 @@
 """One module per IR layer type; the module name is the layer type (reference inference_engine.py:28-43)."""
+
+# Every plugin of this package takes and returns device-resident tensors and enqueues its work on the current
+# compute stream, so the engine may fork independent branches of a graph onto separate streams.
+DEVICE_STREAMS = True

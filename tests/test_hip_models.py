@@ -1,5 +1,6 @@
 """Whole models through the HIP plugins: against the reference's recorded outputs, against the oracle at
 small batch, and through size-independent properties at the BASELINE batch sizes.  GPU only."""
+import ctypes
 import os
 
 import numpy as np
@@ -143,6 +144,37 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
         port = next(iter(net_f.G.nodes[cat]['output']))
         helpers.assert_bit_exact(np.asarray(net_f.G.nodes[cat]['output'][port]['data']),
                                  np.asarray(net_u.G.nodes[cat]['output'][port]['data']), 'concat {}'.format(cat))
+
+
+def test_forked_streams_give_the_single_stream_bits(hip):
+    """The inception arms forked onto 4 compute streams (the default) give exactly the bits of the serial single
+    stream run, for every layer, on repeated passes (a missing event would show as a stale or half-written
+    tensor); the pool does not grow from pass to pass (blocks freed during a forked pass come back after its
+    closing synchronisation)."""
+    from pyopenvino_amd import synth
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), 1234)
+    B = 48    # large enough that kernels of different arms really overlap
+    x = synth.uniform_pixels(555, (B, 3, 224, 224))
+    _, net_s, ex_s = build_network(HIP, 'googlenet-v1', weights=blob, batch=B)
+    ex_s.compute_streams = 1
+    want = infer_one(ex_s, net_s, x)
+    want_layers = helpers.layer_sums(net_s)
+    for fuse in (True, False):
+        _, net_m, ex_m = build_network(HIP, 'googlenet-v1', weights=blob, batch=B, fuse=fuse)
+        ex_m.compute_streams = 4
+        assert ex_m.plan_streams() is not None
+        sizes = []
+        for it in range(4):
+            got = infer_one(ex_m, net_m, x)
+            assert np.array_equal(got, want), 'pass {} fuse {}'.format(it, fuse)
+            in_use, cached = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            hip.call('pvhip_pool_stats', ctypes.byref(in_use), ctypes.byref(cached))
+            sizes.append(in_use.value + cached.value)
+        assert sizes[-1] == sizes[-2] == sizes[-3], sizes
+        if fuse:
+            got_layers = helpers.layer_sums(net_m)
+            assert got_layers == want_layers
+    del net_s, ex_s
 
 
 def test_rccl_binding_single_rank(hip):

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', device.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r' T (pvhip_[a-z0-9_]+)', nm))
     assert declared <= exported
-    assert lib.pvhip_abi_version() == 3
+    assert lib.pvhip_abi_version() == 4
     assert isinstance(lib.pvhip_last_error(), bytes)
 
 
@@ -176,3 +176,35 @@ def test_bench_work_model_matches_survey_totals():
     assert abs(pool_bytes / 1e6 - (11.503 + 5.670)) < 0.01
     relu_bytes = sum(b for nid, (f, b) in work.items() if net.G.nodes[nid]['type'] == 'ReLU')
     assert abs(relu_bytes / 1e6 - 2 * 12.905) < 0.01
+
+
+def test_stream_plan_orders_every_cross_stream_edge():
+    """plan_streams on GoogLeNet (fused, Concat-eliminated) and on the unfused graph: every producer a node
+    reads from is either on the node's own stream or in its wait list (and records an event); the four arms
+    of an inception module land on four different streams; a host plugin set gets no plan."""
+    for fuse in (True, False):
+        _, net, ex = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=fuse)
+        ex.compute_streams = 4
+        stream_of, waits, records = ex.plan_streams()
+        G = net.G
+        assert set(stream_of.values()) == {0, 1, 2, 3}
+
+        def writers(nid):                    # dispatched nodes whose kernels write the tensor `nid` hands on
+            if nid in ex._fused_away and G.nodes[nid]['type'] == 'Concat':
+                return [w for p in G.pred[nid] for w in writers(p)]
+            if nid in ex._fused_away:
+                return [w for p in G.pred[nid] if G.nodes[p]['type'] != 'Const' for w in writers(p)]
+            return [] if G.nodes[nid]['type'] in ('Const', 'Parameter') else [nid]
+
+        position = {t: i for i, t in enumerate(ex.task_list)}
+        for task, st in stream_of.items():
+            for pred in G.pred[task]:
+                for w in writers(pred):
+                    assert position[w] < position[task]
+                    assert stream_of[w] == st or (w in waits[task] and w in records), (G.nodes[task]['name'], G.nodes[w]['name'])
+        by_name = {G.nodes[n]['name']: n for n in G.nodes}
+        arms = [by_name['inception_3a/' + a + '/WithoutBiases'] for a in ('1x1', '3x3_reduce', '5x5_reduce')] + [by_name['inception_3a/pool']]
+        assert len({stream_of[a] for a in arms}) == 4
+        assert stream_of[by_name['inception_3a/3x3/WithoutBiases']] == stream_of[by_name['inception_3a/3x3_reduce/WithoutBiases']]
+    _, _, ex = helpers.build_network('oracle.op_plugins', 'mnist')
+    assert ex.plan_streams() is None
