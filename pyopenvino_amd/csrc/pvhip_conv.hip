@@ -513,6 +513,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
 // 8 gather instructions + at most 2 weight pieces per wave; the loads of stage t+1 are issued before the
 // MFMAs of stage t and waited for only at the end of it.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(4))) int* const_int_p;
 
 // Global -> LDS loads (LDS-DMA), written as asm statements on purpose: hipcc treats the builtin form as a
 // store to all of LDS and puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialise the
@@ -535,7 +536,7 @@ __device__ __forceinline__ void dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, u
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int BM>
+template <int BM, bool kRS>   // kRS: (r,s)-major reduction order (C % 16 == 0); else c-major with the window-bit table
 __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
     constexpr int A_PIECES = kBK * BM * 4 / 1024;          // 1-KiB wave-instructions per weight tile
@@ -587,8 +588,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wp_bytes, 0x00020000);
-    const int* __restrict__ rstab = a.ktab;
-    const int ncs = a.C / kBK;
+    // The gather tables were written by conv_pack_kernel in an earlier launch and are constant here: read them
+    // through the constant address space so that the loads stay scalar (s_load) next to the asm statements.
+    const const_int_p rstab  = (const_int_p)(unsigned long)a.ktab;
+    const const_int_p tab_rs = rstab + a.kred_pad + kTabSpare;          // c-major: window-bit index of every row
+    const int ncs = kRS ? a.C / kBK : 1;
     const int nrs = a.kh * a.kw;
 
     // weight pieces of this wave: piece q covers floats [q*256, q*256 + 256) of the [16][BM] image
@@ -601,20 +605,38 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     const unsigned a_stage_bytes = (unsigned)(kBK * a.kout_pad) * 4u;
 
     int      rs_l = 0, cs_l = 0, kt_l = 0;      // stage being loaded
-    unsigned voff = (inb & 1ull) ? xoff + (unsigned)rstab[0] : kOob;
+    unsigned voff = kRS ? ((inb & 1ull) ? xoff + (unsigned)rstab[0] : kOob) : 0u;
+    // c-major: the 8 table entries (byte offset c*H*W + r*W + s, window bit r*kw + s; padding rows carry bit 63,
+    // never set) of this wave's rows of the stage being loaded, in scalar registers
+    int tko[B_LOADS], trs[B_LOADS];
+#define PV3_LOAD_ENT(kt_)                                                                                 \
+    if (!kRS) {                                                                                           \
+        const const_int_p tp = rstab + (kt_) * kBK + prow0;                                               \
+        const const_int_p tq = tab_rs + (kt_) * kBK + prow0;                                              \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j) { tko[j] = tp[j]; trs[j] = tq[j]; }           \
+    }
+    PV3_LOAD_ENT(0);
 
 #define PV3_ISSUE(buf_)                                                                                   \
     {                                                                                                     \
-        const unsigned sbase = (unsigned)(cs_l * kBK + prow0) * chan_bytes;                               \
-        _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                               \
-            dma_b32(xr, &Bs[buf_][prow0 + j][phalf], voff, sbase + (unsigned)j * chan_bytes);             \
+        if (kRS) {                                                                                        \
+            const unsigned sbase = (unsigned)(cs_l * kBK + prow0) * chan_bytes;                           \
+            _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                           \
+                dma_b32(xr, &Bs[buf_][prow0 + j][phalf], voff, sbase + (unsigned)j * chan_bytes);         \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j) {                                         \
+                const unsigned off = ((unsigned)(inb >> trs[j]) & 1u) ? xoff + (unsigned)tko[j] : kOob;   \
+                dma_b32(xr, &Bs[buf_][prow0 + j][phalf], off, 0u);                                        \
+            }                                                                                             \
+        }                                                                                                 \
         _Pragma("unroll") for (int q = 0; q < A_PER_WAVE; ++q)                                            \
             if (A_PIECES % 4 == 0 || wid + 4 * q < A_PIECES)                                              \
                 dma_b128(wr, &As[buf_][0][0] + (wid + 4 * q) * 256, avoff[q], (unsigned)kt_l * a_stage_bytes); \
     }
 #define PV3_ADVANCE()                                                                                     \
     ++kt_l;                                                                                               \
-    if (++cs_l == ncs) {                                                                                  \
+    PV3_LOAD_ENT(kt_l);                                                                                   \
+    if (kRS && ++cs_l == ncs) {                                                                           \
         cs_l = 0;                                                                                         \
         ++rs_l;                                                                                           \
         const unsigned ro = (unsigned)rstab[rs_l];  /* spare zero entries past the last tap */            \
@@ -630,7 +652,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int b_col = wid * 32 + l31;
 
-    const int nk = nrs * ncs;
+    const int nk = kRS ? nrs * ncs : a.kred_pad / kBK;
     PV3_ISSUE(0);
     PV3_ADVANCE();
     dma_wait_all();
@@ -664,6 +686,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
         __syncthreads();
     }
 #undef PV3_ISSUE
+#undef PV3_LOAD_ENT
 #undef PV3_ADVANCE
 
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
@@ -893,8 +916,13 @@ inline bool dma_enabled() {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
-    if (rs_major(a.C, a.kh, a.kw) && BN == 128 && WAVES_M == 1 && dma_enabled()) {
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<BM>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+    if (BN == 128 && WAVES_M == 1 && dma_enabled() && (rs_major(a.C, a.kh, a.kw) || a.kh * a.kw < 64)) {
+        const char* pad = getenv("PVHIP_CONV_LDS_PAD_KB");     // diagnostic: extra dynamic LDS caps workgroups per CU
+        const size_t dyn = pad ? (size_t)atoi(pad) * 1024 : 0;
+        if (rs_major(a.C, a.kh, a.kw))
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
     } else if (rs_major(a.C, a.kh, a.kw)) {
         const bool pointwise = a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
                                a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && getenv("PVHIP_CONV_PW") != nullptr;   // 16-byte gather measured slower: opt-in

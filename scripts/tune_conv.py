@@ -78,10 +78,14 @@ def main():
             for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE', 'PVHIP_CONV_ABLATE'):
                 os.environ.pop(envk, None)
             os.environ.pop('PVHIP_CONV_LDS_PAD_KB', None)
-            if tile.startswith('p'):     # p<KB>:<tile>: LDS kernel with extra dynamic LDS (occupancy cap)
+            if tile == 'auto':           # the library's own kernel / tile choice
+                pass
+            elif tile.startswith('p'):     # p<KB>:<tile>: LDS kernel with extra dynamic LDS (occupancy cap)
                 kb, tl = tile[1:].split(':')
                 os.environ['PVHIP_CONV_LDS_PAD_KB'] = kb
-                os.environ['PVHIP_CONV_TILE'] = tl
+                os.environ['PVHIP_CONV_TILE'] = tl.lstrip('d')
+                if not tl.startswith('d'):
+                    os.environ['PVHIP_CONV_KERNEL'] = 'lds'
             elif tile.startswith('a'):     # a<bits>w<tile>: ablated wave kernel (diagnostic)
                 os.environ['PVHIP_CONV_KERNEL'] = 'wave'
                 os.environ['PVHIP_CONV_ABLATE'] = tile[1]

@@ -125,13 +125,18 @@ def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
 
 
 def test_conv_lds_dma_kernel_every_tile(hip, monkeypatch):
-    """The LDS-DMA (buffer_load ... lds) kernel on every channel tile: zero padding through the out-of-range
-    sentinel, stride 2, ragged pixel and channel tiles, one and many reduction stages."""
+    """The LDS-DMA (buffer_load ... lds) kernel, both reduction orders, on every channel tile: zero padding
+    through the out-of-range sentinel, stride 2, ragged pixel and channel tiles, one and many reduction stages."""
     cases = [((3, 32, 13, 11), (150, 32, 3, 3), (1, 1), (1, 1), (1, 1)),
              ((2, 48, 7, 7), (24, 48, 1, 1), (1, 1), (0, 0), (0, 0)),
              ((1, 16, 37, 37), (16, 16, 7, 7), (2, 2), (3, 3), (3, 3)),
              ((2, 16, 10, 10), (70, 16, 5, 5), (1, 1), (2, 2), (2, 2)),
-             ((5, 192, 28, 28), (16, 192, 1, 1), (1, 1), (0, 0), (0, 0))]
+             ((5, 192, 28, 28), (16, 192, 1, 1), (1, 1), (0, 0), (0, 0)),
+             # c-major reduction order (C not a multiple of 16): per-row window-bit table
+             ((3, 20, 13, 11), (150, 20, 3, 3), (1, 1), (1, 1), (1, 1)),
+             ((1, 3, 37, 37), (16, 3, 7, 7), (2, 2), (3, 3), (3, 3)),
+             ((2, 9, 10, 10), (70, 9, 5, 5), (1, 1), (2, 2), (2, 2)),
+             ((2, 1, 12, 12), (8, 1, 3, 3), (1, 1), (0, 0), (0, 0))]
     for tile in ('32x128', '64x128', '128x128'):
         monkeypatch.setenv('PVHIP_CONV_TILE', tile)
         for xs, ws, st, pb, pe in cases:
