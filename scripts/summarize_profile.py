@@ -24,8 +24,10 @@ def main():
     prof = os.path.join(repo, 'profiles')
     os.makedirs(prof, exist_ok=True)
     md = ['# rocprofv3 summary `{}`'.format(tag), '',
-          'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0` '
-          '(7 forward passes of googlenet-v1, batch 256, 1 GPU).', '']
+          'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0 --streams 1` '
+          '(googlenet-v1, batch 256, 1 GPU; ONE compute stream, so that a launch\'s start-to-end time is its own: this is what '
+          'bench.py\'s roofline measures on its sampled single-stream steps).  The default command (inception arms forked onto 4 streams, '
+          'kernels overlapping) is summarised at the end.', '']
     stats = find(os.path.join(raw, 'stats'), '*kernel_stats.csv')
     conv_total_ns = conv_calls = 0
     if stats:
@@ -52,6 +54,24 @@ def main():
         md += ['', 'bench.py line of the profiled run: {:.1f} images/s, {:.3f} ms/step; roofline.achieved {:.2f} TFLOP/s = '
                '{:.3f} GFLOP per launch / {:.2f} us average launch (hipEvents on the compute stream, {} sampled steps).'.format(
                    b['value'], b['ms_per_step'], r['achieved'], r['flops_per_launch'] / 1e9, r['avg_launch_us'], r.get('event_sampled_steps'))]
+    forked = find(os.path.join(raw, 'stats_forked'), '*kernel_stats.csv')
+    forked_md = []
+    if forked:
+        tot = calls = 0.0
+        for r in csv.DictReader(open(forked)):
+            if 'conv_igemm' in r['Name']:
+                tot += float(r['TotalDurationNs'])
+                calls += int(r['Calls'])
+        with open(os.path.join(prof, tag + '_kernel_stats_forked.csv'), 'w') as f:
+            f.write(open(forked).read())
+        forked_md = ['', '## Default command (4 compute streams)', '',
+                     '`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0`: per-kernel table in `{}_kernel_stats_forked.csv`.  '
+                     'Convolution launches: {:.0f}, average start-to-end {:.2f} us -- longer than on one stream because launches of different arms '
+                     'share the chip; the step is shorter.'.format(tag, calls, tot / max(1.0, calls) / 1e3)]
+        fl = os.path.join(raw, 'bench_line_forked.json')
+        if os.path.isfile(fl) and os.path.getsize(fl):
+            b = json.loads(open(fl).read())
+            forked_md.append('bench.py line of that run: {:.1f} images/s, {:.3f} ms/step.'.format(b['value'], b['ms_per_step']))
     traffic = {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         cc = find(os.path.join(raw, 'pmc_' + counter), '*counter_collection.csv')
@@ -91,8 +111,19 @@ def main():
             md += ['', '## conv_igemm_kernel, SQ counters summed over its launches', '']
             md += ['- MFMA pipe busy: {:.1f} % of SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))'.format(
                 100.0 * agg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / cyc)]
+            if agg.get('SQ_BUSY_CU_CYCLES'):
+                md += ['- CUs holding at least one wave: {:.1f} % of CU-cycles (SQ_BUSY_CU_CYCLES / 256 CUs / (GRBM_GUI_ACTIVE / 8))'.format(
+                    100.0 * agg['SQ_BUSY_CU_CYCLES'] / 256.0 / cyc)]
+            kt = find(os.path.join(raw, 'pmc_SQ'), '*kernel_trace.csv')
+            if kt:
+                dur = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(kt)) if 'conv_igemm' in r['Kernel_Name'])
+                if dur:
+                    ghz = cyc / dur
+                    md += ['- shader clock while these kernels ran: {:.2f} GHz (GRBM_GUI_ACTIVE / 8 / summed kernel time) -> fp32 MFMA ceiling at that clock '
+                           '{:.0f} TFLOP/s (157.3 at 2.4 GHz)'.format(ghz, 157.3 * ghz / 2.4)]
             for k in sorted(agg):
                 md.append('- {} = {:.4g}'.format(k, agg[k]))
+    md += forked_md
     with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
         f.write('\n'.join(md) + '\n')
     print('\n'.join(md))
