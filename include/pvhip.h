@@ -158,6 +158,18 @@ int pvhip_dwconv2d_f32(const float* x, const float* w, float* y, int n, int g, i
                        int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left,
                        const float* bias, int act, float act_lo, float act_hi);
 
+/* ---------------------------------------------------------------- SSD head ------------------ */
+/* DetectionOutput.py:163-259 kernel_DetectionOutput_naive with its helpers iou (:12-34), nms (:38-63),
+ * screen_out_prior_boxes (:69-97), decode_bboxes (:100-150), clip_bounding_boxes (:153-158); share_location and
+ * normalized boxes, as the reference asserts.  loc [n][P*4], conf [n][P*C], priors [1][2][P*4] (boxes, variances),
+ * out [n*records][7] = [rank, class, score, xmin, ymin, xmax, ymax] in descending score order per image, a
+ * [-1,0,..] terminator after the last record, zeros after it.  The reference handles n == 1 only; images are
+ * independent here.  code_type_center_size: 1 = caffe.PriorBoxParameter.CENTER_SIZE, 0 = CORNER. */
+int pvhip_detection_output_f32(const float* loc, const float* conf, const float* priors, float* out, int n,
+                               int num_priors, int num_classes, int records_per_image, float confidence_threshold,
+                               float nms_threshold, int code_type_center_size, int variance_encoded_in_target,
+                               int clip_before_nms, int clip_after_nms);
+
 /* ---------------------------------------------------------------- multi-GPU gather ---------- */
 /* No reference counterpart (the reference is single-process).  Batch shards are independent; the only
  * exchange is an all-gather of the Result tensor over RCCL/xGMI.  unique_id is a 128-byte buffer. */

@@ -203,3 +203,122 @@ def reshape_dims(in_shape, target):
     if deferred != -1:
         dims[deferred] = remaining
     return dims
+
+
+# ---------------------------------------------------------------------------------------------------
+# SSD head
+def prior_box_clustered(grid_hw, image_hw, width, height, step, step_h, step_w, offset, variance, img_h, img_w):
+    """reference op_plugins/PriorBoxClustered.py:10-40: one box per (grid cell, (width, height) pair), corners in
+    image-relative units; row 0 = boxes, row 1 = the variance vector tiled.  Python-float (float64) arithmetic,
+    rounded to float32 once at the end, in the reference's operation order.  `clip` is read and ignored there."""
+    grid_h, grid_w = int(grid_hw[0]), int(grid_hw[1])
+    image_h, image_w = int(image_hw[0]), int(image_hw[1])
+    img_h = image_h if img_h == 0 else img_h
+    img_w = image_w if img_w == 0 else img_w
+    step_w = step if step_w == 0 else step_w
+    step_h = step if step_h == 0 else step_h
+    step_w = (img_w / grid_w) if step_w == 0 else step_w
+    step_h = (img_h / grid_h) if step_h == 0 else step_h
+    bw = np.asarray(width, dtype=np.float64)
+    bh = np.asarray(height, dtype=np.float64)
+    cx = ((np.arange(grid_w, dtype=np.float64) + offset) * step_w)[None, :, None]
+    cy = ((np.arange(grid_h, dtype=np.float64) + offset) * step_h)[:, None, None]
+    boxes = np.empty((grid_h, grid_w, len(bw), 4), dtype=np.float64)
+    boxes[..., 0] = (cx - (bw / 2)) / img_w
+    boxes[..., 1] = (cy - (bh / 2)) / img_h
+    boxes[..., 2] = (cx + (bw / 2)) / img_w
+    boxes[..., 3] = (cy + (bh / 2)) / img_h
+    count = grid_h * grid_w * len(bw)
+    return np.array([boxes.reshape(-1), np.tile(np.asarray(variance, dtype=np.float64), count)], dtype=np.float32)
+
+
+def strided_slice(x, begin, end, stride):
+    """reference op_plugins/StridedSlice.py:9-26: x[b0:e0:s0, b1:e1:s1, ...] over the leading len(begin) axes; the
+    five mask attributes are read and ignored."""
+    index = tuple(slice(int(b), int(e), int(s)) for b, e, s in zip(begin[:x.ndim], end[:x.ndim], stride[:x.ndim]))
+    return x[index]
+
+
+def _iou_row(a, others):
+    """DetectionOutput.py:12-34, box `a` against every row of `others`: float32 corner boxes, float32 arithmetic in
+    the reference's operation order (numpy scalars there, whole rows here)."""
+    area_a = (a[2] - a[0]) * (a[3] - a[1])
+    area_b = (others[:, 2] - others[:, 0]) * (others[:, 3] - others[:, 1])
+    w = np.minimum(a[2], others[:, 2]) - np.maximum(a[0], others[:, 0])
+    h = np.minimum(a[3], others[:, 3]) - np.maximum(a[1], others[:, 1])
+    inter = w * h
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = inter / (area_a + area_b - inter)
+    return np.where((w < 0) | (h < 0), np.float32(0.0), iou).astype(np.float32)
+
+
+def detection_output(loc, conf, priors, num_classes, keep_top_k, top_k, code_type, variance_encoded, nms_threshold,
+                     confidence_threshold, clip_before_nms, clip_after_nms):
+    """reference op_plugins/DetectionOutput.py:163-259 for one image (the reference asserts N == 1, share_location and
+    normalized): per prior the best class and its score; priors with score > threshold and class != 0 survive (in
+    prior order); boxes decoded from the priors (float32, exp evaluated in double and rounded, :100-150); the
+    reference's all-pairs suppression (:38-49: for every pair with IoU > threshold the lower-scored box -- the later
+    one on a tie -- is dropped, whether or not either was dropped before); clip; records
+    [n, class, score, xmin, ymin, xmax, ymax] in descending score order, a [-1, 0...] terminator when fewer than the
+    record count, zeros after it.  Equal scores are ordered by numpy's unstable sort in the reference; here the later
+    index comes first (a stable sort reversed)."""
+    f = np.float32
+    P = priors.shape[2] // 4
+    box_logits = loc.reshape(P, 4)
+    cls_pred = conf.reshape(P, num_classes)
+    pp = priors[0, 0].reshape(P, 4)
+    pv = priors[0, 1].reshape(P, 4)
+    cls = np.empty(P, dtype=np.int64)
+    for p in range(P):
+        cls[p] = np.argsort(cls_pred[p], kind='stable')[::-1][0]
+    score = cls_pred[np.arange(P), cls]
+    sel = np.nonzero((score > confidence_threshold) & (cls != 0))[0]
+    boxes = np.zeros((len(sel), 4), dtype=np.float32)
+    for i, p in enumerate(sel):
+        x0, y0, x1, y1 = pp[p]
+        l0, l1, l2, l3 = box_logits[p]
+        if code_type == 'caffe.PriorBoxParameter.CORNER':
+            if variance_encoded:
+                box = (x0 + l0, y0 + l1, x1 + l2, y1 + l3)
+            else:
+                box = (x0 + pv[p, 0] * l0, y0 + pv[p, 1] * l1, x1 + pv[p, 2] * l2, y1 + pv[p, 3] * l3)
+        else:
+            pw, ph = f(x1 - x0), f(y1 - y0)
+            pcx, pcy = f(f(x0 + x1) / f(2)), f(f(y0 + y1) / f(2))
+            if variance_encoded:
+                cx, cy = f(f(l0 * pw) + pcx), f(f(l1 * ph) + pcy)
+                w, h = f(f(np.exp(np.float64(l2))) * pw), f(f(np.exp(np.float64(l3))) * ph)
+            else:
+                cx = f(f(f(pv[p, 0] * l0) * pw) + pcx)
+                cy = f(f(f(pv[p, 1] * l1) * ph) + pcy)
+                w = f(f(np.exp(np.float64(f(pv[p, 2] * l2)))) * pw)
+                h = f(f(np.exp(np.float64(f(pv[p, 3] * l3)))) * ph)
+            box = (f(cx - f(w / f(2))), f(cy - f(h / f(2))), f(cx + f(w / f(2))), f(cy + f(h / f(2))))
+        boxes[i] = box
+    if clip_before_nms:
+        boxes = np.clip(boxes, 0, 1)
+    sc, cl = score[sel], cls[sel]
+    keep = np.ones(len(sel), dtype=bool)
+    for i in range(len(sel) - 1):
+        over = _iou_row(boxes[i], boxes[i + 1:]) > nms_threshold      # pairs (i, j > i)
+        better = sc[i] < sc[i + 1:]
+        if np.any(over & better):
+            keep[i] = False
+        keep[i + 1:][over & ~better] = False
+    boxes, sc, cl = boxes[keep], sc[keep], cl[keep]
+    if clip_after_nms:
+        boxes = np.clip(boxes, 0, 1)
+    if keep_top_k > 0:
+        records = keep_top_k
+    elif keep_top_k == -1 and top_k > 0:
+        records = top_k * num_classes
+    else:
+        records = num_classes * P
+    res = np.zeros((records, 7), dtype=np.float32)
+    order = np.argsort(sc, kind='stable')[::-1]
+    for n in range(min(records, len(order))):
+        i = order[n]
+        res[n] = (n, cl[i], sc[i], boxes[i, 0], boxes[i, 1], boxes[i, 2], boxes[i, 3])
+    if len(order) < records:
+        res[len(order)] = (-1, 0, 0, 0, 0, 0, 0)
+    return res

@@ -65,6 +65,8 @@ SIGNATURES = {
     'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
     'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_dwconv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 12 + [_fp, _c.c_int, _c.c_float, _c.c_float]),
+    'pvhip_detection_output_f32': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                              _c.c_float, _c.c_float, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_comm_unique_id': (_c.c_int, [_c.c_void_p]),
     'pvhip_comm_init': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     'pvhip_comm_allgather_f32': (_c.c_int, [_fp, _fp, _c.c_size_t]),

@@ -188,7 +188,9 @@ class IENetwork:
         """Run ``batch`` independent images through the graph: multiply the leading dimension of every
         port that carries activations (anything downstream of a Parameter) by ``batch / current``.
         Constant ports keep their shape; Reshape targets in the shipped IRs use -1 / 0 for the batch
-        axis, so they need no edit."""
+        axis, so they need no edit.  A ShapeOf output is a shape vector, not an activation: nothing that hangs off
+        one (the SSD prior-box subgraph) is scaled.  DetectionOutput's records are (1, 1, N * keep, 7)
+        (DetectionOutput.py:229-235): its third axis scales."""
         batch = int(batch)
         if batch < 1:
             raise ValueError('batch must be >= 1')
@@ -198,26 +200,33 @@ class IENetwork:
             raise ValueError('set_batch works from the IR batch (call it once, or with a multiple)')
         old = self.batch_size
         G = self.G
+        carries = G.copy()
+        carries.remove_edges_from([(u, v) for u, v in G.edges if G.nodes[u]['type'] == 'ShapeOf'])
         act_nodes = set()
         for pid, _ in self.find_node_by_type('Parameter'):
             act_nodes.add(pid)
-            act_nodes.update(nx.descendants(G, pid))
+            act_nodes.update(nx.descendants(carries, pid))
+        records = set()       # nodes whose tensors are detection records (1, 1, N * keep, 7): DetectionOutput and on
+        for did, _ in self.find_node_by_type('DetectionOutput'):
+            records.add(did)
+            records.update(nx.descendants(G, did))
 
-        def scaled(dims):
-            if len(dims) == 0:
+        def scaled(dims, axis=0):
+            if len(dims) <= axis:
                 return dims
-            return (dims[0] // old * batch,) + tuple(dims[1:])
+            return tuple(dims[:axis]) + (dims[axis] // old * batch,) + tuple(dims[axis + 1:])
 
         for nid in act_nodes:
             node = G.nodes[nid]
-            for port in node.get('output', {}).values():
-                port['dims'] = scaled(port['dims'])
+            if node['type'] != 'ShapeOf':
+                for port in node.get('output', {}).values():
+                    port['dims'] = scaled(port['dims'], 2 if nid in records else 0)
             if node['type'] == 'Parameter':
                 node['data']['shape'] = scaled(tuple(node['data']['shape']))
             for pred in G.pred[nid]:
-                if pred in act_nodes:
+                if pred in act_nodes and G.nodes[pred]['type'] != 'ShapeOf':
                     sink_port = G.edges[(pred, nid)]['connection'][3]
-                    node['input'][sink_port]['dims'] = scaled(node['input'][sink_port]['dims'])
+                    node['input'][sink_port]['dims'] = scaled(node['input'][sink_port]['dims'], 2 if pred in records else 0)
         self.batch_size = batch
 
 

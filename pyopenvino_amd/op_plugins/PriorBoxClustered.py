@@ -1,0 +1,57 @@
+# PriorBoxClustered -- HIP plugin.  Replaces kernel_PriorBoxClustered_naive (reference
+# op_plugins/PriorBoxClustered.py:10-40).  The boxes depend only on the two shape vectors and the node attributes,
+# never on tensor data: they are computed once on the host with the reference's float64 operation order, rounded
+# to float32, uploaded, and the same device tensor is handed out on every infer (a constant fold; the reference
+# rebuilds the list in Python loops each time).  `clip` is read and ignored there.
+import numpy as np
+
+from .. import common_def
+from .. import device as dev
+
+
+def name():
+    print('PriorBoxClustered')
+
+
+def boxes(grid_hw, image_hw, width, height, step, step_h, step_w, offset, variance, img_h, img_w):
+    grid_h, grid_w = int(grid_hw[0]), int(grid_hw[1])
+    image_h, image_w = int(image_hw[0]), int(image_hw[1])
+    img_h = image_h if img_h == 0 else img_h
+    img_w = image_w if img_w == 0 else img_w
+    step_w = step if step_w == 0 else step_w
+    step_h = step if step_h == 0 else step_h
+    step_w = (img_w / grid_w) if step_w == 0 else step_w
+    step_h = (img_h / grid_h) if step_h == 0 else step_h
+    half_w = np.asarray(width, dtype=np.float64) / 2
+    half_h = np.asarray(height, dtype=np.float64) / 2
+    center_x = ((np.arange(grid_w, dtype=np.float64) + offset) * step_w).reshape(1, grid_w, 1)
+    center_y = ((np.arange(grid_h, dtype=np.float64) + offset) * step_h).reshape(grid_h, 1, 1)
+    out = np.empty((grid_h, grid_w, len(half_w), 4), dtype=np.float64)
+    out[..., 0] = (center_x - half_w) / img_w
+    out[..., 1] = (center_y - half_h) / img_h
+    out[..., 2] = (center_x + half_w) / img_w
+    out[..., 3] = (center_y + half_h) / img_h
+    per_box = np.tile(np.asarray(variance, dtype=np.float64), grid_h * grid_w * len(half_w))
+    return np.array([out.reshape(-1), per_box], dtype=np.float32)
+
+
+def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bool = False):
+    if debug:
+        print(node)
+    common_def.validate_inputs(node, inputs)
+    grid_hw = tuple(int(v) for v in np.asarray(inputs[0]).ravel())
+    image_hw = tuple(int(v) for v in np.asarray(inputs[1]).ravel())
+    cached = node.get('_hip_priors')
+    if cached is not None and cached[0] == (grid_hw, image_hw):
+        return {common_def.first_output_port(node): cached[1]}
+    d = node['data']
+    host = boxes(grid_hw, image_hw,
+                 width=common_def.string_to_tuple_float(d['width']) if 'width' in d else [1.0],
+                 height=common_def.string_to_tuple_float(d['height']) if 'height' in d else [1.0],
+                 step=int(d['step']) if 'step' in d else 0.0, step_h=int(d['step_h']) if 'step_h' in d else 0.0,
+                 step_w=int(d['step_w']) if 'step_w' in d else 0.0, offset=float(d['offset']),
+                 variance=common_def.string_to_tuple_float(d['variance']) if 'variance' in d else [],
+                 img_h=float(d['img_h']) if 'img_h' in d else 0.0, img_w=float(d['img_w']) if 'img_w' in d else 0.0)
+    value = dev.DeviceTensor.from_numpy(host)
+    node['_hip_priors'] = ((grid_hw, image_hw), value)
+    return {common_def.first_output_port(node): value}

@@ -16,7 +16,8 @@ reference's un-shifted SoftMax stays finite):
                                 (-104, -117, -123);
   Multiply constants            1 + N(0, 0.1^2) (folded BatchNorm scale); a scalar one on the Parameter is 1/127.5;
   I64 constants                 real values: LRN axes [1]; Reshape target [0, -1, out dims 2..]; Transpose
-                                permutation NCHW -> NHWC; others zero.
+                                permutation NCHW -> NHWC; StridedSlice begin / end / stride and Unsqueeze axes
+                                reconstructed from the port dims (SSD prior-box subgraph); others zero.
 """
 import xml.etree.ElementTree as et
 
@@ -127,6 +128,19 @@ def synth_weights(xml_path: str, seed: int = 1234) -> bytes:
                 if len(tgt) > 1:
                     tgt[1] = -1
                 vals[:] = np.array(tgt[:count], dtype=width)
+            elif dtype_name == 'StridedSlice':
+                # the SSD head slices [H, W] out of a ShapeOf vector: begin = len(in) - len(out), end = len(in), stride 1
+                n_in = layers[dst]['ports'][('input', 0)][0]
+                n_out = next(v for (tag, _), v in layers[dst]['ports'].items() if tag == 'output')[0]
+                vals[:] = {1: n_in - n_out, 2: n_in, 3: 1}[dport]
+            elif dtype_name == 'Unsqueeze':
+                in_dims = layers[dst]['ports'][('input', 0)]
+                out_dims = next(v for (tag, _), v in layers[dst]['ports'].items() if tag == 'output')
+                import itertools
+                axes = next(c for c in itertools.combinations(range(len(out_dims)), len(out_dims) - len(in_dims))
+                            if all(out_dims[i] == 1 for i in c) and
+                            tuple(d for i, d in enumerate(out_dims) if i not in c) == tuple(in_dims))
+                vals[:] = np.array(axes[:count], dtype=width)
             elif dtype_name == 'Transpose':
                 in_dims = layers[dst]['ports'][('input', 0)]
                 perm = [0, 2, 3, 1] if len(in_dims) == 4 else list(range(len(in_dims)))[::-1]

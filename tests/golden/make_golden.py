@@ -20,6 +20,8 @@ Fixtures
   mnist_bn_e2e.npz         models/mnist_bn on synthetic weights, 2 images
   ssd_backbone_e2e.npz     models/ssd_mobilenet_v1_coco backbone + heads (up to 'concat', 'concat_1', the Sigmoid) on
                            synthetic weights, 1 image: 'concat' in full, the two class tensors subsampled + float64 sums
+  ssd_full_e2e.npz         the whole SSD IR (prior boxes + DetectionOutput included) through the reference's infer(),
+                           synthetic weights, 1 image: the (1,1,100,7) detections and the (1,2,7668) prior tensor
   conv_node6_crop.npz      the reference's own single-node fixture resources/node_args_6.pickle (SSD Conv2d_0,
                            3x3 stride 2 same_upper pads (0,0)/(1,1)), input cropped to 64x64 and cast to fp32
 """
@@ -66,12 +68,12 @@ def make_node(type_, ins, out_dims, data=None, out_prec='FP32', name=None):
     return node
 
 
-def save_case(plugins, name, type_, ins, data=None, per_image=False):
+def save_case(plugins, name, type_, ins, data=None, per_image=False, out_prec='FP32'):
     """Run the reference plugin; per_image=True runs one N=1 call per leading-axis slice and stacks."""
     plugin = plugins[type_]
 
     def run(arrs):
-        node = make_node(type_, arrs, (1,), data)
+        node = make_node(type_, arrs, (1,), data, out_prec=out_prec)
         res = plugin.compute(node, {i: a for i, a in enumerate(arrs)}, kernel_type='special', debug=False)
         return np.ascontiguousarray(next(iter(res.values())))
 
@@ -80,7 +82,7 @@ def save_case(plugins, name, type_, ins, data=None, per_image=False):
         out = np.concatenate(outs, axis=0)
     else:
         out = run(list(ins))
-    node = make_node(type_, ins, out.shape, data, name=name)
+    node = make_node(type_, ins, out.shape, data, out_prec=out_prec, name=name)
     blob = {'in{}'.format(i): a for i, a in enumerate(ins)}
     blob['out'] = out
     blob['node'] = np.array(json.dumps(node))
@@ -172,6 +174,75 @@ def op_cases(plugins):
     save_case(plugins, 'transpose_nchw_nhwc', 'Transpose', [rnd(120, (2, 5, 3, 4)), np.array([0, 2, 3, 1], dtype=np.int64)])
     save_case(plugins, 'reshape_flatten', 'Reshape', [rnd(121, (2, 3, 3, 4)), np.array([-1, 36], dtype=np.int64)], {'special_zero': 'false'})
     save_case(plugins, 'reshape_zero_copy', 'Reshape', [rnd(122, (2, 6, 1, 1)), np.array([0, -1], dtype=np.int64)], {'special_zero': 'true'})
+
+
+def i64(*values):
+    return np.array(values, dtype=np.int64)
+
+
+DETECTION = {'background_label_id': '0', 'clip_after_nms': 'true', 'clip_before_nms': 'false',
+             'code_type': 'caffe.PriorBoxParameter.CENTER_SIZE', 'confidence_threshold': '0.30000001192092896',
+             'decrease_label_id': 'false', 'input_height': '1', 'input_width': '1', 'keep_top_k': '100',
+             'nms_threshold': '0.60000002384185791', 'normalized': 'true', 'num_classes': '21', 'objectness_score': '0',
+             'share_location': 'true', 'top_k': '100', 'variance_encoded_in_target': 'false'}
+
+
+def head_cases(plugins):
+    """SSD head glue: ShapeOf / StridedSlice / Unsqueeze / PriorBoxClustered / DetectionOutput."""
+    save_case(plugins, 'shapeof_nchw', 'ShapeOf', [rnd(130, (1, 12, 19, 19))], {'output_type': 'i64'}, out_prec='I64')
+    ss = {'begin_mask': '0', 'ellipsis_mask': '0', 'end_mask': '1', 'new_axis_mask': '0', 'shrink_axis_mask': '0'}
+    save_case(plugins, 'stridedslice_hw_of_shape', 'StridedSlice', [i64(1, 12, 19, 19), i64(2), i64(4), i64(1)], ss, out_prec='I64')
+    save_case(plugins, 'stridedslice_step2', 'StridedSlice', [i64(3, 1, 4, 1, 5, 9, 2, 6), i64(1), i64(8), i64(2)], ss, out_prec='I64')
+    save_case(plugins, 'unsqueeze_front', 'Unsqueeze', [rnd(131, (2, 24)), i64(0)])
+    save_case(plugins, 'unsqueeze_two_axes', 'Unsqueeze', [rnd(132, (3, 3)), i64(0, 3)])
+    pb = {'clip': 'false', 'height': '30, 42.4264, 84.8528', 'offset': '0.5', 'step': '0', 'step_h': '0', 'step_w': '0',
+          'variance': '0.1, 0.1, 0.2, 0.2', 'width': '30, 84.8528, 42.4264'}
+    save_case(plugins, 'priorbox_19x19_3', 'PriorBoxClustered', [i64(19, 19), i64(300, 300)], pb)
+    pb2 = dict(pb, height='105, 74.2462, 148.492, 60.6218, 181.874, 125.499', width='105, 148.492, 74.2462, 181.865, 60.6187, 125.499',
+               step='16', offset='0.25')
+    save_case(plugins, 'priorbox_3x5_6_step16', 'PriorBoxClustered', [i64(3, 5), i64(120, 200)], pb2)
+    # DetectionOutput: priors from the reference's own PriorBoxClustered (10x10 grid, 3 boxes per cell = 300 priors),
+    # box deltas ~ N(0, 0.5^2), class scores = a seeded permutation of an even grid on (0, 1) (no ties), 21 classes
+    node = make_node('PriorBoxClustered', [i64(10, 10), i64(300, 300)], (1,), pb)
+    priors = np.ascontiguousarray(next(iter(plugins['PriorBoxClustered'].compute(node, {0: i64(10, 10), 1: i64(300, 300)}, kernel_type='special').values())))[None]
+    P = priors.shape[2] // 4
+    loc = rnd(140, (1, P * 4), 0.5)
+    order = np.argsort(synth.uniform01(141, 7, P * 21), kind='stable')          # a seeded permutation: all scores distinct
+    conf = ((order + 0.5) / float(P * 21)).astype(np.float32).reshape(1, P * 21)
+    assert len(np.unique(conf)) == conf.size
+    save_case(plugins, 'detout_center_size_300x21', 'DetectionOutput', [loc, conf, priors], DETECTION)
+    save_case(plugins, 'detout_few_boxes_terminator', 'DetectionOutput', [loc, conf, priors],
+              dict(DETECTION, confidence_threshold='0.995', keep_top_k='20'))
+    save_case(plugins, 'detout_corner_encoded_clip_before', 'DetectionOutput', [rnd(142, (1, P * 4), 0.05), conf, priors],
+              dict(DETECTION, code_type='caffe.PriorBoxParameter.CORNER', variance_encoded_in_target='true', clip_before_nms='true',
+                   clip_after_nms='false', keep_top_k='30', nms_threshold='0.45', confidence_threshold='0.9'))
+    save_case(plugins, 'detout_corner_variance', 'DetectionOutput', [rnd(143, (1, P * 4), 0.3), conf, priors],
+              dict(DETECTION, code_type='caffe.PriorBoxParameter.CORNER', keep_top_k='-1', top_k='3', confidence_threshold='0.98'))
+
+
+def ssd_full_case(IECore):
+    """The WHOLE SSD-MobileNet IR (backbone, prior boxes, DetectionOutput) through the reference's own infer() on
+    synthetic weights, one image."""
+    print('ssd_mobilenet_v1_coco end to end on synthetic weights (seed 1234), 1 image -- slow (python loops, O(n^2) NMS)')
+    tmp = '/tmp/pv_golden_models'
+    os.makedirs(tmp, exist_ok=True)
+    xml = os.path.join(REF, 'models', 'ssd_mobilenet_v1_coco.xml')
+    stem = os.path.join(tmp, 'ssd_mobilenet_v1_coco')
+    with open(stem + '.bin', 'wb') as f:
+        f.write(synth.synth_weights(xml, 1234))
+    if not os.path.exists(stem + '.xml'):
+        os.symlink(xml, stem + '.xml')
+    x = synth.uniform_pixels(700, (1, 3, 300, 300))
+    ie = IECore()
+    net = ie.read_network(stem + '.xml', stem + '.bin')
+    ex = ie.load_network(net, 'CPU')
+    ex.kernel_type = 'special'
+    res = ex.infer({net.inputs[0]['name']: x})
+    out = np.ascontiguousarray(res[net.outputs[0]['name']])
+    by_name = {net.G.nodes[n]['name']: n for n in net.G.nodes}
+    priors = np.ascontiguousarray(next(iter(net.G.nodes[by_name['ConcatPriorBoxesClustered']]['output'].values()))['data'])
+    np.savez_compressed(os.path.join(HERE, 'ssd_full_e2e.npz'), image_seed=np.array(700), weight_seed=np.array(1234), out=out, priors=priors)
+    print('  detections', out.shape, 'records', int((out[0, 0, :, 0] >= 0).sum()), 'first', out[0, 0, 0])
 
 
 def run_model(IECore, model, x, input_name=None, capture_layers=False):
@@ -294,13 +365,20 @@ def node6_case(plugins):
 def main():
     IECore = import_reference()
     plugins = IECore().plugins.plugins
-    if 'ssd' in sys.argv[1:]:            # only (re)generate the slow SSD backbone fixture
+    if 'ssd' in sys.argv[1:]:            # only (re)generate the slow SSD fixtures
         ssd_backbone_case(IECore)
+        ssd_full_case(IECore)
+        return
+    if 'head' in sys.argv[1:]:           # only the SSD head per-op fixtures and the end-to-end SSD fixture
+        head_cases(plugins)
+        ssd_full_case(IECore)
         return
     op_cases(plugins)
+    head_cases(plugins)
     node6_case(plugins)
     model_cases(IECore)
     ssd_backbone_case(IECore)
+    ssd_full_case(IECore)
     print('done')
 
 

@@ -10,7 +10,8 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 MODELS = os.path.join(REPO, 'models')
 
 # Ops whose HIP result must equal the reference bit for bit (pure selection / copy / one IEEE op)
-BIT_EXACT = {'ReLU', 'MaxPool', 'Add', 'Multiply', 'Concat', 'Transpose', 'Reshape', 'Clamp'}
+BIT_EXACT = {'ReLU', 'MaxPool', 'Add', 'Multiply', 'Concat', 'Transpose', 'Reshape', 'Clamp', 'ShapeOf', 'StridedSlice', 'Unsqueeze',
+             'PriorBoxClustered'}
 # Stated tolerance of the path (BASELINE.json north_star): 1e-4 relative, fp32
 REL_TOL = 1e-4
 

@@ -208,3 +208,35 @@ def test_ssd_backbone_vs_reference_and_oracle(hip):
     want = ssd_backbone(ORACLE, 2, x)
     for k in got:
         assert_close(got[k], want[k], helpers.REL_TOL, 'ssd ' + k)
+
+
+def test_ssd_whole_ir_vs_reference_and_batch(hip):
+    """the whole SSD IR on the device (prior boxes constant-folded and uploaded once, DetectionOutput
+    kernel) against the reference's own infer() at N=1, and at batch 6 against the oracle (images independent)."""
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, 'ssd_full_e2e.npz'))
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'ssd_mobilenet_v1_coco.xml'), int(z['weight_seed']))
+    x = synth.uniform_pixels(int(z['image_seed']), (1, 3, 300, 300))
+    _, net, ex = build_network(HIP, 'ssd_mobilenet_v1_coco', weights=blob)
+    out = infer_one(ex, net, x)
+    assert out.shape == z['out'].shape
+    assert np.array_equal(out[..., :2], z['out'][..., :2]), 'record order / classes differ from the reference'
+    assert_close(out, z['out'], helpers.REL_TOL, 'ssd detections vs reference')
+    by_name = {net.G.nodes[n]['name']: n for n in net.G.nodes}
+    priors = next(iter(net.G.nodes[by_name['ConcatPriorBoxesClustered']]['output'].values()))['data']
+    helpers.assert_bit_exact(np.asarray(priors), z['priors'], 'prior boxes')
+    B = 6
+    xb = np.concatenate([synth.uniform_pixels(800 + i, (1, 3, 300, 300)) for i in range(B - 1)] + [x], 0)
+    _, net_b, ex_b = build_network(HIP, 'ssd_mobilenet_v1_coco', weights=blob, batch=B)
+    got = infer_one(ex_b, net_b, xb)
+    assert got.shape == (1, 1, B * 100, 7)
+    assert np.array_equal(got[0, 0, (B - 1) * 100:, :2], z['out'][0, 0, :, :2])
+    assert_close(got[:, :, (B - 1) * 100:], z['out'], helpers.REL_TOL, 'last image of the batch vs reference')
+    _, net_o, ex_o = build_network(ORACLE, 'ssd_mobilenet_v1_coco', weights=blob, batch=2)
+    ex_o.kernel_type = 'special'
+    want2 = infer_one(ex_o, net_o, xb[:2])
+    # scores within 1e-4 of each other may legitimately swap ranks between fp32 implementations: compare as sets of rows
+    for b in range(2):
+        g, w = got[0, 0, b * 100:(b + 1) * 100], want2[0, 0, b * 100:(b + 1) * 100]
+        assert np.array_equal(np.sort(g[:, 1]), np.sort(w[:, 1])), 'image {}: detected classes differ'.format(b)
+        assert_close(g[np.argsort(-g[:, 2], kind='stable'), 2:], w[np.argsort(-w[:, 2], kind='stable'), 2:], helpers.REL_TOL, 'image {} of the batch'.format(b))

@@ -22,6 +22,12 @@ def oracle_plugin(type_):
 
 def check(node, inputs, want, what):
     got = first_out(hip_plugin(node['type']).compute(node, inputs, kernel_type='hip', debug=False))
+    want = np.asarray(want)
+    if want.dtype.kind == 'i':
+        assert got.dtype == want.dtype and np.array_equal(got, want), what
+        return 0.0
+    if node['type'] == 'DetectionOutput':       # record index and class bit for bit, score / box within the tolerance
+        assert got.shape == want.shape and np.array_equal(got[..., :2], want[..., :2]), what + ': record order / classes differ'
     if node['type'] in helpers.BIT_EXACT:
         assert_bit_exact(got, np.asarray(want, dtype=np.float32), what)
         return 0.0
@@ -178,6 +184,35 @@ def test_conv_fused_bias_and_activation_bit_exact(hip, monkeypatch, kernel):
             fused_node['_fuse_act'] = act
             got = first_out(hip_plugin(type_).compute(fused_node, {0: x, 1: w}))
             assert_bit_exact(got, want, '{} fused bias + {}'.format(type_, act[0]))
+
+
+def test_detection_output_batch_and_ties(hip):
+    """Batch rule (the reference asserts N == 1): every image of a batch gives the records of its own N=1 run,
+    stacked; equal class scores pick the later class, equal box scores put the later box first (what the oracle's
+    stable sorts give); no candidate at all leaves a terminator in row 0."""
+    z = np.load(os.path.join(helpers.GOLDEN, 'ops', 'detout_center_size_300x21.npz'))
+    node, inputs, want = load_case(os.path.join(helpers.GOLDEN, 'ops', 'detout_center_size_300x21.npz'))
+    loc2 = np.concatenate([inputs[0], rnd(5, inputs[0].shape, 0.5)], 0)
+    conf2 = np.concatenate([inputs[1], inputs[1][:, ::-1].copy()], 0)
+    node2 = dict(node)
+    node2['input'] = {0: {'precision': 'FP32', 'dims': loc2.shape}, 1: {'precision': 'FP32', 'dims': conf2.shape}, 2: node['input'][2]}
+    ins2 = {0: loc2, 1: conf2, 2: inputs[2]}
+    got = first_out(hip_plugin('DetectionOutput').compute(node2, ins2))
+    ref = first_out(oracle_plugin('DetectionOutput').compute(node2, ins2))
+    assert got.shape == (1, 1, 200, 7) and np.array_equal(got[..., :2], ref[..., :2])
+    assert_close(got, ref, 1e-6, 'batch of 2')
+    assert_close(got[:, :, :100], want, 1e-6, 'image 0 of the batch vs the reference N=1 record list')
+    # ties: quantised scores (many equal maxima per prior and equal box scores)
+    conf_q = (np.round(inputs[1] * 8) / 8).astype(np.float32)
+    ins_q = {0: inputs[0], 1: conf_q, 2: inputs[2]}
+    got_q = first_out(hip_plugin('DetectionOutput').compute(node, ins_q))
+    ref_q = first_out(oracle_plugin('DetectionOutput').compute(node, ins_q))
+    assert np.array_equal(got_q[..., :2], ref_q[..., :2])
+    assert_close(got_q, ref_q, 1e-6, 'tied scores')
+    # nothing above the threshold
+    ins_0 = {0: inputs[0], 1: np.full_like(inputs[1], 0.1), 2: inputs[2]}
+    got_0 = first_out(hip_plugin('DetectionOutput').compute(node, ins_0))
+    assert got_0[0, 0, 0, 0] == -1 and not got_0[0, 0, 1:].any() and not got_0[0, 0, 0, 1:].any()
 
 
 def test_conv_identity_weights_asymmetric_input(hip):

@@ -18,7 +18,9 @@ def test_oracle_op_matches_reference(path):
     plugin = importlib.import_module('oracle.op_plugins.' + node['type'])
     got = helpers.first_out(plugin.compute(node, inputs, kernel_type='special', debug=False))
     assert got.shape == want.shape
-    if node['type'] in helpers.BIT_EXACT:
+    if want.dtype.kind == 'i':
+        assert got.dtype == want.dtype and np.array_equal(got, want), node['name']
+    elif node['type'] in helpers.BIT_EXACT:
         helpers.assert_bit_exact(got.astype(np.float32), want, node['name'])
     else:
         assert_close(got, want, ORACLE_TOL, node['name'])
@@ -91,3 +93,25 @@ def test_oracle_ssd_backbone_vs_reference():
     z = np.load(os.path.join(GOLDEN, 'ssd_backbone_e2e.npz'))
     x = synth.uniform_pixels(int(z['image_seed']), (1, 3, 300, 300))
     check_ssd_against_fixture(ssd_backbone('oracle.op_plugins', 1, x), z, 2e-5)
+
+
+def test_oracle_ssd_whole_ir_vs_reference():
+    """the WHOLE SSD IR (prior-box subgraph and DetectionOutput included) through infer(), against the
+    reference's own infer() on the same synthetic weights and image; and the batch rule at N=2."""
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, 'ssd_full_e2e.npz'))
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'ssd_mobilenet_v1_coco.xml'), int(z['weight_seed']))
+    x = synth.uniform_pixels(int(z['image_seed']), (1, 3, 300, 300))
+    _, net, ex = build_network('oracle.op_plugins', 'ssd_mobilenet_v1_coco', weights=blob)
+    ex.kernel_type = 'special'
+    out = helpers.infer_one(ex, net, x)
+    assert out.shape == z['out'].shape and np.array_equal(out[..., :2], z['out'][..., :2])
+    assert_close(out, z['out'], 1e-6, 'ssd detections')
+    by_name = {net.G.nodes[n]['name']: n for n in net.G.nodes}
+    priors = next(iter(net.G.nodes[by_name['ConcatPriorBoxesClustered']]['output'].values()))['data']
+    helpers.assert_bit_exact(np.asarray(priors), z['priors'], 'prior boxes')
+    _, net2, ex2 = build_network('oracle.op_plugins', 'ssd_mobilenet_v1_coco', weights=blob, batch=2)
+    ex2.kernel_type = 'special'
+    out2 = helpers.infer_one(ex2, net2, np.concatenate([synth.uniform_pixels(9, (1, 3, 300, 300)), x], 0))
+    assert out2.shape == (1, 1, 200, 7)
+    assert_close(out2[:, :, 100:], z['out'], 1e-6, 'image 1 of a batch of 2')
