@@ -36,6 +36,34 @@ inline int grid_for(size_t work_items, int per_block = kBlock) {
     return (int)b;
 }
 
+// (bias + alpha * sum)^beta of the LRN kernels.  beta_mode: 1 -> d^0.75 as sqrt(d)*sqrt(sqrt(d)) (two correctly
+// rounded roots), 2 -> d^0.5, 3 -> d, 0 -> powf.
+__device__ __forceinline__ float lrn_pow_f(float d, float beta, int beta_mode) {
+    if (beta_mode == 1) {
+        const float s = sqrtf(d);
+        return s * sqrtf(s);
+    }
+    if (beta_mode == 2) return sqrtf(d);
+    if (beta_mode == 3) return d;
+    return powf(d, beta);
+}
+
+// x / (bias + alpha * sum)^beta.  Mode 4 is d^-0.75 = rsq(d) * rsq(sqrt(d)) on the hardware's 1-ulp square-root
+// instructions (3 transcendental issues instead of two IEEE square roots and an IEEE division, ~1/3 of the VALU work of
+// an LRN element; a few ulp from the exact quotient, far inside the 1e-4 of the path).  It is chosen on the host only
+// when bias keeps d in the normal range, where those instructions are accurate.
+__device__ __forceinline__ float lrn_div(float x, float d, float beta, int beta_mode) {
+    if (beta_mode == 4) return x * (__builtin_amdgcn_rsqf(d) * __builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf(d)));
+    return x / lrn_pow_f(d, beta, beta_mode);
+}
+
+inline int lrn_beta_mode(float beta, float bias) {
+    if (beta == 0.75f) return bias >= 1e-20f ? 4 : 1;
+    if (beta == 0.5f) return 2;
+    if (beta == 1.0f) return 3;
+    return 0;
+}
+
 }  // namespace pvhip
 
 #define PVHIP_REQUIRE_INIT()                                                          \

@@ -55,18 +55,6 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_kernel(const float* __res
     }
 }
 
-__device__ __forceinline__ float lrn_pow(float d, float beta, int beta_mode) {
-    // beta_mode: 1 -> d^0.75 as sqrt(d)*sqrt(sqrt(d)) (two correctly rounded roots), 2 -> d^0.5,
-    // 3 -> d, 0 -> powf
-    if (beta_mode == 1) {
-        const float s = sqrtf(d);
-        return s * sqrtf(s);
-    }
-    if (beta_mode == 2) return sqrtf(d);
-    if (beta_mode == 3) return d;
-    return powf(d, beta);
-}
-
 // One lane owns VEC adjacent pixels of one image and walks the channel axis in chunks of T = 8 channels
 // (C must be a multiple of 8; other channel counts take the generic kernel).  The T loads of chunk k+1 are
 // issued before the outputs that chunk k completes are computed, so T independent 16-byte loads per lane are
@@ -98,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void lrn_window_kernel(const float* __restr
         vec_t o_;                                                                              \
         _Pragma("unroll") for (int v = 0; v < VEC; ++v) {                                      \
             const float d_ = bias + alpha * s_[v];                                             \
-            o_[v]          = ext[(j_) + HALF][v] / lrn_pow(d_, beta, beta_mode);               \
+            o_[v]          = lrn_div(ext[(j_) + HALF][v], d_, beta, beta_mode);                \
         }                                                                                      \
         yv[(size_t)(ch_) * cstride] = o_;                                                      \
     }
@@ -174,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void lrn_generic_kernel(const float* __rest
             s             = (k == lo) ? v * v : s + v * v;
         }
         const float d = bias + alpha * s;
-        y[e]          = x[e] / lrn_pow(d, beta, beta_mode);
+        y[e]          = lrn_div(x[e], d, beta, beta_mode);
     }
 }
 
@@ -197,6 +185,7 @@ void launch_lrn_window(const float* x, float* y, int n, int c, int hw, float alp
         case 1: launch_lrn_window_b<SIZE, 1>(x, y, n, c, hw, alpha, beta, bias); break;
         case 2: launch_lrn_window_b<SIZE, 2>(x, y, n, c, hw, alpha, beta, bias); break;
         case 3: launch_lrn_window_b<SIZE, 3>(x, y, n, c, hw, alpha, beta, bias); break;
+        case 4: launch_lrn_window_b<SIZE, 4>(x, y, n, c, hw, alpha, beta, bias); break;
         default: launch_lrn_window_b<SIZE, 0>(x, y, n, c, hw, alpha, beta, bias); break;
     }
 }
@@ -223,10 +212,7 @@ int pvhip_lrn_f32(const float* x, float* y, int n, int c, int hw, int size, floa
     PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
     if ((unsigned long long)n * c * hw >= (1ull << 31))
         return fail(PVHIP_EUNSUPPORTED, "pvhip_lrn_f32: tensor exceeds 2^31 elements");
-    int bm = 0;
-    if (beta == 0.75f) bm = 1;
-    else if (beta == 0.5f) bm = 2;
-    else if (beta == 1.0f) bm = 3;
+    const int bm = lrn_beta_mode(beta, bias);
     switch ((c % 8 == 0 && c >= 8) ? size : 0) {
         case 3: launch_lrn_window<3>(x, y, n, c, hw, alpha, beta, bias, bm); break;
         case 5: launch_lrn_window<5>(x, y, n, c, hw, alpha, beta, bias, bm); break;
