@@ -364,10 +364,14 @@ class Executable_Network:
 
     def plan_streams(self):
         """Static stream assignment for the current task list (the reference's list scheduler
-        runs the branches of a module one after the other, :259-292).  A node runs on the stream of the
-        producer of its data input if it is that tensor's first consumer in schedule order; the tensor's
-        j-th consumer goes to the j-th next stream, so the arms of a fan-out run side by side.  Returns
-        (stream of task, tasks to wait for, tasks that must record an event) or None when not applicable."""
+        runs the branches of a module one after the other, :259-292).  The consumers of a tensor are ranked by
+        the estimated time of the arm each one starts (the chain of single-consumer nodes behind it); the
+        heaviest stays on the stream the tensor was produced on, the others go to the next streams, so the arms
+        of a fan-out run side by side.  A tensor assembled by several producers (an eliminated Concat) counts as
+        produced on the stream of the producer expected to finish last.  Both rules keep the critical path of
+        consecutive modules on ONE stream: its kernels follow each other without waiting for a cross-stream event
+        (measured 25-40 us per join), which only the lighter arms pay.  Returns (stream of task, tasks to wait
+        for, tasks that must record an event) or None when not applicable."""
         registry = self.ienet.ie.plugins.plugins
         n = min(int(self.compute_streams), 8)
         if n <= 1 or not all(getattr(sys.modules.get(m.__package__), 'DEVICE_STREAMS', False) for m in registry.values()):
@@ -392,18 +396,78 @@ class Executable_Network:
                 return []                # uploads are synchronous (or the tensor is already resident)
             return [nid]
 
-        stream_of, waits, records, placed = {}, {}, set(), {}
-        for task in self.task_list:
-            if task in self._fused_away or G.nodes[task]['type'] in ('Const', 'Parameter'):
-                continue
+        def prod(dims):
+            out = 1
+            for d in dims:
+                out *= int(d)
+            return out
+
+        def cost(task):                  # rough device time of a task in microseconds (ranking only)
+            node = G.nodes[task]
+            out = prod(next(iter(node['output'].values()))['dims']) if node.get('output') else 0
+            if node['type'] == 'Convolution':
+                k = node['input'][1]['dims']
+                return 2.0 * out * k[1] * k[2] * k[3] / 100e6 + 4.0 * out / 4.5e6
+            if node['type'] == 'MatMul':
+                return 2.0 * out * node['input'][0]['dims'][-1] / 20e6
+            inp = prod(node['input'][0]['dims']) if node.get('input') else 0
+            return 4.0 * (inp + out) / 4.5e6
+
+        dispatched = [t for t in self.task_list
+                      if t not in self._fused_away and G.nodes[t]['type'] not in ('Const', 'Parameter')]
+        position = {t: i for i, t in enumerate(dispatched)}
+
+        def tail(task):                  # graph node whose output port carries the tensor the task writes
+            f = self._fusion.get(task)
+            if f is None:
+                return task
+            return f['relu'] if f['relu'] is not None else f['add']
+
+        def consumers(nid):              # dispatched tasks that read the tensor of graph node nid
+            out = []
+            for succ in G.successors(nid):
+                if succ in self._concat_direct and succ in self._fused_away:
+                    out += consumers(succ)
+                elif succ in position and succ not in out:
+                    out.append(succ)
+            return sorted(out, key=position.get)
+
+        def joins(task):                 # the task writes into a tensor that other tasks write too
+            f = self._fusion.get(task)
+            return f is not None and f['into'] is not None
+
+        arm_memo = {}
+
+        def arm_cost(task):              # the task plus the chain of sole consumers behind it, up to the next fork / join
+            if task not in arm_memo:
+                total, cur = 0.0, task
+                while True:
+                    total += cost(cur)
+                    nxt = consumers(tail(cur))
+                    if joins(cur) or len(nxt) != 1:
+                        break
+                    srcs = {p for pred in G.pred[nxt[0]] for p in producers(pred)}
+                    if srcs != {cur}:
+                        break
+                    cur = nxt[0]
+                arm_memo[task] = total
+            return arm_memo[task]
+
+        stream_of, waits, records, rank_of, finish = {}, {}, set(), {}, {}
+        for task in dispatched:
             preds = sorted(G.pred[task], key=lambda p: G.edges[(p, task)]['connection'][3])
             primary = next((p for p in preds if producers(p)), None)
             if primary is None:
                 stream_of[task] = 0
+                finish[task] = cost(task)
             else:
-                j = placed.get(primary, 0)
-                placed[primary] = j + 1
-                stream_of[task] = (stream_of[producers(primary)[0]] + j) % n
+                if primary not in rank_of:           # heaviest arm first; schedule order breaks ties
+                    arms = sorted(consumers(primary), key=lambda t: (-arm_cost(t), position[t]))
+                    rank_of[primary] = {t: j for j, t in enumerate(arms)}
+                srcs = producers(primary)
+                base = max(srcs, key=lambda p: (finish[p], -position[p]))     # the producer expected to finish last
+                stream_of[task] = (stream_of[base] + rank_of[primary].get(task, 0)) % n
+                finish[task] = finish[base] + cost(task)
             deps = []
             for pred in preds:
                 for p in producers(pred):
