@@ -102,6 +102,7 @@ def main():
     ap.add_argument('--cpu-images', type=int, default=60, help='images timed on the CPU baseline (0 = skip)')
     ap.add_argument('--no-node-timing', action='store_true')
     ap.add_argument('--streams', type=int, default=0, help='compute streams the scheduler forks branches onto (0 = engine default)')
+    ap.add_argument('--requests', type=int, default=4, help='infer requests in flight per GPU (each a whole batch; 1 = synchronous infer())')
     args = ap.parse_args()
 
     from pyopenvino_amd import IECore, device, shard, synth
@@ -119,10 +120,11 @@ def main():
     ie = IECore()
     net = ie.read_network(xml, weights=blob)
     net.set_batch(args.batch)
-    ex = ie.load_network(net)
+    n_req = max(1, args.requests)
     if args.streams > 0:
-        ex.compute_streams = args.streams
-    n_streams = ex.compute_streams
+        os.environ['PVHIP_STREAMS'] = str(args.streams)
+    ex = ie.load_network(net, 'GPU', num_requests=n_req)
+    n_streams = ex.compute_streams           # per request
     comm = shard.BatchShardComm(group)
     ex.comm = comm
     comm.init_device()
@@ -130,15 +132,47 @@ def main():
     # synthetic input of this rank's shard, resident in HBM before the timed region
     x_host = synth.uniform_pixels(1000 + rank, (args.batch, 3, 224, 224))
     x_dev = device.DeviceTensor.from_numpy(x_host)
+    x_req = [x_dev] + [device.DeviceTensor.from_numpy(synth.uniform_pixels(1000 + rank + 100 * r, (args.batch, 3, 224, 224)))
+                       for r in range(1, n_req)]
     in_name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
 
-    for _ in range(args.warmup):
+    SAMPLE_EVERY = 10        # every 10th timed step is taken out of the pipeline and instrumented
+    dispatch_s = [0.0]       # host seconds spent dispatching asynchronous passes
+
+    def pipelined(steps, first=0, on_sample=None):
+        """`steps` forward passes with up to n_req whole-batch requests in flight (request i on its own streams and
+        its own resident input); every SAMPLE_EVERY-th pass is taken out of the pipeline when on_sample is given."""
+        in_flight, out = [], None
+        for step in range(first, first + steps):
+            if on_sample is not None and step % SAMPLE_EVERY == 0:
+                while in_flight:
+                    out = ex.wait(in_flight.pop(0))[out_name]
+                out = on_sample()
+                continue
+            r = step % n_req
+            if r in in_flight:
+                in_flight.remove(r)
+                out = ex.wait(r)[out_name]
+            ex.start_async(r, {in_name: x_req[r]})
+            dispatch_s[0] += sum(t[3] for t in ex.requests[r].runner.last_node_times if t[1] != 'Result')
+            in_flight.append(r)
+        while in_flight:
+            out = ex.wait(in_flight.pop(0))[out_name]
+        return out
+
+    # set-up, like the weight upload: three passes per request bring the device-memory pool to its steady state (a pass
+    # allocates its outputs before the previous ones are released), so that no hipMalloc falls into the timed region
+    for req in ex.requests:
+        for _ in range(3):
+            req.infer({in_name: x_req[req.index]})
+    out = pipelined(args.warmup) if n_req > 1 else None
+    for _ in range(args.warmup if n_req == 1 else 1):
         out = ex.infer({in_name: x_dev})[out_name]
     assert out.shape == (args.batch * world, 1000) and np.isfinite(out).all()
 
     # A hipEvent bracket costs ~10-15 us of stream time, so inside the timed region only the dominant kernel
-    # (the Convolution launches) is bracketed, one bracket per RUN of consecutive Convolution launches (~17 runs
-    # of 57 launches per step) and only on every 5th step; the per-layer breakdown (one bracket per node, each
+    # (the Convolution launches) is bracketed, one bracket per RUN of consecutive Convolution launches (~14 runs
+    # of 57 launches per step) and only on every 10th step, which runs alone and on one stream; the per-layer breakdown (one bracket per node, each
     # inflated by its bracket) is taken in an extra, untimed pass afterwards and is informational only.
     KERNEL_NODES = {'Convolution', 'MatMul', 'MaxPool', 'AvgPool', 'Add', 'Multiply', 'ReLU', 'SoftMax', 'LRN',
                     'Concat', 'Transpose', 'GroupConvolution', 'Clamp', 'Sigmoid'}
@@ -150,19 +184,31 @@ def main():
     device.synchronize()
     t0 = time.perf_counter()
     ev0 = device.Event().record()
-    for step in range(args.steps):
-        sample = (not args.no_node_timing) and step % 5 == 0
-        ex.device_timing = {'Convolution'} if sample else None
-        ex.device_timing_runs = True
-        ex.compute_streams = 1 if sample else n_streams   # a kernel's own duration: sampled steps run the branches serially
-        out = ex.infer({in_name: x_dev})[out_name]
+    def sampled_step():
+        nonlocal host_dispatch, sampled_steps, conv_ms, conv_launches, conv_brackets
+        ex.device_timing, ex.device_timing_runs = {'Convolution'}, True
+        streams_before, ex.compute_streams = ex.compute_streams, 1     # a kernel's own duration: one stream, nothing else in flight
+        res = ex.infer({in_name: x_dev})[out_name]
+        ex.compute_streams, ex.device_timing = streams_before, None
         host_dispatch += sum(t[3] for t in ex.last_node_times if t[1] != 'Result')
-        if sample:
-            sampled_steps += 1
-            for nid, typ, name, ms, count in ex.device_times_ms(with_counts=True):
-                conv_ms += ms
-                conv_launches += count
-                conv_brackets += 1
+        sampled_steps += 1
+        for nid, typ, name, ms, count in ex.device_times_ms(with_counts=True):
+            conv_ms += ms
+            conv_launches += count
+            conv_brackets += 1
+        return res
+
+    if n_req > 1:
+        dispatch_s[0] = 0.0
+        out = pipelined(args.steps, 0, None if args.no_node_timing else sampled_step)
+        host_dispatch += dispatch_s[0]
+    else:
+        for step in range(args.steps):
+            if (not args.no_node_timing) and step % SAMPLE_EVERY == 0:
+                out = sampled_step()
+            else:
+                out = ex.infer({in_name: x_dev})[out_name]
+                host_dispatch += sum(t[3] for t in ex.last_node_times if t[1] != 'Result')
     ev1 = device.Event().record()
     device.synchronize()
     group.barrier()
@@ -199,7 +245,7 @@ def main():
                                    'input resident in HBM, Result copied to host'.format(args.batch, WEIGHT_SEED),
                        'global_batch': args.batch * world,
                        'parallelism': 'batch shard x{} (one process per GPU), RCCL all-gather of Result'.format(world),
-                       'compute_streams': n_streams},
+                       'requests_in_flight': n_req, 'compute_streams_per_request': n_streams},
             'device_ms_per_step': dev_ms / args.steps,
             'host_dispatch_ms_per_step': 1000.0 * host_dispatch / args.steps,
         }
@@ -243,8 +289,8 @@ def main():
                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_launch_ms * 1e3,
                         'algorithmic_bytes_per_launch': conv['bytes'] / n_launch,
                         'traffic_source': traffic_src, 'event_sampled_steps': sampled_steps,
-                        'measured_on': 'every 5th timed step, run on one stream (the other steps fork the inception arms onto {} streams, '
-                                       'where kernels overlap and a launch has no duration of its own)'.format(n_streams),
+                        'measured_on': 'every 10th timed step, run alone on one stream (the other steps keep {} requests in flight with the inception '
+                                       'arms on {} streams each: kernels overlap and a launch has no duration of its own)'.format(n_req, n_streams),
                         'event_brackets_per_step': conv_brackets // sampled_steps}
             breakdown = {}
             for typ, agg in sorted(by_type.items(), key=lambda kv: -kv[1]['ms']):

@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   4
+#define PVHIP_ABI_VERSION   5
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -49,6 +49,13 @@ int         pvhip_malloc(void** ptr, size_t bytes);     /* pooled: freed blocks 
 int         pvhip_free(void* ptr);                      /* returns the block to the pool             */
 int         pvhip_pool_release(void);                   /* hipFree everything cached in the pool     */
 int         pvhip_pool_stats(size_t* bytes_in_use, size_t* bytes_cached);
+/* Allocation epochs, for forward passes that run on several streams or asynchronously (several requests in flight):
+ * blocks allocated between _begin and _dispatched belong to the epoch; one of them that is freed while the epoch is
+ * open waits until _end (called once the pass is known to have finished on the device) instead of being handed out
+ * again at once; blocks of ended epochs -- the previous outputs a new pass replaces -- are reusable immediately. */
+int         pvhip_pool_epoch_begin(int* epoch);
+int         pvhip_pool_epoch_dispatched(void);          /* later allocations belong to no epoch */
+int         pvhip_pool_epoch_end(int epoch);
 int         pvhip_memcpy_h2d(void* dst, const void* src, size_t bytes);  /* Parameter.py:11-13, Const.py:11-13 upload; async w.r.t. device, host buffer reusable on return */
 int         pvhip_memcpy_d2h(void* dst, const void* src, size_t bytes);  /* Result.py:17 read-back; SYNCHRONISES the stream */
 int         pvhip_memcpy_d2d(void* dst, const void* src, size_t bytes);

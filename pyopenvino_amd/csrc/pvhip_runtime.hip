@@ -31,9 +31,15 @@ int fail(int code, const char* fmt, ...) {
 namespace {
 struct Pool {
     std::mutex                                  mu;
-    std::unordered_map<void*, size_t>           live;    // ptr -> rounded bytes
+    struct Live { size_t bytes; int epoch; };
+    std::unordered_map<void*, Live>             live;    // ptr -> rounded bytes, allocation epoch
     std::map<size_t, std::vector<void*>>        cached;  // rounded bytes -> free blocks
-    std::vector<std::pair<void*, size_t>>       deferred; // freed while streams were forked: reusable after a full sync
+    std::vector<std::pair<void*, size_t>>       deferred; // epoch-0 blocks freed while streams were forked: reusable after a full sync
+    // Allocation epochs: one per forward pass that runs on several streams (or asynchronously).  A block freed while
+    // the pass that allocated it may still be executing waits in `parked` until that pass is declared finished;
+    // blocks of finished passes (the previous outputs a new pass replaces) are reusable at once.
+    int                                                     next_epoch = 1, current_epoch = 0;
+    std::unordered_map<int, std::vector<std::pair<void*, size_t>>> parked;   // open epoch -> freed blocks
     size_t                                      bytes_live = 0, bytes_cached = 0;
 };
 Pool& pool() {
@@ -128,6 +134,12 @@ int pvhip_shutdown(void) {
         std::lock_guard<std::mutex> g(p.mu);
         for (auto& kv : p.live) (void)hipFree(kv.first);
         p.live.clear();
+        for (auto& kv : p.parked)
+            for (auto& blk : kv.second) (void)hipFree(blk.first);
+        p.parked.clear();
+        for (auto& blk : p.deferred) (void)hipFree(blk.first);
+        p.deferred.clear();
+        p.current_epoch = 0;
         p.bytes_live = 0;
     }
     for (int i = 0; i < kMaxStreams; ++i)
@@ -186,7 +198,7 @@ int pvhip_malloc(void** ptr, size_t bytes) {
         }
         *ptr = d;
     }
-    p.live[*ptr] = rb;
+    p.live[*ptr] = Pool::Live{rb, p.current_epoch};
     p.bytes_live += rb;
     return PVHIP_OK;
 }
@@ -198,10 +210,17 @@ int pvhip_free(void* ptr) {
     std::lock_guard<std::mutex> g(p.mu);
     auto it = p.live.find(ptr);
     if (it == p.live.end()) return fail(PVHIP_EINVAL, "pvhip_free: %p is not a live pvhip block", ptr);
-    const size_t rb = it->second;
+    const size_t rb    = it->second.bytes;
+    const int    epoch = it->second.epoch;
     p.live.erase(it);
     p.bytes_live -= rb;
-    if (state().forked) {
+    if (epoch != 0) {
+        auto open = p.parked.find(epoch);
+        if (open != p.parked.end()) {       // its pass may still be running on some stream
+            open->second.emplace_back(ptr, rb);
+            return PVHIP_OK;
+        }
+    } else if (state().forked) {
         // consumers may still be queued on another stream: reusable only after the next full sync
         p.deferred.emplace_back(ptr, rb);
         return PVHIP_OK;
@@ -210,6 +229,40 @@ int pvhip_free(void* ptr) {
     // stream before the free, and the next owner's work is enqueued after it.
     p.cached[rb].push_back(ptr);
     p.bytes_cached += rb;
+    return PVHIP_OK;
+}
+
+int pvhip_pool_epoch_begin(int* epoch) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(epoch != nullptr);
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    *epoch          = p.next_epoch++;
+    p.current_epoch = *epoch;
+    p.parked[*epoch];            // open
+    return PVHIP_OK;
+}
+
+int pvhip_pool_epoch_dispatched(void) {
+    PVHIP_REQUIRE_INIT();
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.current_epoch = 0;
+    return PVHIP_OK;
+}
+
+int pvhip_pool_epoch_end(int epoch) {
+    PVHIP_REQUIRE_INIT();
+    Pool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    auto it = p.parked.find(epoch);
+    if (it == p.parked.end()) return fail(PVHIP_EINVAL, "pvhip_pool_epoch_end: epoch %d is not open", epoch);
+    for (auto& blk : it->second) {
+        p.cached[blk.second].push_back(blk.first);
+        p.bytes_cached += blk.second;
+    }
+    p.parked.erase(it);
+    if (p.current_epoch == epoch) p.current_epoch = 0;
     return PVHIP_OK;
 }
 

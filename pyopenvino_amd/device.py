@@ -37,6 +37,9 @@ SIGNATURES = {
     'pvhip_memcpy_d2d': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
     'pvhip_memset': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t]),
     'pvhip_sync': (_c.c_int, []),
+    'pvhip_pool_epoch_begin': (_c.c_int, [_c.POINTER(_c.c_int)]),
+    'pvhip_pool_epoch_dispatched': (_c.c_int, []),
+    'pvhip_pool_epoch_end': (_c.c_int, [_c.c_int]),
     'pvhip_stream_select': (_c.c_int, [_c.c_int]),
     'pvhip_stream_wait_event': (_c.c_int, [_c.c_void_p]),
     'pvhip_event_create_untimed': (_c.c_int, [_c.POINTER(_c.c_void_p)]),
@@ -323,6 +326,21 @@ def i64_array(values):
     """Host int64 array in ctypes form (shapes, strides, permutations)."""
     arr = (_c.c_int64 * max(1, len(values)))(*[int(v) for v in values])
     return arr
+
+
+def pool_epoch_begin() -> int:
+    """Open an allocation epoch (one forward pass on several streams / in flight): see include/pvhip.h."""
+    e = _c.c_int(0)
+    call('pvhip_pool_epoch_begin', _c.byref(e))
+    return e.value
+
+
+def pool_epoch_dispatched():
+    call('pvhip_pool_epoch_dispatched')
+
+
+def pool_epoch_end(epoch: int):
+    call('pvhip_pool_epoch_end', int(epoch))
 
 
 def select_stream(index: int):

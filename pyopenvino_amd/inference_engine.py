@@ -84,9 +84,13 @@ class IECore:
         return net
 
     def load_network(self, network, device_name: str = 'GPU', num_requests: int = 1):
+        """`num_requests` (accepted and ignored by the reference, inference_engine.py:86) is the number of infer
+        requests that may be in flight at once: `exenet.requests[i].start_async(inputs)` / `.wait()`, each request
+        with its own graph state and its own compute streams.  `exenet.infer()` stays the synchronous call."""
         exenet = Executable_Network(network)
         self.check_nodes(exenet.ienet.G)
         exenet.schedule_tasks()
+        exenet.create_requests(max(1, int(num_requests)))
         return exenet
 
 
@@ -230,6 +234,64 @@ class IENetwork:
         self.batch_size = batch
 
 
+class InferRequest:
+    """One inference that can be in flight next to others (the OpenVINO infer-request idea behind the reference's
+    unused `num_requests`): it owns a copy of the graph state (node outputs, cached device constants) and a set of
+    compute streams, so that the kernels of several requests interleave on the device -- the HBM-bound layers of one
+    run beside the matrix-core-bound layers of another, and each fills the other's tails."""
+
+    def __init__(self, owner, runner, index: int):
+        self.owner, self.runner, self.index = owner, runner, index      # owner: the network load_network returned
+        self._in_flight = False
+
+    def start_async(self, inputs: dict):
+        if self._in_flight:
+            raise RuntimeError('request {} is still in flight: wait() first'.format(self.index))
+        ex = self.runner
+        G = ex.ienet.G
+        by_name = {G.nodes[n]['name']: n for n in G.nodes}
+        for node_name, val in inputs.items():
+            if node_name in by_name:
+                G.nodes[by_name[node_name]]['param'] = val
+        for nid, _ in ex.ienet.find_node_by_type('Result'):
+            G.nodes[nid]['comm'] = None          # the shards are gathered in wait(): one collective at a time, on stream 0
+            G.nodes[nid]['_async'] = True        # keep the result on the device: wait() reads it back
+        ex.defer_sync = True
+        try:
+            ex.run_tasks(False)
+        finally:
+            ex.defer_sync = False
+            for nid, _ in ex.ienet.find_node_by_type('Result'):
+                G.nodes[nid].pop('_async', None)
+        self._in_flight = True
+
+    def wait(self) -> dict:
+        ex = self.runner
+        G = ex.ienet.G
+        ex.wait_done()
+        self._in_flight = False
+        out = {}
+        comm = self.owner.comm
+        for nid, name in ex.ienet.find_node_by_type('Result'):
+            value = G.nodes[nid]['result']
+            if comm is not None and comm.world > 1:
+                # every rank waits for its requests in the same order, so the collectives of the one communicator
+                # are issued in the same order everywhere and never overlap each other (all on stream 0)
+                if hasattr(value, 'numpy') and not isinstance(value, np.ndarray):
+                    from . import device
+                    device.select_stream(0)
+                value = comm.allgather_rows(value)
+            if hasattr(value, 'numpy') and not isinstance(value, np.ndarray):
+                value = value.numpy()
+            G.nodes[nid]['result'] = value
+            out[name] = value
+        return out
+
+    def infer(self, inputs: dict) -> dict:
+        self.start_async(inputs)
+        return self.wait()
+
+
 class Executable_Network:
     def __init__(self, ienetwork: IENetwork):
         self.ienet = ienetwork
@@ -250,7 +312,43 @@ class Executable_Network:
         # Independent branches of the graph (the four arms of an inception module) go to separate compute
         # streams, ordered by untimed events; only for plugin sets whose tensors live on the device.
         self.compute_streams = int(os.environ.get('PVHIP_STREAMS', '4'))
+        self.stream_base = 0            # first compute stream of this network (several requests in flight use disjoint sets)
+        self.defer_sync = False         # True: run_tasks returns after the device-side join; the caller waits
         self._stream_plans = {}
+
+    def create_requests(self, count: int):
+        """Request 0 runs on this network's own graph; the others on copies of it made now, before anything has been
+        uploaded (constants are uploaded and weights packed per request: the IRs' weights are tens of MB).  The
+        compute streams (`compute_streams`, 4: what the device's hardware queues take without multiplexing -- more
+        streams than that serialise behind each other's event waits) are split evenly between the requests."""
+        import copy
+        if count > 8:
+            raise ValueError('at most 8 requests (one compute stream each)')
+        per = max(1, int(self.compute_streams) // count)
+        self.requests = [InferRequest(self, self, 0)]
+        for i in range(1, count):
+            twin = IENetwork(self.ienet.ie)
+            for key, val in self.ienet.__dict__.items():
+                if key not in ('ie', 'G'):
+                    twin.__dict__[key] = val
+            twin.G = copy.deepcopy(self.ienet.G)
+            twin.inputs = self.ienet.ie.construct_node_info(twin, 'Parameter')
+            twin.outputs = self.ienet.ie.construct_node_info(twin, 'Result')
+            runner = Executable_Network(twin)
+            runner.fuse_epilogues = self.fuse_epilogues
+            runner.schedule_tasks()
+            runner.requests = []
+            self.requests.append(InferRequest(self, runner, i))
+        if count > 1:
+            for i, req in enumerate(self.requests):
+                req.runner.stream_base = i * per
+                req.runner.compute_streams = per
+
+    def start_async(self, request_id: int, inputs: dict):
+        self.requests[request_id].start_async(inputs)
+
+    def wait(self, request_id: int) -> dict:
+        return self.requests[request_id].wait()
 
     def schedule_tasks(self):
         """Static list schedule: sources (Const, Parameter) first, then repeated sweeps in node order
@@ -373,8 +471,8 @@ class Executable_Network:
         (measured 25-40 us per join), which only the lighter arms pay.  Returns (stream of task, tasks to wait
         for, tasks that must record an event) or None when not applicable."""
         registry = self.ienet.ie.plugins.plugins
-        n = min(int(self.compute_streams), 8)
-        if n <= 1 or not all(getattr(sys.modules.get(m.__package__), 'DEVICE_STREAMS', False) for m in registry.values()):
+        n = max(1, min(int(self.compute_streams), 8 - self.stream_base))
+        if (n <= 1 and self.stream_base == 0 and not self.defer_sync) or not all(getattr(sys.modules.get(m.__package__), 'DEVICE_STREAMS', False) for m in registry.values()):
             return None                  # some plugin of the set computes on the host
         key = (tuple(self.task_list), frozenset(self._fused_away), n)
         plan = self._stream_plans.get(key)
@@ -491,8 +589,14 @@ class Executable_Network:
             from . import device
             stream_of, waits, records = plan
             done_events, spare, current = {}, self.__dict__.setdefault('_order_events', []), 0
-            device.select_stream(1)      # the whole pass counts as forked: blocks freed during it are not
-            device.select_stream(0)      # handed out again before the synchronisation that ends it
+            held = self.__dict__.setdefault('_events_in_flight', [])
+            spare.extend(held)           # the pass that recorded them has been waited for by now
+            del held[:]
+            base = self.stream_base
+            # blocks allocated during this pass and freed before it has finished on the device (workspaces) are
+            # parked until it has; the previous pass's outputs, replaced as we go, are reusable at once
+            epoch = device.pool_epoch_begin()
+            device.select_stream(base)
         for task in self.task_list:
             if task in self._fused_away:
                 continue
@@ -501,7 +605,7 @@ class Executable_Network:
             if plan is not None and task in stream_of:
                 if stream_of[task] != current:
                     current = stream_of[task]
-                    device.select_stream(current)
+                    device.select_stream(base + current)
                 for dep in waits[task]:
                     done_events[dep].wait()
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
@@ -557,15 +661,31 @@ class Executable_Network:
             # (infer() has read the Result back by now, so this costs nothing) and freed blocks become reusable
             joins = []
             for st in sorted(set(stream_of.values()) - {0}):
-                device.select_stream(st)
+                device.select_stream(base + st)
                 joins.append((spare.pop() if spare else device.Event(timed=False)).record())
-            device.select_stream(0)
+            device.select_stream(base)
             for ev in joins:
                 ev.wait()
-            device.synchronize()
-            spare.extend(joins)
-            spare.extend(done_events.values())
+            held.extend(joins)
+            held.extend(done_events.values())
+            device.pool_epoch_dispatched()
+            if self.defer_sync:          # asynchronous request: wait_done() ends the pass
+                self._pending = (epoch, (spare.pop() if spare else device.Event(timed=False)).record())
+            else:
+                device.select_stream(0)
+                device.synchronize()
+                device.pool_epoch_end(epoch)
         self.last_node_times = times
+
+    def wait_done(self):
+        """Host-side wait for a pass dispatched with defer_sync (its streams have been joined on the base stream)."""
+        pending = self.__dict__.pop('_pending', None)
+        if pending is not None:
+            from . import device
+            epoch, done = pending
+            done.synchronize()
+            device.pool_epoch_end(epoch)
+            self.__dict__.setdefault('_order_events', []).append(done)
 
     def _concat_buffer(self, cat_id):
         """Output tensor of a Concat whose producers write in place; one fresh tensor per infer."""

@@ -20,5 +20,8 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     comm = node.get('comm')
     if comm is not None and comm.world > 1:
         value = comm.allgather_rows(value)
-    node['result'] = value.numpy() if isinstance(value, dev.DeviceTensor) else np.asarray(value)
+    if node.get('_async') and isinstance(value, dev.DeviceTensor):
+        node['result'] = value          # an asynchronous request: InferRequest.wait() copies it to the host
+    else:
+        node['result'] = value.numpy() if isinstance(value, dev.DeviceTensor) else np.asarray(value)
     return []

@@ -177,6 +177,41 @@ def test_forked_streams_give_the_single_stream_bits(hip):
     del net_s, ex_s
 
 
+def test_requests_in_flight_give_the_synchronous_bits(hip):
+    """Three GoogLeNet requests in flight on disjoint stream sets (load_network(num_requests=3)) return exactly what
+    the synchronous infer() returns for the same inputs, over several rounds with the requests restarted in a
+    different order; the pool stops growing after the first rounds (workspaces of a pass are parked until it has
+    finished, previous outputs are recycled at once)."""
+    from pyopenvino_amd import IECore, synth
+    xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    blob = synth.synth_weights(xml, 1234)
+    B, R = 32, 3
+    ie = IECore(plugin_package=HIP)
+    net = ie.read_network(xml, weights=blob)
+    net.set_batch(B)
+    ex = ie.load_network(net, 'GPU', num_requests=R)
+    assert [r.runner.stream_base for r in ex.requests] == [0, 1, 2] and ex.requests[2].runner.compute_streams == 1
+    name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
+    xs = [synth.uniform_pixels(900 + i, (B, 3, 224, 224)) for i in range(R)]
+    want = [ex.infer({name: x})[out_name].copy() for x in xs]
+    for r in ex.requests:                    # two streams per request: forks inside a request AND requests side by side
+        r.runner.stream_base, r.runner.compute_streams = 2 * r.index, 2
+    sizes = []
+    for rnd_ in range(5):
+        order = [(i + rnd_) % R for i in range(R)]
+        for i in order:
+            ex.start_async(i, {name: xs[(i + rnd_) % R]})
+        for i in reversed(order):
+            got = ex.wait(i)[out_name]
+            assert np.array_equal(got, want[(i + rnd_) % R]), 'round {} request {}'.format(rnd_, i)
+        in_use, cached = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        hip.call('pvhip_pool_stats', ctypes.byref(in_use), ctypes.byref(cached))
+        sizes.append(in_use.value + cached.value)
+    assert sizes[-1] == sizes[-2] == sizes[-3], sizes
+    # the synchronous call still works on the same network afterwards
+    assert np.array_equal(ex.infer({name: xs[1]})[out_name], want[1])
+
+
 def test_rccl_binding_single_rank(hip):
     """The RCCL path of the C ABI (dlopen, unique id, communicator, all-gather, destroy) with one rank:
     exercises every call the multi-GPU Result gather makes; with world == 1 the gather is a device copy."""

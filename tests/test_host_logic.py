@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', device.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r' T (pvhip_[a-z0-9_]+)', nm))
     assert declared <= exported
-    assert lib.pvhip_abi_version() == 4
+    assert lib.pvhip_abi_version() == 5
     assert isinstance(lib.pvhip_last_error(), bytes)
 
 
@@ -208,3 +208,24 @@ def test_stream_plan_orders_every_cross_stream_edge():
         assert stream_of[by_name['inception_3a/3x3/WithoutBiases']] == stream_of[by_name['inception_3a/3x3_reduce/WithoutBiases']]
     _, _, ex = helpers.build_network('oracle.op_plugins', 'mnist')
     assert ex.plan_streams() is None
+
+
+def test_infer_requests_api_on_host_plugins():
+    """load_network(num_requests=N): requests own separate graph state; with host plugins start_async simply runs
+    the pass, wait() hands the result over; a request cannot be started twice without a wait."""
+    from pyopenvino_amd import IECore, synth
+    ie = IECore(plugin_package='oracle.op_plugins')
+    net = ie.read_network(os.path.join(MODELS, 'mnist.xml'))
+    net.set_batch(2)
+    ex = ie.load_network(net, 'CPU', num_requests=3)
+    assert len(ex.requests) == 3 and ex.requests[0].runner is ex and ex.requests[1].runner.ienet.G is not net.G
+    xs = [synth.uniform_pixels(40 + i, (2, 1, 28, 28)) for i in range(3)]
+    name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
+    want = [ex.infer({name: x})[out_name].copy() for x in xs]
+    for i, x in enumerate(xs):
+        ex.start_async(i, {name: x})
+    with pytest.raises(RuntimeError):
+        ex.start_async(1, {name: xs[1]})
+    for i in (2, 0, 1):
+        assert np.array_equal(ex.wait(i)[out_name], want[i])
+    assert np.array_equal(ex.requests[1].infer({name: xs[0]})[out_name], want[0])
