@@ -343,6 +343,9 @@ def pool_epoch_end(epoch: int):
     call('pvhip_pool_epoch_end', int(epoch))
 
 
+MAX_STREAMS = 8     # PVHIP_MAX_STREAMS of include/pvhip.h
+
+
 def select_stream(index: int):
     """Make compute stream `index` (0..7) the current one: every later launch and copy goes to it."""
     call('pvhip_stream_select', int(index))

@@ -274,15 +274,21 @@ class InferRequest:
         comm = self.owner.comm
         for nid, name in ex.ienet.find_node_by_type('Result'):
             value = G.nodes[nid]['result']
-            if comm is not None and comm.world > 1:
-                # every rank waits for its requests in the same order, so the collectives of the one communicator
-                # are issued in the same order everywhere and never overlap each other (all on stream 0)
-                if hasattr(value, 'numpy') and not isinstance(value, np.ndarray):
-                    from . import device
-                    device.select_stream(0)
-                value = comm.allgather_rows(value)
             if hasattr(value, 'numpy') and not isinstance(value, np.ndarray):
-                value = value.numpy()
+                from . import device
+                # The copy to the host synchronises the stream it is issued on: use one that has nothing else queued
+                # (this request's own have drained; another request's have not).
+                # With sharded batches the gather and the copy go to the LAST stream, which no request computes on:
+                # every rank waits for its requests in the same order, so the collectives of the one communicator
+                # are issued in the same order everywhere and never overlap each other.
+                gathers = comm is not None and comm.world > 1
+                device.select_stream(device.MAX_STREAMS - 1 if gathers else ex.stream_base)
+                if gathers:
+                    value = comm.allgather_rows(value)
+                value = value.numpy() if hasattr(value, 'numpy') and not isinstance(value, np.ndarray) else np.asarray(value)
+                device.select_stream(0)
+            elif comm is not None and comm.world > 1:
+                value = comm.allgather_rows(value)
             G.nodes[nid]['result'] = value
             out[name] = value
         return out
