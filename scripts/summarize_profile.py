@@ -24,10 +24,10 @@ def main():
     prof = os.path.join(repo, 'profiles')
     os.makedirs(prof, exist_ok=True)
     md = ['# rocprofv3 summary `{}`'.format(tag), '',
-          'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0 --streams 1` '
-          '(googlenet-v1, batch 256, 1 GPU; ONE compute stream, so that a launch\'s start-to-end time is its own: this is what '
-          'bench.py\'s roofline measures on its sampled single-stream steps).  The default command (inception arms forked onto 4 streams, '
-          'kernels overlapping) is summarised at the end.', '']
+          'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0 --requests 1 --streams 1` '
+          '(googlenet-v1, batch 256, 1 GPU; one request at a time on ONE compute stream, so that a launch\'s start-to-end time is its own: '
+          'this is what bench.py\'s roofline measures on its sampled steps).  The default command (4 whole-batch requests in flight, '
+          'kernels of different passes overlapping) is summarised at the end.', '']
     stats = find(os.path.join(raw, 'stats'), '*kernel_stats.csv')
     conv_total_ns = conv_calls = 0
     if stats:
@@ -47,6 +47,14 @@ def main():
             md += ['', '**conv_igemm_dma_kernel + conv_igemm_kernel (+ conv_igemm_rs_kernel), all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of 57 launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * 57 / 1e6)]
+    trace = find(os.path.join(raw, 'stats'), '*kernel_trace.csv')
+    if trace and conv_calls:
+        conv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(trace)) if 'conv_igemm' in r['Kernel_Name'])
+        tail_ = conv[-5 * 57:]
+        head_ = conv[:3 * 57]
+        md += ['', 'From the kernel trace of the same run: the first 3 forward passes (clocks ramping up from idle, cold caches) average {:.2f} us '
+               'per convolution launch, the LAST 5 passes **{:.2f} us** -- the steady state the timed region of bench.py sees.'.format(
+                   sum(e - b for b, e in head_) / len(head_) / 1e3, sum(e - b for b, e in tail_) / len(tail_) / 1e3)]
     line = os.path.join(raw, 'bench_line_under_profiler.json')
     if os.path.isfile(line) and os.path.getsize(line):
         b = json.loads(open(line).read())
@@ -64,10 +72,10 @@ def main():
                 calls += int(r['Calls'])
         with open(os.path.join(prof, tag + '_kernel_stats_forked.csv'), 'w') as f:
             f.write(open(forked).read())
-        forked_md = ['', '## Default command (4 compute streams)', '',
+        forked_md = ['', '## Default command (4 requests in flight)', '',
                      '`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0`: per-kernel table in `{}_kernel_stats_forked.csv`.  '
-                     'Convolution launches: {:.0f}, average start-to-end {:.2f} us -- longer than on one stream because launches of different arms '
-                     'share the chip; the step is shorter.'.format(tag, calls, tot / max(1.0, calls) / 1e3)]
+                     'Convolution launches: {:.0f}, average start-to-end {:.2f} us -- longer than alone on one stream because launches of different '
+                     'passes share the chip; the step is shorter.'.format(tag, calls, tot / max(1.0, calls) / 1e3)]
         fl = os.path.join(raw, 'bench_line_forked.json')
         if os.path.isfile(fl) and os.path.getsize(fl):
             b = json.loads(open(fl).read())
