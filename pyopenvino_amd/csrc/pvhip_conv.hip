@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "pvhip_common.h"
+#include "pvhip_wino.h"
 
 using namespace pvhip;
 
@@ -951,7 +952,9 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     if (k_out <= 0 || c <= 0 || kh <= 0 || kw <= 0) return 0;
     const size_t kred_pad = (size_t)round_up_int(c * kh * kw, kBK);
     const size_t kout_pad = (size_t)round_up_int(k_out, kKoutAlign);
-    return 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
+    size_t elems = 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
+    if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c);   // 3x3: the Winograd-transformed panel rides along (stride / pad are not known yet)
+    return elems;
 }
 
 int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw, int h, int w) {
@@ -965,6 +968,10 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
     float* wp   = wpack + 2 * (kred_pad + kTabSpare);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kPanelSpare) * kout_pad)), dim3(kBlock), 0, state().stream,
                        w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad, rs_major(c, kh, kw) ? 1 : 0);
+    if (kh == 3 && kw == 3 && wino_pack_elems(k_out, c) > 0) {
+        const int rc = wino_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out, c);
+        if (rc) return rc;
+    }
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }
@@ -1004,6 +1011,15 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
 
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
+
+    // ---- 3x3 / stride 1 / same padding: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (pvhip_wino.hip)
+    if (wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
+        const int rc = wino_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, c, h, w, k_out, bias, relu, act_lo,
+                                 act_hi, a.y_coff, a.y_ctotal);
+        if (rc) return rc;
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
 
     // ---- wave-direct kernel (PVHIP_CONV_KERNEL=wave, PVHIP_CONV_WTILE=TMxTN in units of 32)
     const char* kenv = getenv("PVHIP_CONV_KERNEL");

@@ -1,0 +1,14 @@
+// Internal interface of the Winograd F(2x2, 3x3) convolution (pvhip_wino.hip), used by pvhip_conv.hip.
+#pragma once
+#include <cstddef>
+
+namespace pvhip {
+
+// 3x3, stride 1, pad 1 ("same"), C a multiple of 4, and not switched off with PVHIP_CONV_WINOGRAD=0
+bool   wino_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow);
+size_t wino_pack_elems(int k, int c);                                 // floats of the transformed weight panel (0: not applicable)
+int    wino_pack(const float* w_oihw, float* u, int k, int c);       // enqueue the weight transform
+int    wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
+                 float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
+
+}  // namespace pvhip

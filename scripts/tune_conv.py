@@ -66,7 +66,6 @@ def main():
         y = dev.DeviceTensor.empty((n, k, oh, ow))
         elems = dev.call('pvhip_conv2d_pack_elems', k, c, kh, kw)
         wp = dev.DeviceTensor.empty((int(elems),))
-        dev.call('pvhip_conv2d_pack_f32', ctypes.c_void_p(wt.ptr), ctypes.c_void_p(wp.ptr), k, c, kh, kw, h, w)
         gflop = 2.0 * n * k * oh * ow * c * kh * kw / 1e9
         row = {'id': nid, 'name': name, 'x': xs, 'w': ws, 'gflop': gflop, 'ms': {}}
 
@@ -77,9 +76,16 @@ def main():
         for tile in tiles + ['auto']:
             for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE', 'PVHIP_CONV_ABLATE'):
                 os.environ.pop(envk, None)
+            os.environ['PVHIP_CONV_WINOGRAD'] = '1' if tile == 'auto' or tile.startswith('wg') else '0'     # other names are the direct kernels
+            os.environ.pop('PVHIP_WINO_KB', None)
+            os.environ.pop('PVHIP_WINO_WAVES', None)
             os.environ.pop('PVHIP_CONV_LDS_PAD_KB', None)
             if tile == 'auto':           # the library's own kernel / tile choice
                 pass
+            elif tile.startswith('wg'):      # wg<32|64>[x4]: Winograd, output channels per workgroup, 4 instead of 8 waves
+                os.environ['PVHIP_WINO_KB'] = tile[2:4]
+                if tile.endswith('x4'):
+                    os.environ['PVHIP_WINO_WAVES'] = '4'
             elif tile.startswith('p'):     # p<KB>:<tile>: LDS kernel with extra dynamic LDS (occupancy cap)
                 kb, tl = tile[1:].split(':')
                 os.environ['PVHIP_CONV_LDS_PAD_KB'] = kb
@@ -99,6 +105,7 @@ def main():
             elif tile != 'auto':
                 os.environ['PVHIP_CONV_KERNEL'] = 'lds'
                 os.environ['PVHIP_CONV_TILE'] = tile
+            dev.call('pvhip_conv2d_pack_f32', ctypes.c_void_p(wt.ptr), ctypes.c_void_p(wp.ptr), k, c, kh, kw, h, w)   # layout follows the env
             run()
             dev.synchronize()
             e0 = dev.Event().record()
@@ -107,7 +114,7 @@ def main():
             e1 = dev.Event().record()
             e1.synchronize()
             row['ms'][tile] = e0.elapsed_ms(e1) / args.reps
-        for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE'):
+        for envk in ('PVHIP_CONV_TILE', 'PVHIP_CONV_KERNEL', 'PVHIP_CONV_WTILE', 'PVHIP_CONV_WINOGRAD', 'PVHIP_WINO_KB', 'PVHIP_WINO_WAVES'):
             os.environ.pop(envk, None)
         best = min(tiles, key=lambda t: row['ms'][t])
         row['best'] = best

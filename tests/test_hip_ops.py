@@ -101,8 +101,32 @@ def test_conv_model_shapes_vs_oracle(hip, xs, ws, st, pb, pe):
     vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'conv {} * {}'.format(xs, ws))
 
 
+def test_conv_winograd_3x3(hip):
+    """3x3 / stride 1 / pad 1 layers run Winograd F(2x2, 3x3) (the default): odd extents (half-empty last patches),
+    one and many channel stages, ragged channel blocks, fewer patches than a workgroup holds, fused bias + activation."""
+    cases = [((2, 4, 7, 7), 5), ((3, 20, 13, 11), 70), ((1, 64, 14, 14), 32), ((2, 96, 28, 28), 128), ((5, 8, 1, 1), 3),
+             ((1, 12, 2, 9), 33)]
+    for xs, k in cases:
+        x = rnd(sum(xs), xs)
+        w = rnd(k, (k, xs[1], 3, 3), (2.0 / (xs[1] * 9)) ** 0.5)
+        err = vs_oracle('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)), 'winograd {} k{}'.format(xs, k))
+        assert err <= 2e-5, 'winograd {}: {:.2e}'.format(xs, err)
+    # same weights through the direct kernel: the two algorithms agree far inside the tolerance of the path
+    x, w = rnd(1, (2, 32, 9, 9)), rnd(2, (40, 32, 3, 3), 0.1)
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
+    wino = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+    os.environ['PVHIP_CONV_WINOGRAD'] = '0'
+    try:
+        direct = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+    finally:
+        del os.environ['PVHIP_CONV_WINOGRAD']
+    assert_close(wino, direct, 5e-6, 'winograd vs direct')
+    assert not np.array_equal(wino, direct)          # (they are different summations)
+
+
 def test_conv_every_tile_config(hip, monkeypatch):
     """Force each (BM, BN) instantiation on one shape that has ragged edges in both tile dimensions."""
+    monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
     x = rnd(1, (3, 20, 13, 11))
     w = rnd(2, (150, 20, 3, 3), 0.1)
     x2 = rnd(3, (3, 32, 13, 11))
@@ -133,6 +157,7 @@ def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
 def test_conv_lds_dma_kernel_every_tile(hip, monkeypatch):
     """The LDS-DMA (buffer_load ... lds) kernel, both reduction orders, on every channel tile: zero padding
     through the out-of-range sentinel, stride 2, ragged pixel and channel tiles, one and many reduction stages."""
+    monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
     cases = [((3, 32, 13, 11), (150, 32, 3, 3), (1, 1), (1, 1), (1, 1)),
              ((2, 48, 7, 7), (24, 48, 1, 1), (1, 1), (0, 0), (0, 0)),
              ((1, 16, 37, 37), (16, 16, 7, 7), (2, 2), (3, 3), (3, 3)),
@@ -168,6 +193,7 @@ def test_conv_fused_bias_and_activation_bit_exact(hip, monkeypatch, kernel):
     the separate Add / ReLU / Clamp launches bit for bit."""
     if kernel != 'default':
         monkeypatch.setenv('PVHIP_CONV_KERNEL', kernel)
+        monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
     cases = [('Convolution', (2, 32, 9, 9), (40, 32, 3, 3)),     # (r,s)-major kernel (LDS-DMA by default)
              ('Convolution', (2, 5, 9, 9), (70, 5, 3, 3)),       # c-major kernel
              ('GroupConvolution', (2, 24, 11, 11), (24, 1, 1, 3, 3))]
