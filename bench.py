@@ -288,7 +288,8 @@ def main():
                         continue
                 roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': tf / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic,
-                        'kernel': 'conv_igemm_dma_kernel + conv_igemm_kernel (all instantiations; {} Convolution launches per step, bias+ReLU fused)'.format(n_launch),
+                        'kernel': 'conv_wino_kernel (the ten 3x3 layers: Winograd F(2x2,3x3), 16/36 of the algorithmic multiplies) + conv_igemm_dma_kernel '
+                                  '(all instantiations; {} Convolution launches per step, bias+ReLU fused)'.format(n_launch),
                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_launch_ms * 1e3,
                         'algorithmic_bytes_per_launch': conv['bytes'] / n_launch,
                         'traffic_source': traffic_src, 'event_sampled_steps': sampled_steps,

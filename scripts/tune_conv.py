@@ -84,7 +84,7 @@ def main():
                 pass
             elif tile.startswith('wg'):      # wg<32|64>[x4]: Winograd, output channels per workgroup, 4 instead of 8 waves
                 os.environ['PVHIP_WINO_KB'] = tile[2:4]
-                if tile.endswith('x4'):
+                if 'x4' in tile:
                     os.environ['PVHIP_WINO_WAVES'] = '4'
             elif tile.startswith('p'):     # p<KB>:<tile>: LDS kernel with extra dynamic LDS (occupancy cap)
                 kb, tl = tile[1:].split(':')
