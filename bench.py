@@ -136,7 +136,7 @@ def main():
                        for r in range(1, n_req)]
     in_name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
 
-    SAMPLE_EVERY = 10        # every 10th timed step is taken out of the pipeline and instrumented
+    SAMPLE_EVERY = 20        # every 20th timed step (the first one included) is taken out of the pipeline and instrumented
     dispatch_s = [0.0]       # host seconds spent dispatching asynchronous passes
 
     def pipelined(steps, first=0, on_sample=None):
@@ -198,7 +198,7 @@ def main():
 
     # A hipEvent bracket costs ~10-15 us of stream time, so inside the timed region only the dominant kernel
     # (the Convolution launches) is bracketed, one bracket per RUN of consecutive Convolution launches (~14 runs
-    # of 57 launches per step) and only on every 10th step, which runs alone and on one stream; the per-layer breakdown (one bracket per node, each
+    # of 57 launches per step) and only on every 20th step, which runs alone and on one stream; the per-layer breakdown (one bracket per node, each
     # inflated by its bracket) is taken in an extra, untimed pass afterwards and is informational only.
     conv_ms, conv_launches, conv_brackets = 0.0, 0, 0
     sampled_steps = 0
@@ -293,7 +293,7 @@ def main():
                         'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_launch_ms * 1e3,
                         'algorithmic_bytes_per_launch': conv['bytes'] / n_launch,
                         'traffic_source': traffic_src, 'event_sampled_steps': sampled_steps,
-                        'measured_on': 'every 10th timed step, run alone on one stream (the other steps keep {} requests in flight with the inception '
+                        'measured_on': 'every 20th timed step (the first included), run alone on one stream (the other steps keep {} requests in flight with the inception '
                                        'arms on {} streams each: kernels overlap and a launch has no duration of its own)'.format(n_req, n_streams),
                         'event_brackets_per_step': conv_brackets // sampled_steps}
             breakdown = {}

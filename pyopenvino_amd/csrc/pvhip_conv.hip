@@ -537,8 +537,12 @@ __device__ __forceinline__ void dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, u
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int BM, bool kRS>   // kRS: (r,s)-major reduction order (C % 16 == 0); else c-major with the window-bit table
+// kPW (pointwise: 1x1, stride 1, no padding, H*W % 4 == 0, (r,s)-major): the im2col tile is then a plain copy of 16
+// channel rows x 128 consecutive pixels, moved as 8 one-KiB pieces (16 bytes per lane, two tile rows per piece) instead
+// of 32 dword gathers per stage.
+template <int BM, bool kRS, bool kPW = false>   // kRS: (r,s)-major reduction order (C % 16 == 0); else c-major with the window-bit table
 __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
+    static_assert(!kPW || kRS, "the pointwise copy uses the (r,s)-major panel");
     constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
     constexpr int A_PIECES = kBK * BM * 4 / 1024;          // 1-KiB wave-instructions per weight tile
     constexpr int A_PER_WAVE = (A_PIECES + 3) / 4;
@@ -605,6 +609,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     }
     const unsigned a_stage_bytes = (unsigned)(kBK * a.kout_pad) * 4u;
 
+    // pointwise: lane -> (row parity inside a piece, group of 4 consecutive pixels); a group never straddles two images
+    unsigned pwoff = kOob;
+    if (kPW) {
+        const int gp = ptile * BN + (lane & 31) * 4;
+        if (gp < a.P) {
+            const int n = gp / HW, hw = gp - n * HW;
+            pwoff = (unsigned)(n * a.C * HW + hw) * 4u + (unsigned)(lane >> 5) * chan_bytes;
+        }
+    }
+
     int      rs_l = 0, cs_l = 0, kt_l = 0;      // stage being loaded
     unsigned voff = kRS ? ((inb & 1ull) ? xoff + (unsigned)rstab[0] : kOob) : 0u;
     // c-major: the 8 table entries (byte offset c*H*W + r*W + s, window bit r*kw + s; padding rows carry bit 63,
@@ -620,7 +634,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
 
 #define PV3_ISSUE(buf_)                                                                                   \
     {                                                                                                     \
-        if (kRS) {                                                                                        \
+        if (kPW) {                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                 \
+                dma_b128(xr, &Bs[buf_][2 * (wid + 4 * q)][0], pwoff,                                      \
+                         (unsigned)(cs_l * kBK + 2 * (wid + 4 * q)) * chan_bytes);                        \
+        } else if (kRS) {                                                                                 \
             const unsigned sbase = (unsigned)(cs_l * kBK + prow0) * chan_bytes;                           \
             _Pragma("unroll") for (int j = 0; j < B_LOADS; ++j)                                           \
                 dma_b32(xr, &Bs[buf_][prow0 + j][phalf], voff, sbase + (unsigned)j * chan_bytes);         \
@@ -920,7 +938,11 @@ void launch_conv(const ConvArgs& a, int n_ptiles) {
     if (BN == 128 && WAVES_M == 1 && dma_enabled() && (rs_major(a.C, a.kh, a.kw) || a.kh * a.kw < 64)) {
         const char* pad = getenv("PVHIP_CONV_LDS_PAD_KB");     // diagnostic: extra dynamic LDS caps workgroups per CU
         const size_t dyn = pad ? (size_t)atoi(pad) * 1024 : 0;
-        if (rs_major(a.C, a.kh, a.kw))
+        const bool pw = rs_major(a.C, a.kh, a.kw) && a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
+                        a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && getenv("PVHIP_CONV_NOPW") == nullptr;
+        if (pw)
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
+        else if (rs_major(a.C, a.kh, a.kw))
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
         else
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
@@ -1069,6 +1091,7 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     // leaves >= 4 workgroups per CU, else 32.  PVHIP_CONV_TILE=BMxBN overrides (tuning runs only).
     int bm = (k_out % 64 == 0 || k_out % 64 > 32) ? 64 : 32, bn = 128;
     if (bm == 64 && (long)((a.P + 127) / 128) * ((k_out + 63) / 64) < 4 * kNumCU) bm = 32;
+    if (kh == 1 && kw == 1) bm = 32;      // 1x1 layers: the smaller tile wins on every GoogLeNet shape (more workgroups per CU)
     const char* env = getenv("PVHIP_CONV_TILE");
     if (env != nullptr) {
         int ebm = 0, ebn = 0;

@@ -79,6 +79,7 @@ def main():
             os.environ['PVHIP_CONV_WINOGRAD'] = '1' if tile == 'auto' or tile.startswith('wg') else '0'     # other names are the direct kernels
             os.environ.pop('PVHIP_WINO_KB', None)
             os.environ.pop('PVHIP_WINO_WAVES', None)
+            os.environ.pop('PVHIP_CONV_NOPW', None)
             os.environ.pop('PVHIP_CONV_LDS_PAD_KB', None)
             if tile == 'auto':           # the library's own kernel / tile choice
                 pass
@@ -96,6 +97,10 @@ def main():
                 os.environ['PVHIP_CONV_KERNEL'] = 'wave'
                 os.environ['PVHIP_CONV_ABLATE'] = tile[1]
                 os.environ['PVHIP_CONV_WTILE'] = tile[3:]
+            elif tile.startswith('n'):     # n<tile>: LDS-DMA kernel without the 16-byte pointwise copy
+                os.environ['PVHIP_CONV_KERNEL'] = 'dma'
+                os.environ['PVHIP_CONV_TILE'] = tile[1:]
+                os.environ['PVHIP_CONV_NOPW'] = '1'
             elif tile.startswith("d"):     # d<tile>: LDS-DMA kernel (the default for (r,s)-major shapes)
                 os.environ['PVHIP_CONV_KERNEL'] = 'dma'
                 os.environ['PVHIP_CONV_TILE'] = tile[1:]
