@@ -330,6 +330,7 @@ def i64_array(values):
 
 def pool_epoch_begin() -> int:
     """Open an allocation epoch (one forward pass on several streams / in flight): see include/pvhip.h."""
+    ensure_init()
     e = _c.c_int(0)
     call('pvhip_pool_epoch_begin', _c.byref(e))
     return e.value
@@ -348,6 +349,7 @@ MAX_STREAMS = 8     # PVHIP_MAX_STREAMS of include/pvhip.h
 
 def select_stream(index: int):
     """Make compute stream `index` (0..7) the current one: every later launch and copy goes to it."""
+    ensure_init()
     call('pvhip_stream_select', int(index))
 
 

@@ -275,3 +275,17 @@ def test_ssd_whole_ir_vs_reference_and_batch(hip):
         g, w = got[0, 0, b * 100:(b + 1) * 100], want2[0, 0, b * 100:(b + 1) * 100]
         assert np.array_equal(np.sort(g[:, 1]), np.sort(w[:, 1])), 'image {}: detected classes differ'.format(b)
         assert_close(g[np.argsort(-g[:, 2], kind='stable'), 2:], w[np.argsort(-w[:, 2], kind='stable'), 2:], helpers.REL_TOL, 'image {} of the batch'.format(b))
+
+
+def test_infer_without_explicit_device_init():
+    """A fresh process that never calls device.init(): the first infer() binds the GPU itself (the scheduler's stream /
+    pool calls come before the first tensor is created)."""
+    import subprocess
+    import sys
+    code = ("import sys, os, numpy as np; sys.path.insert(0, %r); "
+            "from pyopenvino_amd import IECore; ie = IECore(); "
+            "net = ie.read_network(os.path.join(%r, 'mnist.xml')); ex = ie.load_network(net); "
+            "out = ex.infer({net.inputs[0]['name']: np.zeros((1, 1, 28, 28), np.float32)}); "
+            "print(next(iter(out.values())).shape)") % (helpers.REPO, helpers.MODELS)
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and '(1, 10)' in res.stdout, res.stderr[-2000:]
