@@ -33,10 +33,15 @@ def _worker(rank, world, port, total, out_dir):
     ie.plugins.plugins['Result'] = importlib.import_module('pyopenvino_amd.op_plugins.Result')   # the product's gather
     net = ie.read_network(os.path.join(helpers.MODELS, 'mnist.xml'))
     net.set_batch(hi - lo)
-    ex = ie.load_network(net)
+    ex = ie.load_network(net, 'CPU', num_requests=2)
     ex.comm = comm
     x = np.concatenate([synth.uniform_pixels(300 + i, (1, 1, 28, 28)) for i in range(total)], 0)
     out = ex.infer({net.inputs[0]['name']: x[lo:hi]})[net.outputs[0]['name']]
+    # the same through two requests in flight: the shards are gathered in wait(), in the same order on every rank
+    for r in (0, 1):
+        ex.start_async(r, {net.inputs[0]['name']: x[lo:hi]})
+    for r in (1, 0):
+        assert np.array_equal(ex.wait(r)[net.outputs[0]['name']], out)
     t = group.allreduce_max(float(rank + 1))
     group.barrier()
     np.save(os.path.join(out_dir, 'rank{}.npy'.format(rank)), out)
