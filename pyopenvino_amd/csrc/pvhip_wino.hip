@@ -117,9 +117,14 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino
     // ---- gather duty.  NTL == 2: wave w gathers channel w of the stage for 64 patches (lane <-> patch).
     // NTL == 1: waves 0 and 1 gather two channels each for 32 patches (lane & 31 <-> patch, lane >> 5 picks the channel,
     // whose offset is folded into the lane's addresses); waves 2 and 3 have none.
-    const bool gathers = (NTL == 2) ? wid < 4 : wid < 2;
+    // With 8 waves the duty rotates from stage to stage (waves 2g, 2g+1 resp. 4g..4g+3 take the stages with s % groups == g):
+    // the transform is vector-ALU work, which the fp32 MFMA cannot overlap, so it is spread over all four SIMDs.
+    constexpr int G_WAVES = (NTL == 2) ? 4 : 2;               // waves that gather one stage
+    constexpr int G_GROUPS = WAVES / G_WAVES;                  // 1 or 2 (4 waves), 2 or 4 (8 waves)
+    const int  g_group = wid / G_WAVES, g_wave = wid % G_WAVES;
     const int  g_patch = (NTL == 2) ? lane : (lane & 31);
-    const int  g_chan  = (NTL == 2) ? wid : wid * 2 + (lane >> 5);         // channel inside the stage (per lane when NTL == 1)
+    const int  g_chan  = (NTL == 2) ? g_wave : g_wave * 2 + (lane >> 5);   // channel inside the stage (per lane when NTL == 1)
+    const bool gathers = true;                                 // every wave has the duty for some stages
     unsigned voff[16];
     {
         const int t = tb * NT + g_patch;
@@ -145,8 +150,8 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino
 
     float d[16];
 #define PVW_GATHER(s_)                                                                                          \
-    if (gathers) {                                                                                              \
-        const unsigned soff = (unsigned)((s_) * kCB + ((NTL == 2) ? wid : 0)) * chan_bytes;                      \
+    if (g_group == (s_) % G_GROUPS) {                                                                           \
+        const unsigned soff = (unsigned)((s_) * kCB + ((NTL == 2) ? g_wave : 0)) * chan_bytes;                   \
         _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                           \
             d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff[e], soff, 0));        \
     }
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino
             wino_dma_b128(ur, &Us[buf_][0][0][0] + (wid + WAVES * q) * 256, u_lane + (unsigned)(wid + WAVES * q) * 1024u, soff); \
     }
     // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]];  written as V[xi][channel][patch]
-#define PVW_TRANSFORM_STORE(buf_)                                                                               \
-    if (gathers) {                                                                                              \
+#define PVW_TRANSFORM_STORE(buf_, s_)                                                                           \
+    if (g_group == (s_) % G_GROUPS) {                                                                           \
         float m[16];                                                                                            \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
             m[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];                                                          \
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino
 
     PVW_GATHER(0);
     PVW_LOAD_U(0, 0);
-    PVW_TRANSFORM_STORE(0);
+    PVW_TRANSFORM_STORE(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        PVW_TRANSFORM_STORE(buf ^ 1);
+        PVW_TRANSFORM_STORE(buf ^ 1, s + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
