@@ -317,7 +317,8 @@ def main():
                 with open(os.path.join(out_dir, 'bench_breakdown.json'), 'w') as f:
                     json.dump({'by_type': breakdown, 'layers': layers, 'device': device.device_name()}, f, indent=1)
         result['roofline'] = roof
-        result['cpu_baseline'] = cpu_baseline(blob, args.cpu_images) if args.cpu_images > 0 else None
+        # the CPU restatement of the reference path, on rank 0 at N=1 only (the other ranks would wait for it at the exit barrier)
+        result['cpu_baseline'] = cpu_baseline(blob, args.cpu_images) if (args.cpu_images > 0 and world == 1) else None
         print(json.dumps(result), flush=True)
 
     comm.close()
