@@ -21,7 +21,9 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         if param.dtype != np.dtype(precision):
             raise TypeError('device-resident input must already be {}'.format(np.dtype(precision).name))
         return {0: param.reshape(shape)}
-    host = np.array(param).reshape(shape).astype(precision)
+    # no host-side copies unless the caller's array needs one (the reference copies twice, Parameter.py:11-13; at
+    # (256,3,224,224) fp32 each copy costs more than the upload)
+    host = np.asarray(param).reshape(shape).astype(precision, copy=False)
     if host.dtype != np.float32:
         return {0: host}
     return {0: dev.DeviceTensor.from_numpy(host)}
