@@ -124,6 +124,39 @@ def test_conv_winograd_3x3(hip):
     assert not np.array_equal(wino, direct)          # (they are different summations)
 
 
+def test_conv_seeded_random_shapes(hip):
+    """80 seeded random convolutions (kernel 1..5, stride 1..2, pads 0..2 on either side, ragged channel counts,
+    batch 1..5) against the oracle: every kernel family is hit (Winograd, pointwise copy, (r,s)-major and c-major
+    LDS-DMA) with shapes nobody picked by hand."""
+    rng = np.random.RandomState(20240611)
+    families = set()
+    for case in range(80):
+        kh, kw = (int(rng.randint(1, 6)),) * 2 if rng.rand() < 0.7 else (int(rng.randint(1, 6)), int(rng.randint(1, 6)))
+        sh = sw = int(rng.randint(1, 3))
+        pb = (int(rng.randint(0, 3)), int(rng.randint(0, 3)))
+        pe = (int(rng.randint(0, 3)), int(rng.randint(0, 3)))
+        if rng.rand() < 0.35:
+            kh = kw = 3; sh = sw = 1; pb = pe = (1, 1)                       # Winograd-eligible
+        c = int(rng.choice([1, 3, 4, 7, 8, 16, 20, 32, 48]))
+        k = int(rng.choice([1, 5, 16, 31, 32, 33, 64, 70, 100]))
+        h, w = int(rng.randint(max(kh - pb[0] - pe[0], 1), 19)), int(rng.randint(max(kw - pb[1] - pe[1], 1), 19))
+        if rng.rand() < 0.15:
+            kh = kw = sh = sw = 1; pb = pe = (0, 0); c = int(rng.choice([16, 32, 48])); w = 4 * int(rng.randint(1, 5))   # pointwise copy
+        if h + pb[0] + pe[0] < kh or w + pb[1] + pe[1] < kw:
+            continue
+        n = int(rng.randint(1, 6))
+        if (h + pb[0] + pe[0] - kh) % sh or (w + pb[1] + pe[1] - kw) % sw:
+            continue                                                          # the reference's im2col raises on these
+        x = rnd(1000 + case, (n, c, h, w))
+        wt = rnd(2000 + case, (k, c, kh, kw), (2.0 / (c * kh * kw)) ** 0.5)
+        vs_oracle('Convolution', [x, wt], conv_data((sh, sw), pb, pe), 'random case {}: x{} w{} s{} pb{} pe{}'.format(
+            case, x.shape, wt.shape, (sh, sw), pb, pe))
+        families.add('wino' if (kh, kw, sh, sw, pb, pe) == (3, 3, 1, 1, (1, 1), (1, 1)) and c % 4 == 0 else
+                     'pw' if (kh, kw, sh, sw, pb, pe) == (1, 1, 1, 1, (0, 0), (0, 0)) and c % 16 == 0 and (h * w) % 4 == 0 else
+                     'rs' if c % 16 == 0 else 'c')
+    assert families == {'wino', 'pw', 'rs', 'c'}, families
+
+
 def test_conv_every_tile_config(hip, monkeypatch):
     """Force each (BM, BN) instantiation on one shape that has ragged edges in both tile dimensions."""
     monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
