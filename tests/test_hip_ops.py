@@ -340,6 +340,34 @@ def test_maxpool_vs_oracle_bit_exact(hip, xs, k, s, pb, pe, rounding):
     vs_oracle('MaxPool', [rnd(sum(xs), xs, 1.0, -0.7)], pool_data(k, s, pb, pe, rounding))
 
 
+def test_pools_seeded_random_shapes(hip):
+    """120 seeded random MaxPool / AvgPool configurations (window 1..4, stride 1..3, pads 0..2, floor / ceil) against
+    the oracle, bit for bit for MaxPool; where the reference raises (an empty window), so must the plugin."""
+    rng = np.random.RandomState(7)
+    ran = 0
+    for case in range(120):
+        type_ = 'MaxPool' if case % 3 else 'AvgPool'
+        k = (int(rng.randint(1, 5)), int(rng.randint(1, 5)))
+        st = (int(rng.randint(1, 4)), int(rng.randint(1, 4)))
+        pb = (int(rng.randint(0, 3)), int(rng.randint(0, 3)))
+        pe = (int(rng.randint(0, 3)), int(rng.randint(0, 3)))
+        xs = (int(rng.randint(1, 4)), int(rng.randint(1, 9)), int(rng.randint(1, 40)), int(rng.randint(1, 40)))
+        data = pool_data(k, st, pb, pe, 'ceil' if rng.rand() < 0.5 else 'floor')
+        x = rnd(3000 + case, xs, 1.0, -0.5)
+        node = make_node(type_, [x], data)
+        try:
+            want = first_out(oracle_plugin(type_).compute(node, {0: x}, kernel_type='special'))
+        except Exception as exc:                     # the reference's own failure modes (np.max of an empty slice, ...)
+            with pytest.raises(type(exc)):
+                hip_plugin(type_).compute(node, {0: x})
+            continue
+        if want.size == 0:
+            continue
+        check(node, {0: x}, want, '{} case {}: x{} k{} s{} pb{} pe{} {}'.format(type_, case, xs, k, st, pb, pe, data['rounding_type']))
+        ran += 1
+    assert ran >= 80, ran
+
+
 def test_maxpool_nan_propagates(hip):
     x = rnd(5, (1, 2, 6, 6))
     x[0, 1, 2, 3] = np.nan
