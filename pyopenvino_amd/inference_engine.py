@@ -70,15 +70,20 @@ class IECore:
             print('Unsupported nodes : {}'.format(sorted(missing)))
         return missing
 
-    def read_network(self, model: str, weights=None):
+    def read_network(self, model: str, weights=None, fp16_as_fp32=None):
         """``model``: path of the IR ``.xml``.  ``weights``: path of the ``.bin`` (default: next to the
         xml, as the reference does) or the blob itself (bytes / uint8 ndarray) when the weights were
-        synthesised in memory."""
+        synthesised in memory.  ``fp16_as_fp32``: run an FP16 IR with fp32 tensors (constants upcast once at load,
+        every FP16 port declared FP32); default: what the plugin package asks for (``COMPUTE_FP32``)."""
         net = IENetwork(self)
         net.read_IR_Model(model, weights)
         net.parse_IR_XML()
         net.build_graph()
         net.set_constants_to_graph()
+        if fp16_as_fp32 is None:
+            fp16_as_fp32 = all(getattr(sys.modules.get(m.__package__), 'COMPUTE_FP32', False) for m in self.plugins.plugins.values())
+        if fp16_as_fp32:
+            net.promote_fp16()
         net.inputs = self.construct_node_info(net, 'Parameter')
         net.outputs = self.construct_node_info(net, 'Result')
         return net
@@ -186,6 +191,28 @@ class IENetwork:
 
     def find_node_by_type(self, type: str) -> list:
         return [(n, self.G.nodes[n]['name']) for n in self.G.nodes if self.G.nodes[n]['type'] == type]
+
+    def promote_fp16(self):
+        """SURVEY 8(f)-4, first step: an FP16 IR (ports FP16, f16 constants; the reference runs it in numpy float16,
+        common_def.py:13-17) is computed with fp32 tensors -- every FP16 port is declared FP32, f16 constants are upcast
+        once here, the Parameter takes fp32.  Results are at least as close to exact arithmetic as the reference's."""
+        promoted = False
+        for nid in self.G.nodes:
+            node = self.G.nodes[nid]
+            for tag in ('input', 'output'):
+                for port in node.get(tag, {}).values():
+                    if port['precision'] == 'FP16':
+                        port['precision'] = 'FP32'
+                        promoted = True
+            attrs = node.get('data')
+            if attrs is not None and str(attrs.get('element_type', '')).lower() == 'f16':
+                attrs['element_type'] = 'f32'
+                promoted = True
+                if node['type'] == 'Const':
+                    data = np.asarray(node['const']['data'], dtype=np.float16).astype(np.float32)
+                    node['const'] = {'data': data, 'element_info': 'F32', 'size': data.nbytes,
+                                     'decode_info': common_def.format_config['F32']}
+        self.ir_precision = 'FP16' if promoted else 'FP32'
 
     # ------------------------------------------------------------------ batch
     def set_batch(self, batch: int):

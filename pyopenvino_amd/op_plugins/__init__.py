@@ -3,3 +3,7 @@
 # Every plugin of this package takes and returns device-resident tensors and enqueues its work on the current
 # compute stream, so the engine may fork independent branches of a graph onto separate streams.
 DEVICE_STREAMS = True
+
+# The kernels of this package compute in fp32: an FP16 IR is loaded with its constants upcast and its ports declared FP32
+# (IENetwork.promote_fp16).
+COMPUTE_FP32 = True

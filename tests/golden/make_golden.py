@@ -22,6 +22,7 @@ Fixtures
                            synthetic weights, 1 image: 'concat' in full, the two class tensors subsampled + float64 sums
   ssd_full_e2e.npz         the whole SSD IR (prior boxes + DetectionOutput included) through the reference's infer(),
                            synthetic weights, 1 image: the (1,1,100,7) detections and the (1,2,7668) prior tensor
+  mnist_fp16_e2e.npz       models/mnist rewritten as an FP16 IR (tests/helpers.fp16_ir) through the reference (numpy float16), 3 images
   conv_node6_crop.npz      the reference's own single-node fixture resources/node_args_6.pickle (SSD Conv2d_0,
                            3x3 stride 2 same_upper pads (0,0)/(1,1)), input cropped to 64x64 and cast to fp32
 """
@@ -245,6 +246,30 @@ def ssd_full_case(IECore):
     print('  detections', out.shape, 'records', int((out[0, 0, :, 0] >= 0).sum()), 'first', out[0, 0, 0])
 
 
+def fp16_case(IECore):
+    """models/mnist as an FP16 IR (tests/helpers.fp16_ir: every port FP16, constants stored as f16)
+    through the reference, which computes it in numpy float16; three of the mnist_e2e images."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import helpers
+    print('mnist as an FP16 IR through the reference (float16 numpy)')
+    tmp = '/tmp/pv_golden_models'
+    os.makedirs(tmp, exist_ok=True)
+    blob = open(os.path.join(REF, 'models', 'mnist.bin'), 'rb').read()
+    xml16, blob16 = helpers.fp16_ir(os.path.join(REF, 'models', 'mnist.xml'), blob, tmp)
+    stem = xml16[:-4]
+    with open(stem + '.bin', 'wb') as f:
+        f.write(blob16)
+    images = np.load(os.path.join(HERE, 'mnist_e2e.npz'))['images'][:3]
+    outs = []
+    for i in range(len(images)):
+        o, _ = run_model(IECore, stem, images[i:i + 1])
+        assert o.dtype == np.float16, o.dtype
+        outs.append(o.astype(np.float32))
+    out = np.concatenate(outs, 0)
+    np.savez_compressed(os.path.join(HERE, 'mnist_fp16_e2e.npz'), out=out, n_images=np.array(len(images)))
+    print('  out', out.shape, 'argmax', out.argmax(axis=1))
+
+
 def run_model(IECore, model, x, input_name=None, capture_layers=False):
     """Reference, kernel_type='special', N=1.  Returns the Result array and {node id: float64 sum}."""
     ie = IECore()
@@ -369,6 +394,9 @@ def main():
         ssd_backbone_case(IECore)
         ssd_full_case(IECore)
         return
+    if 'fp16' in sys.argv[1:]:           # only the FP16-IR fixture
+        fp16_case(IECore)
+        return
     if 'head' in sys.argv[1:]:           # only the SSD head per-op fixtures and the end-to-end SSD fixture
         head_cases(plugins)
         ssd_full_case(IECore)
@@ -377,6 +405,7 @@ def main():
     head_cases(plugins)
     node6_case(plugins)
     model_cases(IECore)
+    fp16_case(IECore)
     ssd_backbone_case(IECore)
     ssd_full_case(IECore)
     print('done')

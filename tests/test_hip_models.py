@@ -289,3 +289,9 @@ def test_infer_without_explicit_device_init():
             "print(next(iter(out.values())).shape)") % (helpers.REPO, helpers.MODELS)
     res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and '(1, 10)' in res.stdout, res.stderr[-2000:]
+
+
+def test_fp16_ir_computed_in_fp32(hip, tmp_path):
+    """SURVEY 8(f)-4, first step: an FP16 IR loads (constants upcast once, ports declared FP32) and runs on the fp32 kernels."""
+    from test_oracle_golden import check_fp16_ir
+    check_fp16_ir(HIP, tmp_path)

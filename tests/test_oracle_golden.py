@@ -115,3 +115,35 @@ def test_oracle_ssd_whole_ir_vs_reference():
     out2 = helpers.infer_one(ex2, net2, np.concatenate([synth.uniform_pixels(9, (1, 3, 300, 300)), x], 0))
     assert out2.shape == (1, 1, 200, 7)
     assert_close(out2[:, :, 100:], z['out'], 1e-6, 'image 1 of a batch of 2')
+
+
+def check_fp16_ir(plugin_package, tmp_path):
+    """models/mnist rewritten as an FP16 IR, computed with fp32 tensors (IENetwork.promote_fp16), against what the
+    reference makes of the same IR in numpy float16: equal within float16 resolution where the reference is finite;
+    where its float16 exp() overflowed (NaN at the winning class of the two real digits) fp32 gives the probability."""
+    z = np.load(os.path.join(GOLDEN, 'mnist_fp16_e2e.npz'))
+    images = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))['images'][:int(z['n_images'])]
+    blob = open(os.path.join(helpers.MODELS, 'mnist.bin'), 'rb').read()
+    xml16, blob16 = helpers.fp16_ir(os.path.join(helpers.MODELS, 'mnist.xml'), blob, str(tmp_path))
+    from pyopenvino_amd import IECore
+    ie = IECore(plugin_package=plugin_package)
+    net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=True)
+    assert net.ir_precision == 'FP16' and all(p['precision'] != 'FP16' for n in net.G.nodes for p in net.G.nodes[n].get('output', {}).values())
+    net.set_batch(len(images))
+    ex = ie.load_network(net)
+    ex.kernel_type = 'special'
+    got = helpers.infer_one(ex, net, images)
+    want = z['out']
+    assert got.dtype == np.float32 and got.shape == want.shape and np.isfinite(got).all()
+    finite = np.isfinite(want)
+    assert np.abs(got[finite] - want[finite]).max() <= 2e-3
+    for row in range(len(want)):
+        overflowed = np.isnan(want[row])
+        if overflowed.any():
+            assert overflowed.sum() == 1 and got[row, overflowed][0] > 0.99 and got[row].argmax() == int(np.argmax(overflowed))
+    ref32 = np.load(os.path.join(GOLDEN, 'mnist_e2e.npz'))['out'][:len(images)]     # the FP32 IR: f16 weights barely move it
+    assert_close(got, ref32, 2e-3, 'FP16 IR vs the FP32 IR')
+
+
+def test_oracle_fp16_ir_as_fp32(tmp_path):
+    check_fp16_ir('oracle.op_plugins', tmp_path)
