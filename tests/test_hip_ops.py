@@ -467,6 +467,33 @@ def test_depthwise_conv_vs_oracle(hip, xs, st, pb, pe):
     vs_oracle('GroupConvolution', [rnd(sum(xs), xs), w], conv_data(st, pb, pe, 'same_upper'))
 
 
+def test_hipgraph_capture_and_replay(hip):
+    """pvhip_graph_*: a short sequence of launches captured once on the compute stream and replayed on new input
+    contents gives what the eager launches give (the buffers are fixed, as a captured forward pass requires)."""
+    import ctypes
+    P = ctypes.c_void_p
+    x = hip.DeviceTensor.from_numpy(rnd(1, (3, 8, 12, 12)))
+    b = hip.DeviceTensor.from_numpy(rnd(2, (3, 8, 12, 12)))
+    t, y = hip.DeviceTensor.empty(x.shape), hip.DeviceTensor.empty(x.shape)
+    hip.call('pvhip_relu_f32', P(x.ptr), P(t.ptr), x.size)            # eager run first (also loads the kernels)
+    hip.synchronize()
+    hip.call('pvhip_graph_begin_capture')
+    hip.call('pvhip_relu_f32', P(x.ptr), P(t.ptr), x.size)
+    hip.call('pvhip_sigmoid_f32', P(t.ptr), P(y.ptr), x.size)
+    handle = ctypes.c_void_p(0)
+    hip.call('pvhip_graph_end_capture', ctypes.byref(handle))
+    try:
+        for seed in (3, 4):
+            new = rnd(seed, x.shape)
+            hip.call('pvhip_memcpy_h2d', P(x.ptr), new.ctypes.data_as(P), new.nbytes)
+            hip.call('pvhip_graph_launch', handle)
+            want = first_out(oracle_plugin('Sigmoid').compute(make_node('Sigmoid', [new]), {0: np.where(new < 0, 0, new).astype(np.float32)}))
+            assert_close(y.numpy(), want, 1e-6, 'replay {}'.format(seed))
+    finally:
+        hip.call('pvhip_graph_destroy', handle)
+    del b
+
+
 def test_device_tensor_roundtrip_and_pool_reuse(hip):
     x = rnd(1, (5, 7, 3))
     t = hip.DeviceTensor.from_numpy(x)
