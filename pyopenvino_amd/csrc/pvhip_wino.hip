@@ -7,14 +7,16 @@
 // Rounding differs from the direct sum at the 1e-7 level (fp32 throughout, coefficients 0, +-1, +-1/2).
 //
 //   * Weights are transformed once, at pack time: U[xi][c][k] = (G g G^T)[xi], xi = 4*i + j, laid out per
-//     (block of 32 output channels, stage of 4 input channels) as the dense [16][4][32] image the kernel stages.
-//   * A workgroup owns 32 output channels x 64 patches.  Per stage of 4 input channels: wave w gathers channel w
-//     of every patch (lane <-> patch; 16 buffer_load_dword with per-element out-of-range sentinels for the padding,
-//     wave-uniform channel offset: no address arithmetic in the loop), transforms its patch in registers (32
-//     additions) and writes V[xi][c][patch] to LDS; the U image arrives by LDS-DMA.  Then 16 independent GEMMs
-//     D_xi[k][patch] += U_xi[k][c] * V_xi[c][patch] on v_mfma_f32_32x32x2_f32: wave w owns the four xi of row i = w.
+//     (block of 32 or 64 output channels, stage of 4 input channels) as the dense [16][4][block] image the kernel stages.
+//   * A workgroup of 8 waves owns 64 output channels x 32 patches (32 x 64 when K does not fill 64-channel blocks).
+//     Per stage of 4 input channels the waves on duty (the duty rotates from stage to stage) gather the 4x4 patches
+//     (lane <-> patch; 16 buffer_load_dword with per-element out-of-range sentinels for the padding, wave-uniform
+//     channel offset: no address arithmetic in the loop), transform them in registers (32 additions) and write
+//     V[xi][c][patch] to LDS; the U image arrives by LDS-DMA.  Then 16 independent GEMMs
+//     D_xi[k][patch] += U_xi[k][c] * V_xi[c][patch] on v_mfma_f32_32x32x2_f32: wave w owns the four xi of row
+//     i = w & 3 for the 32x32 tile w >> 2.
 //   * Epilogue: the output transform is separable; each wave applies the column half to its own row (registers), the
-//     four rows meet in LDS, then bias / activation / store of 2x2 patches (8-byte runs per lane, 256 B per 32 lanes).
+//     four rows meet in LDS, then bias / activation / store of 2x2 patches.
 #include "pvhip_common.h"
 #include "pvhip_wino.h"
 
@@ -81,8 +83,8 @@ __device__ __forceinline__ void wino_dma_b128(__amdgpu_buffer_rsrc_t r, float* d
 }
 
 // MT x NTL = 32-channel tiles x 32-patch tiles per workgroup: (1, 2) = 32 channels x 64 patches, (2, 1) = 64 x 32.
-// The second form gathers (and transforms) each input patch once per 64 output channels instead of once per 32 -- the
-// stride-2 patch gather is what the texture-address unit spends its time on -- and is used when K fills 64-channel blocks.
+// The second form gathers (and transforms) each input patch once per 64 output channels instead of once per 32 and is
+// used when K fills 64-channel blocks (or nearly: at most 12 % of padding).
 template <int MT, int NTL, int WAVES>     // WAVES = 4: every wave owns both 32x32 tiles of its four xi; 8: one tile each
 __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino_kernel(WinoArgs a) {
     static_assert(MT * NTL == 2, "two accumulator tiles per xi");
