@@ -127,7 +127,19 @@ def main():
     n_streams = ex.compute_streams           # per request
     comm = shard.BatchShardComm(group)
     ex.comm = comm
-    comm.init_device()
+    # The Result gather goes over RCCL; if the communicator cannot be created on ANY rank (no librccl, no peer access) all
+    # ranks agree to gather through the host group instead -- said loudly on stderr and in the JSON line, never silently.
+    gather_path, rccl_error = ('rccl' if comm.use_rccl else ('none (one rank)' if world == 1 else 'host group (PVHIP_NO_RCCL=1)')), ''
+    if comm.use_rccl:
+        try:
+            comm.init_device()
+        except Exception as exc:       # noqa: BLE001 -- whatever it is, the other ranks must hear about it
+            rccl_error = '{}: {}'.format(type(exc).__name__, exc)
+        if group.allreduce_max(1.0 if rccl_error else 0.0) > 0.0:
+            comm.use_rccl = False
+            gather_path = 'host group (RCCL communicator unavailable{})'.format(': ' + rccl_error if rccl_error else ' on another rank')
+            print('bench.py rank {}: RCCL unavailable, gathering Result tensors through the host group. {}'.format(rank, rccl_error),
+                  file=sys.stderr, flush=True)
 
     # synthetic input of this rank's shard, resident in HBM before the timed region
     x_host = synth.uniform_pixels(1000 + rank, (args.batch, 3, 224, 224))
@@ -247,7 +259,8 @@ def main():
             'config': {'workload': 'models/googlenet-v1.xml 1x3x224x224 fp32, batch {} per GPU, synthetic weights seed {}, '
                                    'input resident in HBM, Result copied to host'.format(args.batch, WEIGHT_SEED),
                        'global_batch': args.batch * world,
-                       'parallelism': 'batch shard x{} (one process per GPU), RCCL all-gather of Result'.format(world),
+                       'parallelism': 'batch shard x{} (one process per GPU), all-gather of Result'.format(world),
+                       'result_gather': gather_path,
                        'requests_in_flight': n_req, 'compute_streams_per_request': n_streams},
             'device_ms_per_step': dev_ms / args.steps,
             'host_dispatch_ms_per_step': 1000.0 * host_dispatch / args.steps,

@@ -102,10 +102,15 @@ class BatchShardComm:
         dev.ensure_init()
         uid = None
         if self.rank == 0:
-            buf = ctypes.create_string_buffer(dev.UNIQUE_ID_BYTES)
-            dev.call('pvhip_comm_unique_id', buf)
-            uid = buf.raw
+            try:
+                buf = ctypes.create_string_buffer(dev.UNIQUE_ID_BYTES)
+                dev.call('pvhip_comm_unique_id', buf)
+                uid = buf.raw
+            except dev.PvhipError as exc:      # the other ranks are waiting in the broadcast: tell them
+                uid = 'error: {}'.format(exc)
         uid = self.group.broadcast_bytes(uid, src=0)
+        if isinstance(uid, str):
+            raise dev.PvhipError('rank 0 could not create the RCCL unique id ({})'.format(uid))
         dev.call('pvhip_comm_init', ctypes.c_char_p(uid), self.rank, self.world)
         self._rccl_ready = True
 
