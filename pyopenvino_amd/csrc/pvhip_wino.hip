@@ -82,22 +82,29 @@ __device__ __forceinline__ void wino_dma_b128(__amdgpu_buffer_rsrc_t r, float* d
 #endif
 }
 
-// MT x NTL = 32-channel tiles x 32-patch tiles per workgroup: (1, 2) = 32 channels x 64 patches, (2, 1) = 64 x 32.
+// MT x NTL = 32-channel tiles x 32-patch tiles per workgroup: (2, 1) = 64 channels x 32 patches, (1, 2) = 32 x 64,
+// (1, 1) = 32 x 32 on four waves.
 // The second form gathers (and transforms) each input patch once per 64 output channels instead of once per 32 and is
 // used when K fills 64-channel blocks (or nearly: at most 12 % of padding).
 template <int MT, int NTL, int WAVES>     // WAVES = 4: every wave owns both 32x32 tiles of its four xi; 8: one tile each
-__global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino_kernel(WinoArgs a) {
-    static_assert(MT * NTL == 2, "two accumulator tiles per xi");
+__global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 2) void conv_wino_kernel(WinoArgs a) {
+    static_assert(MT * NTL == 2 || (MT * NTL == 1 && WAVES == 4), "two accumulator tiles per xi, or one with four waves");
+    constexpr int TILES = MT * NTL;
     static_assert(WAVES == 4 || WAVES == 8, "four or eight waves");
     constexpr int THREADS = WAVES * kWave;
-    constexpr int TPW = 8 / WAVES;            // accumulator tiles per wave and xi
+    constexpr int TPW = TILES * 4 / WAVES;    // accumulator tiles per wave and xi
     constexpr unsigned kOob = 0x80000000u;
     constexpr int KB = 32 * MT, NT = 32 * NTL;
     constexpr int U_PIECES = 16 * kCB * KB * 4 / 1024;      // 1-KiB pieces of one U stage image: 8 * MT
     constexpr int U_PER_WAVE = U_PIECES / WAVES;
-    __shared__ __attribute__((aligned(1024))) float Us[2][16][kCB][KB];
-    __shared__ __attribute__((aligned(1024))) float Vs[2][16][kCB][NT];
-    static_assert(sizeof(Us) + sizeof(Vs) == 48 * 1024, "48 KB of LDS");
+    struct Stage {                     // one allocation: the epilogue's exchange buffer may run across both arrays
+        float Us[2][16][kCB][KB];
+        float Vs[2][16][kCB][NT];
+    };
+    __shared__ __attribute__((aligned(1024))) Stage sm;
+    auto& Us = sm.Us;
+    auto& Vs = sm.Vs;
+    static_assert(sizeof(Stage) == (TILES == 2 ? 48 : 32) * 1024, "48 (32) KB of LDS");
 
     const int nwg = gridDim.x;
     int       lid;
@@ -242,12 +249,12 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8) ? 4 : 2) void conv_wino
 
     // ---- output transform  Y = A^T D A,  A^T = [[1,1,1,0],[0,1,-1,-1]]: columns in registers (this wave holds row i = wid),
     // rows through LDS, one 32-channel x 32-patch tile at a time: Ex[i][b][k][patch].
-    float* Ex = (sizeof(Vs) >= 32 * 1024) ? &Vs[0][0][0][0] : &Us[0][0][0][0];     // 4 * 2 * 32 * 32 floats = 32 KB
+    float* Ex = (sizeof(sm.Vs) >= 32 * 1024) ? &Vs[0][0][0][0] : &Us[0][0][0][0];     // 4 * 2 * 32 * 32 floats = 32 KB (may span Us and Vs)
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
                                                                         a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
     const int OH = a.H, OW = a.W;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < TILES; ++h) {
         if (h == 1) __syncthreads();         // the reads of the first tile are done
         if (TPW == 2 || my_tile == h) {
             const int hh = (TPW == 2) ? h : 0;
@@ -352,13 +359,18 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.u_bytes = (unsigned)(wino_pack_elems(k_out, c) * 4);
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
-    const int  nt   = kb == 64 ? 32 : 64;
+    // 32-channel blocks run as 32 channels x 32 patches on four waves (more, smaller workgroups: the layers whose K is not
+    // made of 64-channel blocks are the small 14x14 ones); PVHIP_WINO_SMALL=0 selects 32 x 64 on eight waves (tuning runs)
+    const char* se    = getenv("PVHIP_WINO_SMALL");
+    const bool  small = kb == 32 && !(se != nullptr && se[0] == '0');
+    const int  nt   = (kb == 64 || small) ? 32 : 64;
     const long n_tb = ((long)a.T + nt - 1) / nt;
     if (n_tb * a.n_kb > 0x7fffffffL) return fail(PVHIP_EUNSUPPORTED, "wino_conv: grid too large");
     const char* we    = getenv("PVHIP_WINO_WAVES");       // tuning runs only
     const int   waves = (we != nullptr && atoi(we) == 4) ? 4 : 8;
     const dim3  grid((unsigned)(n_tb * a.n_kb));
-    if (kb == 64 && waves == 8) hipLaunchKernelGGL((conv_wino_kernel<2, 1, 8>), grid, dim3(512), 0, state().stream, a);
+    if (small) hipLaunchKernelGGL((conv_wino_kernel<1, 1, 4>), grid, dim3(256), 0, state().stream, a);
+    else if (kb == 64 && waves == 8) hipLaunchKernelGGL((conv_wino_kernel<2, 1, 8>), grid, dim3(512), 0, state().stream, a);
     else if (kb == 64) hipLaunchKernelGGL((conv_wino_kernel<2, 1, 4>), grid, dim3(256), 0, state().stream, a);
     else if (waves == 8) hipLaunchKernelGGL((conv_wino_kernel<1, 2, 8>), grid, dim3(512), 0, state().stream, a);
     else hipLaunchKernelGGL((conv_wino_kernel<1, 2, 4>), grid, dim3(256), 0, state().stream, a);

@@ -79,6 +79,7 @@ def main():
             os.environ['PVHIP_CONV_WINOGRAD'] = '1' if tile == 'auto' or tile.startswith('wg') else '0'     # other names are the direct kernels
             os.environ.pop('PVHIP_WINO_KB', None)
             os.environ.pop('PVHIP_WINO_WAVES', None)
+            os.environ.pop('PVHIP_WINO_SMALL', None)
             os.environ.pop('PVHIP_CONV_NOPW', None)
             os.environ.pop('PVHIP_CONV_LDS_PAD_KB', None)
             if tile == 'auto':           # the library's own kernel / tile choice
@@ -87,6 +88,7 @@ def main():
                 os.environ['PVHIP_WINO_KB'] = tile[2:4]
                 if 'x4' in tile:
                     os.environ['PVHIP_WINO_WAVES'] = '4'
+                os.environ['PVHIP_WINO_SMALL'] = '1' if tile.endswith('s') else '0'     # wg32s: 32 channels x 32 patches, four waves
             elif tile.startswith('p'):     # p<KB>:<tile>: LDS kernel with extra dynamic LDS (occupancy cap)
                 kb, tl = tile[1:].split(':')
                 os.environ['PVHIP_CONV_LDS_PAD_KB'] = kb

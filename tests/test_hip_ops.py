@@ -101,14 +101,16 @@ def test_conv_model_shapes_vs_oracle(hip, xs, ws, st, pb, pe):
     vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'conv {} * {}'.format(xs, ws))
 
 
-@pytest.mark.parametrize('kb,waves', [(None, None), ('32', '8'), ('64', '8'), ('32', '4'), ('64', '4')])
+@pytest.mark.parametrize('kb,waves', [(None, None), ('32', 'small'), ('32', '8'), ('64', '8'), ('32', '4'), ('64', '4')])
 def test_conv_winograd_3x3(hip, monkeypatch, kb, waves):
     """3x3 / stride 1 / pad 1 layers run Winograd F(2x2, 3x3) (the default): odd extents (half-empty last patches),
     one and many channel stages, ragged channel blocks, fewer patches than a workgroup holds, fused bias + activation;
-    every workgroup shape (32 / 64 output channels, 8 / 4 waves), the library's own choice first."""
+    every workgroup shape (32 / 64 output channels, 8 / 4 waves, the 32 x 32 four-wave form), the library's own choice first."""
     if kb is not None:
         monkeypatch.setenv('PVHIP_WINO_KB', kb)
-        monkeypatch.setenv('PVHIP_WINO_WAVES', waves)
+        monkeypatch.setenv('PVHIP_WINO_SMALL', '1' if waves == 'small' else '0')
+        if waves != 'small':
+            monkeypatch.setenv('PVHIP_WINO_WAVES', waves)
     cases = [((2, 4, 7, 7), 5), ((3, 20, 13, 11), 70), ((1, 64, 14, 14), 32), ((2, 96, 28, 28), 128), ((5, 8, 1, 1), 3),
              ((1, 12, 2, 9), 33)]
     for xs, k in cases:
