@@ -1,6 +1,9 @@
 // Pooling kernels (HBM-bound).  NCHW fp32; lanes run along the output row so the window loads of a
 // wave are contiguous (stride sw) segments of input rows and the stores are fully coalesced.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "pvhip_common.h"
 
@@ -178,6 +181,270 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __re
         yout[o] = anynan ? NAN : m;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 MaxPool, stride 1 or 2, as a persistent double-buffered pipeline (the GoogLeNet pools: 3x3/s2 ceil and
+// 3x3/s1/p1).  Same semantics as maxpool2d_lds_kernel (MaxPool.py:41-72: zero pad cells take part in the max,
+// windows are clipped at the padded extent, NaN wins).
+//
+// A tile is G planes x a band of output rows.  Its input (whole planes: one dense run; bands: one dense run per
+// plane) goes global -> LDS by LDS-DMA (16 bytes per lane, no staging registers), and the DMA of tile t+1 is in
+// flight while tile t is computed and stored.  The LDS image is the DENSE input (no pad cells): a lane owns one
+// output COLUMN of a segment of rows and slides down it, so every input row costs it 3 LDS reads and one
+// horizontal max, and an output is the max of three of those row values (3 instead of 9 LDS reads per output at
+// stride 1, 6 at stride 2).  Taps outside the tensor are clamped onto a tap of the same window that is inside (a
+// duplicate changes no max); a window that touches pad cells inside the padded extent gets max(m, 0) -- the value
+// those cells hold in the reference.  The outputs of a tile are collected in LDS and leave as dense 16-byte runs.
+struct Pool3Args {
+    const float* x;
+    float*       y;
+    unsigned long long x_bytes;
+    int n_planes, h, w, oh, ow;
+    int pt, pl, hp, wp;
+    int G, S, band_rows, n_bands;   // tile = G planes x band_rows output rows, split over S row segments per column
+    int dense;                      // 1: bands == 1, a tile's input is ONE dense run of G*h*w floats
+    int plane_l;                    // floats between plane images in LDS (dense: h*w; bands: a multiple of 256)
+    int in_floats;                  // floats per input buffer (whole 1-KiB pieces)
+    int out_plane_l;                // floats between plane images of the output stage
+    int n_tiles;
+    int vec_out;                    // 16-byte stores are aligned for every tile
+};
+
+typedef __attribute__((address_space(3))) void* pool_lds_ptr_t;
+
+__device__ __forceinline__ void pool_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds = (unsigned)(unsigned long)(pool_lds_ptr_t)dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
+}
+__device__ __forceinline__ void pool_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct Pool3Divs {
+    FastDiv bands, sow, ow;
+};
+
+template <int ST, bool STAGE>
+__global__ __launch_bounds__(kBlock) void maxpool3x3_cols_kernel(Pool3Args a, Pool3Divs dv) {
+    extern __shared__ __attribute__((aligned(1024))) float lds3[];
+    float* const outb = lds3 + 2 * a.in_floats;
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)(tid & 63) * 16u;
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+
+    // input of tile t -> buffer `dst`
+    auto issue = [&](int t, float* dst) {
+        const int pg = (int)fdiv((unsigned)t, dv.bands), b = t - pg * a.n_bands;
+        const int g0 = pg * a.G, gn = min(a.G, a.n_planes - g0);
+        const int oy0 = b * a.band_rows, oy1 = min(a.oh, oy0 + a.band_rows);
+        const int iy_lo = max(0, oy0 * ST - a.pt), iy_hi = min(a.h, (oy1 - 1) * ST + 3 - a.pt);
+        const size_t src = (size_t)g0 * hw + (size_t)iy_lo * a.w;            // floats
+        const unsigned long long left = a.x_bytes - (unsigned long long)src * 4ull;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x + src), 0, (int)(left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left), 0x00020000);
+        if (a.dense) {
+            const int pieces = (gn * hw + 255) >> 8;
+            for (int q = wave; q < pieces; q += 4) pool_dma_b128(r, dst + q * 256, lane16, (unsigned)q * 1024u);
+        } else {
+            const int ppp = ((iy_hi - iy_lo) * a.w + 255) >> 8;               // pieces per plane
+            for (int p = 0; p < gn; ++p)
+                for (int q = wave; q < ppp; q += 4)
+                    pool_dma_b128(r, dst + p * a.plane_l + q * 256, lane16, (unsigned)(p * hw) * 4u + (unsigned)q * 1024u);
+        }
+    };
+
+    int t = blockIdx.x, cur = 0;
+    if (t < a.n_tiles) issue(t, lds3);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        pool_dma_wait();
+        __syncthreads();          // tile t has landed; every wave is done with the other buffer and with the output stage
+        {
+            const int tn = t + (int)gridDim.x;
+            if (tn < a.n_tiles) issue(tn, lds3 + (cur ^ 1) * a.in_floats);
+        }
+        const float* const in = lds3 + cur * a.in_floats;
+        const int pg = (int)fdiv((unsigned)t, dv.bands), b = t - pg * a.n_bands;
+        const int g0 = pg * a.G, gn = min(a.G, a.n_planes - g0);
+        const int oy0 = b * a.band_rows, oy1 = min(a.oh, oy0 + a.band_rows);
+        const int iy_lo = max(0, oy0 * ST - a.pt);
+        const int rows_t = oy1 - oy0;
+        const int seg_rows = (rows_t + a.S - 1) / a.S;
+        const int n_items = gn * a.S * a.ow;
+        const int sow = a.S * a.ow;
+        for (int it = tid; it < n_items; it += kBlock) {
+            const unsigned p = fdiv((unsigned)it, dv.sow), rem = (unsigned)it - p * (unsigned)sow;
+            const unsigned seg = fdiv(rem, dv.ow), ox = rem - seg * (unsigned)a.ow;
+            const int ys = oy0 + (int)seg * seg_rows, ye = min(oy1, ys + seg_rows);
+            if (ys >= oy1) continue;                                          // trailing segment of a short band
+            const int px0 = (int)ox * ST - a.pl;
+            const int c0 = min(max(px0, 0), a.w - 1), c1 = min(max(px0 + 1, 0), a.w - 1), c2 = min(max(px0 + 2, 0), a.w - 1);
+            const bool  zc    = (px0 < 0) || (min((int)ox * ST + 2, a.wp - 1) - a.pl >= a.w);
+            const float flr_c = zc ? 0.0f : -INFINITY;
+            const float* const L = in + (int)p * a.plane_l - iy_lo * a.w;      // input row iy of this plane at L + iy*w
+#define PV_HROW(IY, HV, NV)                                                                   \
+    do {                                                                                      \
+        const int    r_ = min(max((IY), 0), a.h - 1);                                         \
+        const float* q_ = L + r_ * a.w;                                                       \
+        const float  v0_ = q_[c0], v1_ = q_[c1], v2_ = q_[c2];                                \
+        HV = fmaxf(fmaxf(v0_, v1_), v2_);                                                     \
+        NV = __builtin_isunordered(v0_, v1_) | (v2_ != v2_);                                  \
+    } while (0)
+            float hA, hB, hC;
+            bool  nA, nB, nC;
+            PV_HROW(ys * ST - a.pt, hA, nA);
+            if (ST == 1) PV_HROW(ys - a.pt + 1, hB, nB);
+            float* const yo = STAGE ? outb + (int)p * a.out_plane_l + (ys - oy0) * a.ow + (int)ox
+                                    : a.y + (size_t)(g0 + (int)p) * ohw + (size_t)ys * a.ow + ox;
+            for (int oy = ys; oy < ye; ++oy) {
+                if (ST == 2) PV_HROW(oy * 2 - a.pt + 1, hB, nB);
+                PV_HROW(oy * ST - a.pt + 2, hC, nC);
+                float m = fmaxf(fmaxf(hA, hB), hC);
+                const bool zr = (oy * ST < a.pt) || (min(oy * ST + 2, a.hp - 1) - a.pt >= a.h);
+                m = fmaxf(m, zr ? 0.0f : flr_c);
+                yo[(oy - ys) * a.ow] = (nA | nB | nC) ? NAN : m;
+                if (ST == 1) { hA = hB; nA = nB; hB = hC; nB = nC; }
+                else         { hA = hC; nA = nC; }
+            }
+#undef PV_HROW
+        }
+        if (STAGE) {
+            __syncthreads();
+            if (a.dense) {
+                const int n_out = gn * ohw;
+                float* const yd = a.y + (size_t)g0 * ohw;
+                if (a.vec_out) {
+                    const int n4 = n_out >> 2;
+                    for (int i = tid; i < n4; i += kBlock) reinterpret_cast<float4*>(yd)[i] = reinterpret_cast<const float4*>(outb)[i];
+                    for (int i = (n4 << 2) + tid; i < n_out; i += kBlock) yd[i] = outb[i];
+                } else {
+                    for (int i = tid; i < n_out; i += kBlock) yd[i] = outb[i];
+                }
+            } else {
+                const int run = rows_t * a.ow;
+                for (int p = 0; p < gn; ++p) {
+                    float* const       yd = a.y + (size_t)(g0 + p) * ohw + (size_t)oy0 * a.ow;
+                    const float* const so = outb + p * a.out_plane_l;
+                    if (a.vec_out) {
+                        const int n4 = run >> 2;
+                        for (int i = tid; i < n4; i += kBlock) reinterpret_cast<float4*>(yd)[i] = reinterpret_cast<const float4*>(so)[i];
+                        for (int i = (n4 << 2) + tid; i < run; i += kBlock) yd[i] = so[i];
+                    } else {
+                        for (int i = tid; i < run; i += kBlock) yd[i] = so[i];
+                    }
+                }
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// Tile geometry for maxpool3x3_cols_kernel, or false when the shape is not its (the caller falls back).
+// Env overrides for tuning runs: PVHIP_POOL3=0 disables, PVHIP_POOL3_CFG="G,S,band_rows", PVHIP_POOL3_KB (LDS budget
+// of one input buffer), PVHIP_POOL3_STAGE=0 (direct stores), PVHIP_POOL3_WG (workgroups per CU of the persistent grid).
+struct Pool3Plan {
+    Pool3Args a;
+    size_t    lds;
+    int       grid;
+    bool      stage;
+};
+
+bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int oh, int ow, int st, int pt, int pl, int hp, int wp,
+                Pool3Plan& out) {
+    if (pt > 2 || pl > 2 || (oh - 1) * st > pt + h - 1 || (ow - 1) * st > pl + w - 1) return false;   // clamped taps stay in their window
+    if (ow > kBlock || hp < pt + h || wp < pl + w) return false;
+    const int hw = h * w, ohw = oh * ow;
+    size_t budget = 16 * 1024;
+    if (const char* e = getenv("PVHIP_POOL3_KB")) budget = (size_t)atoi(e) * 1024;
+    bool stage = true;
+    if (const char* e = getenv("PVHIP_POOL3_STAGE")) stage = atoi(e) != 0;
+    int G = 0, S = 0, band = 0;
+    bool forced = false;
+    if (const char* e = getenv("PVHIP_POOL3_CFG")) forced = (sscanf(e, "%d,%d,%d", &G, &S, &band) == 3 && G > 0 && S > 0 && band > 0);
+    const bool need4 = (hw % 4 != 0) || (ohw % 4 != 0);      // group starts must stay 16-byte aligned
+    if (!forced) {
+        double best = -1.0;
+        const size_t row_b = (size_t)w * 4;
+        for (int nb = 1; nb <= oh; ++nb) {                    // number of bands
+            const int br = (oh + nb - 1) / nb;
+            if ((oh + br - 1) / br != nb) continue;
+            const int rows_in = (nb == 1) ? h : min(h, (br - 1) * st + 3);
+            if (nb > 1 && (w % 4 != 0)) break;                // band starts must be 16-byte aligned
+            const size_t plane_b = (size_t)rows_in * row_b;
+            if (plane_b > 2 * budget) continue;
+            const double halo_eff = (nb == 1) ? 1.0 : (double)(br * st) / (double)((br - 1) * st + 3);
+            for (int g = 1; g <= 64 && (size_t)g * plane_b <= budget + budget / 2; ++g) {
+                if (g > planes) break;
+                if (need4 && nb == 1 && (g % 4 != 0) && g != planes) continue;
+                if (need4 && nb > 1) continue;
+                for (int s = 1; s <= 8 && s <= br; ++s) {
+                    const int items = g * s * ow;
+                    const int sr = (br + s - 1) / s;
+                    const double util = (double)items / (double)(((items + kBlock - 1) / kBlock) * kBlock);
+                    const double seg_eff = (double)br / (double)(s * sr) * ((double)(sr * st) / (double)(sr * st + 3 - st));
+                    const double size_eff = (double)((size_t)g * plane_b) / (double)((size_t)g * plane_b + 2048);   // per-tile overhead
+                    const double sc = util * seg_eff * halo_eff * size_eff;
+                    if (sc > best) { best = sc; G = g; S = s; band = br; }
+                }
+            }
+            if (nb == 1 && best > 0.0 && (size_t)h * row_b <= budget) break;   // whole planes fit: no bands
+        }
+        if (best < 0.0) return false;
+    }
+    Pool3Args a{};
+    a.x = x; a.y = y; a.n_planes = planes; a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.pt = pt; a.pl = pl; a.hp = hp; a.wp = wp;
+    a.x_bytes = (unsigned long long)planes * hw * 4ull;
+    if (G > planes) G = planes;
+    a.G = G; a.S = S; a.band_rows = band; a.n_bands = (oh + band - 1) / band;
+    a.dense = (a.n_bands == 1);
+    if (!a.dense && (w % 4 != 0 || need4)) return false;
+    if (a.dense && need4 && (G % 4 != 0) && G != planes) return false;
+    const int rows_in = a.dense ? h : min(h, (band - 1) * st + 3);
+    a.plane_l     = a.dense ? hw : ((rows_in * w + 255) & ~255);
+    a.in_floats   = a.dense ? ((G * hw + 255) & ~255) : G * a.plane_l;
+    a.out_plane_l = a.dense ? ohw : band * ow;
+    a.n_tiles     = ((planes + G - 1) / G) * a.n_bands;
+    a.vec_out     = a.dense ? 1 : ((ohw % 4 == 0) && ((band * ow) % 4 == 0));
+    const size_t out_b = stage ? (size_t)((G * a.out_plane_l + 3) & ~3) * 4 : 0;
+    out.lds = (size_t)a.in_floats * 8 + out_b;
+    if (out.lds > 64 * 1024 || G * S * ow <= 0) return false;
+    int per_cu = (int)((size_t)(160 * 1024) / out.lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    if (const char* e = getenv("PVHIP_POOL3_WG")) per_cu = max(1, atoi(e));
+    out.grid  = min(a.n_tiles, per_cu * kNumCU);
+    out.a     = a;
+    out.stage = stage;
+    return true;
+}
+
+// The search above costs tens of microseconds; a forward pass asks for the same few shapes over and over.
+bool plan_pool3(const float* x, float* y, int planes, int h, int w, int oh, int ow, int st, int pt, int pl, int hp, int wp,
+                Pool3Plan& out) {
+    if (const char* e = getenv("PVHIP_POOL3")) if (atoi(e) == 0) return false;
+    struct Entry { int key[10]; bool ok; Pool3Plan plan; };
+    static std::vector<Entry> cache;
+    const int key[10] = {planes, h, w, oh, ow, st, pt, pl, hp, wp};
+    for (const Entry& e : cache)
+        if (memcmp(e.key, key, sizeof key) == 0) {
+            if (!e.ok) return false;
+            out = e.plan; out.a.x = x; out.a.y = y;
+            return true;
+        }
+    Entry e;
+    memcpy(e.key, key, sizeof key);
+    e.ok = plan_pool3_search(x, y, planes, h, w, oh, ow, st, pt, pl, hp, wp, e.plan);
+    if (getenv("PVHIP_POOL3_VERBOSE"))
+        fprintf(stderr, "pool3 planes=%d %dx%d->%dx%d s%d: %s G=%d S=%d band=%d bands=%d tiles=%d lds=%zu grid=%d\n", planes, h, w, oh, ow, st,
+                e.ok ? "ok" : "fallback", e.plan.a.G, e.plan.a.S, e.plan.a.band_rows, e.plan.a.n_bands, e.plan.a.n_tiles, e.plan.lds, e.plan.grid);
+    const bool tuning = getenv("PVHIP_POOL3_CFG") || getenv("PVHIP_POOL3_KB") || getenv("PVHIP_POOL3_WG") || getenv("PVHIP_POOL3_STAGE");
+    if (cache.size() < 256 && !tuning) cache.push_back(e);
+    if (!e.ok) return false;
+    out = e.plan;
+    return true;
+}
+
 
 // AvgPool with the reference's window rule (AvgPool.py:56): rows [oy*sh, min(h-1, oy*sh+kh)),
 // cols [ox*sw, min(w-1, ox*sw+kw)), no padding; mean = sum / count in fp32; empty window -> NaN.
@@ -408,6 +675,22 @@ int pvhip_maxpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
     // every window must start inside the padded extent (numpy would raise on an empty np.max)
     if ((oh - 1) * sh >= a.hp || (ow - 1) * sw >= a.wp)
         return fail(PVHIP_EINVAL, "pvhip_maxpool2d_f32: window starts outside the padded input");
+    if (kh == 3 && kw == 3 && sh == sw && (sh == 1 || sh == 2)) {
+        Pool3Plan pl3;
+        if (plan_pool3(x, y, n * c, h, w, oh, ow, sh, pad_top, pad_left, a.hp, a.wp, pl3)) {
+            Pool3Divs dv3{make_fastdiv((unsigned)pl3.a.n_bands), make_fastdiv((unsigned)(pl3.a.S * ow)), make_fastdiv((unsigned)ow)};
+            const dim3 g3(pl3.grid), b3(kBlock);
+            if (sh == 1) {
+                if (pl3.stage) hipLaunchKernelGGL((maxpool3x3_cols_kernel<1, true>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
+                else           hipLaunchKernelGGL((maxpool3x3_cols_kernel<1, false>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
+            } else {
+                if (pl3.stage) hipLaunchKernelGGL((maxpool3x3_cols_kernel<2, true>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
+                else           hipLaunchKernelGGL((maxpool3x3_cols_kernel<2, false>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
+            }
+            PVHIP_LAUNCH_CHECK();
+            return PVHIP_OK;
+        }
+    }
     // LDS-staged path.  ~16 KB of LDS per workgroup (8-10 workgroups per CU overlap each other's load and
     // compute phases; measured best on the GoogLeNet shapes): several whole planes per workgroup when planes
     // are small, bands of output rows of one plane when a plane is larger than the budget.
