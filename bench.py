@@ -275,8 +275,16 @@ def main():
             if not all_nodes:   # multi-rank run: no per-layer pass, Convolution work from the graph
                 all_nodes = {nid: [net.G.nodes[nid]['type'], net.G.nodes[nid]['name'], 0.0]
                              for nid in work if net.G.nodes[nid]['type'] == 'Convolution'}
-            for nid, (typ, name, ms) in all_nodes.items():
+            for nid, (typ, name, ms) in list(all_nodes.items()):
                 fl, by = work.get(nid, (0.0, 0.0))
+                pooled = getattr(ex, '_lrn_pool', {}).get(nid)
+                if pooled is not None:   # LRN and the MaxPool behind it as one launch: reads the LRN input once, writes the pooled tensor once
+                    typ = 'LRN+MaxPool'
+                    lrn_in = net.G.nodes[nid]['input'][0]['dims']
+                    pool_out = next(iter(net.G.nodes[pooled]['output'].values()))['dims']
+                    by = 4.0 * (int(np.prod(lrn_in)) + int(np.prod(pool_out)))
+                    work[nid] = (0.0, by)
+                    all_nodes[nid] = [typ, name + ' + ' + net.G.nodes[pooled]['name'], ms]
                 agg = by_type.setdefault(typ, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
                 agg['ms'] += ms
                 agg['flops'] += fl

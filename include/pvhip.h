@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   5
+#define PVHIP_ABI_VERSION   6
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -123,6 +123,16 @@ int pvhip_softmax_rows_f32(const float* x, float* y, int rows, int cols);
  * window clipped to [0, C); alpha is NOT divided by size.  hw = H*W.                             */
 int pvhip_lrn_f32(const float* x, float* y, int n, int c, int hw, int size,
                   float alpha, float beta, float bias);
+/* LRN.py:10-22 followed by MaxPool.py:41-72 (3x3 window, stride 1 or 2) as ONE launch: y = maxpool(lrn(x)) with the
+ * arithmetic and the pooling rules of the two entries above (bit-identical to calling them in turn); the LRN tensor is
+ * never written.  x is (n, c, h, w), y is (n, c, oh, ow).  Covers size == 5, beta == 0.75, c % 8 == 0 and bands of
+ * input rows that fit one workgroup; pvhip_lrn_maxpool_supported() (no device needed) tells whether a shape is covered,
+ * the compute entry fails with PVHIP_EUNSUPPORTED otherwise.                                                        */
+int pvhip_lrn_maxpool_supported(int n, int c, int h, int w, int size, float beta, float bias, int oh, int ow,
+                                int kh, int kw, int sh, int sw, int pad_top, int pad_left, int pad_bottom, int pad_right);
+int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, int size, float alpha, float beta,
+                          float bias, int oh, int ow, int kh, int kw, int sh, int sw, int pad_top, int pad_left,
+                          int pad_bottom, int pad_right);
 
 /* ---------------------------------------------------------------- data movement ------------- */
 /* Concat.py:9-13 kernel_Concat_numpy: srcs[i] is viewed as [outer][inner[i]] and copied to

@@ -36,6 +36,24 @@ inline int grid_for(size_t work_items, int per_block = kBlock) {
     return (int)b;
 }
 
+// Division by a run-time-uniform divisor as multiply-high + shift (exact for n < 2^31).
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u, d};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;                       // 2^(s-1) < d <= 2^s
+    const unsigned long long k = 31ull + s;
+    f.mul   = (unsigned)(((1ull << k) + d - 1) / d);   // ceil(2^k / d) in [2^31, 2^32)
+    f.shift = s - 1;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+    return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shift);
+}
+
 // (bias + alpha * sum)^beta of the LRN kernels.  beta_mode: 1 -> d^0.75 as sqrt(d)*sqrt(sqrt(d)) (two correctly
 // rounded roots), 2 -> d^0.5, 3 -> d, 0 -> powf.
 __device__ __forceinline__ float lrn_pow_f(float d, float beta, int beta_mode) {

@@ -141,6 +141,168 @@ __global__ __launch_bounds__(kBlock) void lrn_window_kernel(const float* __restr
 #undef PV_LRN_OUT
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LRN followed by a 3x3 MaxPool (GoogLeNet's conv2/norm2 -> pool2/3x3_s2) in ONE pass over the input: the LRN
+// tensor (1.2 GB of traffic at batch 256: written once, read once) never exists.
+//
+// A workgroup owns one image and a band of pooled rows; its input band (the rows those windows touch, full width)
+// is one dense run per channel plane.  It walks the channel axis exactly like lrn_window_kernel -- one lane owns
+// VEC adjacent pixels of the band, chunks of T = 8 channels, the loads of chunk k+1 in flight while chunk k is
+// normalised, squares summed in ascending channel order -- but the normalised values of a chunk go to LDS ([T][band])
+// instead of HBM, and after a barrier the workgroup pools those T planes (9 LDS reads per output; taps outside the
+// tensor clamped onto a tap inside the same window, max(m, 0) where the window touches zero-pad cells, NaN wins: the
+// rules of maxpool3x3_cols_kernel) and stores T x band_rows x ow outputs.  The LRN arithmetic is lrn_window_kernel's,
+// so the result carries the bits of the two separate launches.
+struct LrnPoolArgs {
+    const float* x;
+    float*       y;
+    int   n, c, h, w, oh, ow;
+    int   pt, pl, hp, wp;
+    int   band_rows, n_bands;
+    int   plane_l;               // floats per normalised plane in LDS
+    float alpha, beta, bias;
+};
+
+template <int SIZE, int VEC, int BETA_MODE, int ST>
+__global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, FastDiv d_bands, FastDiv d_plane, FastDiv d_ow) {
+    constexpr int beta_mode = BETA_MODE;
+    constexpr int HALF = SIZE / 2;
+    constexpr int T    = 8;
+    constexpr int E    = 2 * HALF + T;
+    static_assert(2 * HALF <= T, "window halo must fit in one chunk");
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) float planes[];   // [T][plane_l]
+
+    const int tid = threadIdx.x;
+    const int img = (int)fdiv(blockIdx.x, d_bands), band = (int)blockIdx.x - img * a.n_bands;
+    const int oy0 = band * a.band_rows, oy1 = min(a.oh, oy0 + a.band_rows);
+    const int rows_t = oy1 - oy0;
+    const int iy_lo = max(0, oy0 * ST - a.pt), iy_hi = min(a.h, (oy1 - 1) * ST + 3 - a.pt);
+    const int band_px = (iy_hi - iy_lo) * a.w;
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+    const bool   active  = tid * VEC < band_px;
+    const size_t cstride = (size_t)hw / VEC;
+    const vec_t* __restrict__ xv =
+        reinterpret_cast<const vec_t*>(a.x + (size_t)img * a.c * hw + (size_t)iy_lo * a.w + (active ? tid * VEC : 0));
+    float* const mine = planes + tid * VEC;
+    const int    n_chunks = a.c / T;
+    const int    out_pp   = a.band_rows * a.ow;            // pooled outputs per plane and full band
+
+    // normalise ext[j_ + HALF] with the window ext[j_ .. j_ + SIZE) into LDS plane slot_
+#define PV_LRN_TO_LDS(j_, slot_)                                                               \
+    {                                                                                          \
+        vec_t s_ = ext[(j_)] * ext[(j_)];                                                      \
+        _Pragma("unroll") for (int q = 1; q < SIZE; ++q) s_ = s_ + ext[(j_) + q] * ext[(j_) + q]; \
+        vec_t o_;                                                                              \
+        _Pragma("unroll") for (int v = 0; v < VEC; ++v) {                                      \
+            const float d_ = a.bias + a.alpha * s_[v];                                         \
+            o_[v]          = lrn_div(ext[(j_) + HALF][v], d_, a.beta, beta_mode);              \
+        }                                                                                      \
+        if (active) *reinterpret_cast<vec_t*>(mine + (slot_) * a.plane_l) = o_;                \
+    }
+
+    // pool the first n_pl planes of LDS into channels [ch0, ch0 + n_pl)
+    auto pool = [&](int n_pl, int ch0) {
+        __syncthreads();
+        const int n_out = n_pl * out_pp;
+        for (int o = tid; o < n_out; o += kBlock) {
+            const unsigned p = fdiv((unsigned)o, d_plane), rem = (unsigned)o - p * (unsigned)out_pp;
+            const unsigned oyl = fdiv(rem, d_ow), ox = rem - oyl * (unsigned)a.ow;
+            if ((int)oyl >= rows_t) continue;
+            const int oy = oy0 + (int)oyl;
+            const int py0 = oy * ST - a.pt, px0 = (int)ox * ST - a.pl;
+            const float* const L = planes + (int)p * a.plane_l - iy_lo * a.w;
+            const int c0 = min(max(px0, 0), a.w - 1), c1 = min(max(px0 + 1, 0), a.w - 1), c2 = min(max(px0 + 2, 0), a.w - 1);
+            float m      = -INFINITY;
+            bool  anynan = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float* q  = L + min(max(py0 + k, 0), a.h - 1) * a.w;
+                const float  v0 = q[c0], v1 = q[c1], v2 = q[c2];
+                m      = fmaxf(m, fmaxf(fmaxf(v0, v1), v2));
+                anynan = anynan | __builtin_isunordered(v0, v1) | (v2 != v2);
+            }
+            const bool zc = (px0 < 0) || (min((int)ox * ST + 2, a.wp - 1) - a.pl >= a.w);
+            const bool zr = (py0 < 0) || (min(oy * ST + 2, a.hp - 1) - a.pt >= a.h);
+            if (zc || zr) m = fmaxf(m, 0.0f);
+            a.y[((size_t)img * a.c + ch0 + (int)p) * ohw + (size_t)oy * a.ow + ox] = anynan ? NAN : m;
+        }
+        __syncthreads();
+    };
+
+    vec_t ext[E], nxt[T];
+#pragma unroll
+    for (int j = 0; j < 2 * HALF; ++j) ext[j] = (vec_t)(0.0f);
+#pragma unroll
+    for (int j = 0; j < T; ++j) ext[2 * HALF + j] = xv[(size_t)j * cstride];
+    for (int k = 0; k + 1 < n_chunks; ++k) {
+        const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
+#pragma unroll
+        for (int j = 0; j < T; ++j) nxt[j] = xn[(size_t)j * cstride];
+        if (k == 0) {
+#pragma unroll
+            for (int j = HALF; j < T; ++j) PV_LRN_TO_LDS(j, j - HALF)
+            pool(T - HALF, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) PV_LRN_TO_LDS(j, j)
+            pool(T, k * T - HALF);
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * HALF; ++j) ext[j] = ext[T + j];
+#pragma unroll
+        for (int j = 0; j < T; ++j) ext[2 * HALF + j] = nxt[j];
+    }
+    {
+        const int k = n_chunks - 1;
+        if (k == 0) {
+#pragma unroll
+            for (int j = HALF; j < T; ++j) PV_LRN_TO_LDS(j, j - HALF)
+            pool(T - HALF, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) PV_LRN_TO_LDS(j, j)
+            pool(T, k * T - HALF);
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * HALF; ++j) ext[j] = ext[T + j];
+#pragma unroll
+        for (int j = 0; j < T; ++j) ext[2 * HALF + j] = (vec_t)(0.0f);
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) PV_LRN_TO_LDS(j, j)
+        pool(HALF, a.c - HALF);
+    }
+#undef PV_LRN_TO_LDS
+}
+
+// Geometry of the fused launch, or false when the pair is outside what lrn_maxpool3x3_kernel covers.
+bool plan_lrn_pool(int n, int c, int h, int w, int size, float beta, float bias, int oh, int ow, int kh, int kw, int sh, int sw,
+                   int pt, int pl, int pb, int pr, LrnPoolArgs& a, int& vec, int& bm, size_t& lds) {
+    if (n <= 0 || c < 8 || c % 8 != 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0) return false;
+    if (size != 5 || kh != 3 || kw != 3 || sh != sw || (sh != 1 && sh != 2)) return false;
+    if (pt < 0 || pl < 0 || pb < 0 || pr < 0 || pt > 2 || pl > 2) return false;
+    if ((oh - 1) * sh > pt + h - 1 || (ow - 1) * sw > pl + w - 1) return false;       // clamped taps stay inside their window
+    if ((unsigned long long)n * c * h * w >= (1ull << 31)) return false;
+    bm = lrn_beta_mode(beta, bias);
+    if (bm != 4 && bm != 1) return false;
+    vec = (w % 4 == 0) ? 4 : 1;
+    int rows = (kBlock * vec / w - 3) / sh + 1;                 // largest band whose input rows fit the 256 lanes
+    if (kBlock * vec / w < 3 && h >= 3) return false;
+    if (rows < 1) return false;
+    if (rows > oh) rows = oh;
+    int bands = (oh + rows - 1) / rows;
+    rows  = (oh + bands - 1) / bands;
+    bands = (oh + rows - 1) / rows;
+    int in_rows = (rows - 1) * sh + 3;
+    if (in_rows > h) in_rows = h;
+    if (in_rows * w > kBlock * vec) return false;
+    a.n = n; a.c = c; a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.pt = pt; a.pl = pl; a.hp = h + pt + pb; a.wp = w + pl + pr;
+    a.band_rows = rows; a.n_bands = bands;
+    a.plane_l   = (in_rows * w + 3) & ~3;
+    lds         = (size_t)8 * a.plane_l * sizeof(float);
+    return lds <= 64 * 1024 && (long long)n * bands < (1ll << 31);
+}
+
 // Fallback for window sizes without a register-window instantiation: every lane re-reads its window.
 __global__ __launch_bounds__(kBlock) void lrn_generic_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
                                                               int c, int hw, int size, float alpha, float beta,
@@ -221,6 +383,42 @@ int pvhip_lrn_f32(const float* x, float* y, int n, int c, int hw, int size, floa
             hipLaunchKernelGGL(lrn_generic_kernel, dim3(grid_for((size_t)n * c * hw)), dim3(kBlock), 0, state().stream, x, y,
                                n, c, hw, size, alpha, beta, bias, bm);
     }
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_lrn_maxpool_supported(int n, int c, int h, int w, int size, float beta, float bias, int oh, int ow, int kh, int kw,
+                                int sh, int sw, int pad_top, int pad_left, int pad_bottom, int pad_right) {
+    LrnPoolArgs a{};
+    int vec = 0, bm = 0;
+    size_t lds = 0;
+    return plan_lrn_pool(n, c, h, w, size, beta, bias, oh, ow, kh, kw, sh, sw, pad_top, pad_left, pad_bottom, pad_right, a, vec, bm, lds) ? 1 : 0;
+}
+
+int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, int size, float alpha, float beta, float bias,
+                          int oh, int ow, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int pad_bottom,
+                          int pad_right) {
+    PVHIP_REQUIRE_INIT();
+    LrnPoolArgs a{};
+    int vec = 0, bm = 0;
+    size_t lds = 0;
+    if (!plan_lrn_pool(n, c, h, w, size, beta, bias, oh, ow, kh, kw, sh, sw, pad_top, pad_left, pad_bottom, pad_right, a, vec, bm, lds))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_lrn_maxpool_f32: shape outside the fused kernel (ask pvhip_lrn_maxpool_supported first)");
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+    a.x = x; a.y = y; a.alpha = alpha; a.beta = beta; a.bias = bias;
+    const dim3 grid((unsigned)(n * a.n_bands));
+    const FastDiv d_bands = make_fastdiv((unsigned)a.n_bands), d_plane = make_fastdiv((unsigned)(a.band_rows * ow)),
+                  d_ow = make_fastdiv((unsigned)ow);
+#define PV_LP(VEC_, BM_, ST_) \
+    hipLaunchKernelGGL((lrn_maxpool3x3_kernel<5, VEC_, BM_, ST_>), grid, dim3(kBlock), lds, state().stream, a, d_bands, d_plane, d_ow)
+    if (vec == 4) {
+        if (bm == 4) { if (sh == 1) PV_LP(4, 4, 1); else PV_LP(4, 4, 2); }
+        else         { if (sh == 1) PV_LP(4, 1, 1); else PV_LP(4, 1, 2); }
+    } else {
+        if (bm == 4) { if (sh == 1) PV_LP(1, 4, 1); else PV_LP(1, 4, 2); }
+        else         { if (sh == 1) PV_LP(1, 1, 1); else PV_LP(1, 1, 2); }
+    }
+#undef PV_LP
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -51,24 +51,6 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_kernel(const float* __restri
     }
 }
 
-// Division by a run-time-uniform divisor as multiply-high + shift (exact for n < 2^31).
-struct FastDiv {
-    unsigned mul, shift, d;
-};
-inline FastDiv make_fastdiv(unsigned d) {
-    FastDiv f{0u, 0u, d};
-    if (d <= 1) return f;
-    unsigned s = 0;
-    while ((1ull << s) < d) ++s;                       // 2^(s-1) < d <= 2^s
-    const unsigned long long k = 31ull + s;
-    f.mul   = (unsigned)(((1ull << k) + d - 1) / d);   // ceil(2^k / d) in [2^31, 2^32)
-    f.shift = s - 1;
-    return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
-    return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shift);
-}
-
 struct PoolDivs {
     FastDiv hw, w, ohw, ow;
 };

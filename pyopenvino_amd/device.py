@@ -61,6 +61,8 @@ SIGNATURES = {
     'pvhip_avgpool2d_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 10),
     'pvhip_softmax_rows_f32': (_c.c_int, [_fp, _fp, _c.c_int, _c.c_int]),
     'pvhip_lrn_f32': (_c.c_int, [_fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float]),
+    'pvhip_lrn_maxpool_supported': (_c.c_int, [_c.c_int] * 5 + [_c.c_float, _c.c_float] + [_c.c_int] * 10),
+    'pvhip_lrn_maxpool_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 5 + [_c.c_float] * 3 + [_c.c_int] * 10),
     'pvhip_concat_f32': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _i64p, _fp, _c.c_int64]),
     'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -77,7 +79,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems'}
+_NOT_STATUS = {'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported'}
 
 
 class PvhipError(RuntimeError):

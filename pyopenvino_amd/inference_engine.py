@@ -340,6 +340,7 @@ class Executable_Network:
         self._fusion = {}               # conv node id -> {'bias': const id, 'add': id, 'relu': id or None}
         self._fused_away = set()        # node ids whose compute() is folded into their producer
         self._concat_direct = {}        # Concat node id -> total channels, when every input is written in place
+        self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it
         self._infer_serial = 0
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
         # Independent branches of the graph (the four arms of an inception module) go to separate compute
@@ -417,10 +418,22 @@ class Executable_Network:
         bit-identical to the three launches); the Add and ReLU nodes are not dispatched and their output
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
-        self._fusion, self._fused_away = {}, set()
+        self._fusion, self._fused_away, self._lrn_pool = {}, set(), {}
         if not self.fuse_epilogues:
             return
         G = self.ienet.G
+        # LRN whose only consumer is a MaxPool the fused kernel covers: one launch, the LRN tensor is never written
+        lrn_plugin = self.ienet.ie.plugins.plugins.get('LRN')
+        if lrn_plugin is not None and getattr(lrn_plugin, 'SUPPORTS_FUSED_POOL', False):
+            for lid in G.nodes:
+                if G.nodes[lid]['type'] != 'LRN':
+                    continue
+                succ = list(G.successors(lid))
+                if len(succ) != 1 or G.nodes[succ[0]]['type'] != 'MaxPool' or G.edges[(lid, succ[0])]['connection'][3] != 0:
+                    continue
+                if lrn_plugin.pool_fusable(G.nodes[lid], G.nodes[succ[0]]):
+                    self._lrn_pool[lid] = succ[0]
+                    self._fused_away.add(succ[0])
         conv_plugin = self.ienet.ie.plugins.plugins.get('Convolution')
         if conv_plugin is None or not getattr(conv_plugin, 'SUPPORTS_FUSED_EPILOGUE', False):
             return
@@ -517,6 +530,8 @@ class Executable_Network:
             for nid in (f['add'], f['relu']):
                 if nid is not None:
                     owner[nid] = cid
+        for lid, pid in self._lrn_pool.items():
+            owner[pid] = lid
 
         def producers(nid):
             if nid in self._concat_direct and nid in self._fused_away:
@@ -549,6 +564,8 @@ class Executable_Network:
         position = {t: i for i, t in enumerate(dispatched)}
 
         def tail(task):                  # graph node whose output port carries the tensor the task writes
+            if task in self._lrn_pool:
+                return self._lrn_pool[task]
             f = self._fusion.get(task)
             if f is None:
                 return task
@@ -652,6 +669,11 @@ class Executable_Network:
             else:
                 node.pop('_fuse_bias', None)
                 node.pop('_fuse_act', None)
+            pooled = self._lrn_pool.get(task)
+            if pooled is not None:
+                node['_fuse_pool'] = G.nodes[pooled]
+            else:
+                node.pop('_fuse_pool', None)
             plugin = registry.get(node_type)
             if plugin is None:
                 print("ERROR: Operation '{}' (node={}) is not supported.".format(node_type, node['name']))
@@ -687,6 +709,9 @@ class Executable_Network:
                         if nid is not None:
                             out = G.nodes[nid]['output']
                             out[next(iter(out))]['data'] = fused
+                if pooled is not None:           # the folded MaxPool's port carries the tensor
+                    out = G.nodes[pooled]['output']
+                    out[next(iter(out))]['data'] = next(iter(res.values()))
         if open_run is not None:
             self._close_run(open_run)
         if plan is not None:
@@ -782,14 +807,16 @@ class Executable_Network:
                 chain = [cid, f['add']] + ([f['relu']] if f['relu'] is not None else [])
                 if all(c in needed for c in chain):
                     keep[cid] = dict(f, into=None)      # Concat elimination is not applied to sub-graphs
-            saved = (self._fusion, self._fused_away, self._concat_direct)
+            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool)
             self._fusion = {c: f for c, f in keep.items()}
             self._fused_away = {n for f in self._fusion.values() for n in (f['add'], f['relu']) if n is not None}
             self._concat_direct = {}
+            self._lrn_pool = {l: p_ for l, p_ in self._lrn_pool.items() if l in needed and p_ in needed and l not in targets}
+            self._fused_away |= set(self._lrn_pool.values())
             try:
                 self.run_tasks(False)
             finally:
-                self._fusion, self._fused_away, self._concat_direct = saved
+                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool = saved
         finally:
             self.task_list = full
         out = {}

@@ -4,6 +4,40 @@ import ctypes
 
 from .. import common_def
 from .. import device as dev
+from . import MaxPool
+
+# The engine may hand over an LRN whose only consumer is a 3x3 MaxPool as one call: node['_fuse_pool'] is then the
+# MaxPool's node dict, the kernel pools the normalised values straight out of LDS and the LRN tensor (written once and
+# read once otherwise) never exists; what is returned is the MaxPool's output.  The engine asks pool_fusable() first.
+SUPPORTS_FUSED_POOL = True
+
+
+def _pool_geometry(pool_node: dict, h: int, w: int):
+    attrs = pool_node['data']
+    strides = common_def.string_to_tuple(attrs['strides'])
+    pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
+    pads_end = common_def.string_to_tuple(attrs['pads_end'])
+    kernel = common_def.string_to_tuple(attrs['kernel'])
+    oh, ow = MaxPool.calc_output_shape((h, w), kernel, strides, pads_begin, pads_end, attrs['rounding_type'], attrs['auto_pad'])
+    return kernel, strides, pads_begin, pads_end, oh, ow
+
+
+def pool_fusable(node: dict, pool_node: dict) -> bool:
+    """True when libpvhip's fused LRN -> MaxPool kernel covers this pair (shapes from the IR ports; no device needed)."""
+    try:
+        dims = node['input'][0]['dims']
+        if len(dims) != 4 or pool_node['input'][0]['precision'] != 'FP32':
+            return False
+        n, c, h, w = (int(d) for d in dims)
+        attrs = node['data']
+        kernel, strides, pads_begin, pads_end, oh, ow = _pool_geometry(pool_node, h, w)
+        if len(kernel) != 2 or tuple(pool_node['output'][common_def.first_output_port(pool_node)]['dims']) != (n, c, oh, ow):
+            return False
+        return bool(dev.call('pvhip_lrn_maxpool_supported', n, c, h, w, int(attrs['size']), float(attrs['beta']),
+                             float(attrs['bias']), oh, ow, kernel[0], kernel[1], strides[0], strides[1],
+                             pads_begin[0], pads_begin[1], pads_end[0], pads_end[1]))
+    except (KeyError, ValueError, AssertionError):
+        return False
 
 
 def name():
@@ -21,6 +55,13 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     size = int(attrs['size'])
     x = dev.as_device(inputs[0])
     n, c, h, w = x.shape
+    pool_node = node.get('_fuse_pool')
+    if pool_node is not None:
+        kernel, strides, pads_begin, pads_end, oh, ow = _pool_geometry(pool_node, h, w)
+        y = dev.DeviceTensor.empty((n, c, oh, ow))
+        dev.call('pvhip_lrn_maxpool_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, size, alpha, beta, bias,
+                 oh, ow, kernel[0], kernel[1], strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1])
+        return {common_def.first_output_port(node): y}
     y = dev.DeviceTensor.empty(x.shape)
     dev.call('pvhip_lrn_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h * w, size, alpha, beta, bias)
     return {common_def.first_output_port(node): y}

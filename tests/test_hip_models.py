@@ -131,7 +131,8 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
     x = np.concatenate([synth.uniform_pixels(70 + i, (1, 3, 224, 224)) for i in range(2)], 0)
     _, net_f, ex_f = build_network(HIP, 'googlenet-v1', weights=blob, batch=2)
     _, net_u, ex_u = build_network(HIP, 'googlenet-v1', weights=blob, batch=2, fuse=False)
-    assert len(ex_f._fusion) == 57 and len(ex_f._fused_away) == 114 + 9 and len(ex_f._concat_direct) == 9 and not ex_u._fusion
+    assert len(ex_f._fusion) == 57 and len(ex_f._fused_away) == 114 + 9 + 1 and len(ex_f._concat_direct) == 9 and not ex_u._fusion
+    assert len(ex_f._lrn_pool) == 1 and not ex_u._lrn_pool          # conv2/norm2 -> pool2/3x3_s2 as one launch
     out_f, out_u = infer_one(ex_f, net_f, x), infer_one(ex_u, net_u, x)
     assert np.array_equal(out_f, out_u)
     for cid, f in ex_f._fusion.items():
@@ -140,6 +141,11 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
         assert next(iter(net_f.G.nodes[f['relu']]['output'].values()))['data'] is fused
         if cid in (4, 293):   # first and one late layer (the latter written in place into its Concat): bit for bit
             helpers.assert_bit_exact(np.asarray(fused), np.asarray(relu_u), 'fused conv {}'.format(cid))
+    for lid, pid in ex_f._lrn_pool.items():   # LRN + MaxPool in one launch == the two launches; the MaxPool's port carries the tensor
+        port = next(iter(net_f.G.nodes[pid]['output']))
+        assert net_f.G.nodes[pid]['output'][port]['data'] is next(iter(net_f.G.nodes[lid]['output'].values()))['data']
+        helpers.assert_bit_exact(np.asarray(net_f.G.nodes[pid]['output'][port]['data']),
+                                 np.asarray(net_u.G.nodes[pid]['output'][port]['data']), 'lrn+pool {}'.format(pid))
     for cat in ex_f._concat_direct:   # the inception outputs assembled by their producers == the Concat kernel's result
         port = next(iter(net_f.G.nodes[cat]['output']))
         helpers.assert_bit_exact(np.asarray(net_f.G.nodes[cat]['output'][port]['data']),

@@ -444,6 +444,60 @@ def test_lrn_generic_beta(hip):
     vs_oracle('LRN', [rnd(3, (2, 10, 6, 6), 10.0), np.array([1], dtype=np.int64)], data)
 
 
+LRN_POOL_CASES = [
+    # (x shape, pool stride, pads_begin, pads_end, rounding)
+    ((2, 192, 56, 56), (2, 2), (0, 0), (0, 0), 'ceil'),      # conv2/norm2 -> pool2/3x3_s2: four bands of 7 pooled rows, clipped last window
+    ((1, 16, 9, 12), (1, 1), (1, 1), (1, 1), 'ceil'),        # stride 1, zero pad cells all round
+    ((2, 8, 13, 20), (2, 2), (1, 1), (0, 0), 'floor'),       # one chunk of channels, asymmetric padding
+    ((3, 16, 7, 7), (1, 1), (1, 1), (1, 1), 'ceil'),         # odd width: one pixel per lane
+    ((1, 24, 30, 10), (2, 2), (0, 0), (1, 1), 'ceil'),       # width 10: one pixel per lane, several bands, bottom / right pad cells
+    ((1, 8, 40, 112), (2, 2), (0, 0), (0, 0), 'ceil'),       # wide rows: bands of 3 pooled rows
+]
+
+
+@pytest.mark.parametrize('xs,st,pb,pe,rounding', LRN_POOL_CASES, ids=lambda v: 'x'.join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_fused_lrn_maxpool_has_the_bits_of_the_two_launches(hip, xs, st, pb, pe, rounding):
+    """LRN -> 3x3 MaxPool as one launch (node['_fuse_pool']): the oracle's LRN then MaxPool within the tolerance of
+    the LRN, and bit for bit what the two HIP launches give."""
+    x = rnd(sum(xs), xs, 40.0)
+    x[0, 1, 2, 3] = np.nan if xs[0] == 1 and xs[1] == 16 else x[0, 1, 2, 3]
+    axes = np.array([1], dtype=np.int64)
+    lrn_data = {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'}
+    lrn_node = make_node('LRN', [x, axes], lrn_data)
+    pool_node = make_node('MaxPool', [x], pool_data((3, 3), st, pb, pe, rounding))
+    want_lrn = first_out(oracle_plugin('LRN').compute(lrn_node, {0: x, 1: axes}, kernel_type='special'))
+    want = first_out(oracle_plugin('MaxPool').compute(pool_node, {0: want_lrn}, kernel_type='special'))
+    pool_node['output'][1]['dims'] = tuple(want.shape)
+    lrn_plugin = hip_plugin('LRN')
+    assert lrn_plugin.pool_fusable(lrn_node, pool_node)
+    two_a = lrn_plugin.compute(dict(lrn_node), {0: x, 1: axes})[2]
+    two = first_out(hip_plugin('MaxPool').compute(pool_node, {0: two_a}))
+    fused_node = dict(lrn_node)
+    fused_node['_fuse_pool'] = pool_node
+    got = first_out(lrn_plugin.compute(fused_node, {0: x, 1: axes}))
+    assert_close(got, want, helpers.REL_TOL, 'fused LRN+MaxPool {}'.format(xs))
+    assert_bit_exact(got, two, 'fused LRN+MaxPool vs two launches {}'.format(xs))
+
+
+def test_fused_lrn_maxpool_declines_what_it_does_not_cover(hip):
+    lrn_plugin = hip_plugin('LRN')
+    axes = np.array([1], dtype=np.int64)
+    def pair(xs, size='5', beta='0.75', kernel=(3, 3), st=(2, 2)):
+        x = np.zeros(xs, dtype=np.float32)
+        ln = make_node('LRN', [x, axes], {'alpha': '1e-4', 'beta': beta, 'bias': '1', 'size': size})
+        pn = make_node('MaxPool', [x], pool_data(kernel, st, (0, 0), (0, 0), 'ceil'))
+        oh, ow = hip_plugin('MaxPool').calc_output_shape(xs[2:], kernel, st, (0, 0), (0, 0), 'ceil', 'explicit')
+        pn['output'][1]['dims'] = (xs[0], xs[1], oh, ow)
+        return ln, pn
+    assert lrn_plugin.pool_fusable(*pair((2, 64, 56, 56)))
+    assert not lrn_plugin.pool_fusable(*pair((2, 60, 56, 56)))            # channels not a multiple of 8
+    assert not lrn_plugin.pool_fusable(*pair((2, 64, 56, 56), size='3'))
+    assert not lrn_plugin.pool_fusable(*pair((2, 64, 56, 56), beta='0.6'))
+    assert not lrn_plugin.pool_fusable(*pair((2, 64, 56, 56), kernel=(2, 2)))
+    assert not lrn_plugin.pool_fusable(*pair((2, 64, 56, 56), st=(3, 3)))
+    assert not lrn_plugin.pool_fusable(*pair((1, 8, 5, 2000)))             # three input rows do not fit one workgroup
+
+
 def test_concat_inception_shapes_bit_exact(hip):
     parts = [rnd(i, (3, c, 7, 7)) for i, c in enumerate((384, 384, 128, 128))]
     vs_oracle('Concat', parts, {'axis': '1'})

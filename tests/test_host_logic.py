@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', device.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r' T (pvhip_[a-z0-9_]+)', nm))
     assert declared <= exported
-    assert lib.pvhip_abi_version() == 5
+    assert lib.pvhip_abi_version() == 6
     assert isinstance(lib.pvhip_last_error(), bytes)
 
 
@@ -203,6 +203,8 @@ def test_stream_plan_orders_every_cross_stream_edge():
                     assert position[w] < position[task]
                     assert stream_of[w] == st or (w in waits[task] and w in records), (G.nodes[task]['name'], G.nodes[w]['name'])
         by_name = {G.nodes[n]['name']: n for n in G.nodes}
+        # LRN -> MaxPool pairs the fused kernel covers are one dispatched task (conv2/norm2 -> pool2; pool1 -> norm1 is the other order)
+        assert ex._lrn_pool == ({by_name['conv2/norm26321']: by_name['pool2/3x3_s2']} if fuse else {})
         arms = [by_name['inception_3a/' + a + '/WithoutBiases'] for a in ('1x1', '3x3_reduce', '5x5_reduce')] + [by_name['inception_3a/pool']]
         assert len({stream_of[a] for a in arms}) == 4
         assert stream_of[by_name['inception_3a/3x3/WithoutBiases']] == stream_of[by_name['inception_3a/3x3_reduce/WithoutBiases']]
