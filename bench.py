@@ -274,9 +274,17 @@ def main():
             all_nodes = per_node
             if not all_nodes:   # multi-rank run: no per-layer pass, Convolution work from the graph
                 all_nodes = {nid: [net.G.nodes[nid]['type'], net.G.nodes[nid]['name'], 0.0]
-                             for nid in work if net.G.nodes[nid]['type'] == 'Convolution'}
+                             for nid in work if net.G.nodes[nid]['type'] == 'Convolution' and nid not in ex._fused_away}
             for nid, (typ, name, ms) in list(all_nodes.items()):
                 fl, by = work.get(nid, (0.0, 0.0))
+                sibs = getattr(ex, '_siblings', {}).get(nid)
+                if sibs:                 # convolutions of the same input launched together: all their flops, the input once
+                    in_bytes = 4.0 * int(np.prod(net.G.nodes[nid]['input'][0]['dims']))
+                    for sid in sibs:
+                        sfl, sby = work.get(sid, (0.0, 0.0))
+                        fl, by = fl + sfl, by + sby - in_bytes
+                    work[nid] = (fl, by)
+                    all_nodes[nid] = [typ, name + ' (+{} siblings)'.format(len(sibs)), ms]
                 pooled = getattr(ex, '_lrn_pool', {}).get(nid)
                 if pooled is not None:   # LRN and the MaxPool behind it as one launch: reads the LRN input once, writes the pooled tensor once
                     typ = 'LRN+MaxPool'

@@ -167,6 +167,27 @@ int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
                         const float* bias, int relu,
                         int out_channel_offset, int out_channels_total,
                         float act_lo, float act_hi);
+/* Several Convolution.py:149-176 calls that share their input (the 1x1, 3x3_reduce and 5x5_reduce arms of an inception
+ * module) as ONE launch: the input is read once and the small arms ride in the big one's grid.  Only 1x1 / stride 1 /
+ * unpadded convolutions with c % 16 == 0 (pvhip_conv2d_multi_supported; no device needed).  wpack is the panel of
+ * pvhip_conv2d_pack_f32 for the (k_panel, c, 1, 1) weight tensor that holds the convolutions' OIHW weights one after
+ * the other, each padded with zero rows to a multiple of 32 output channels (k_panel = sum of the padded counts); bias
+ * (k_panel values, optional) and act / act_lo / act_hi as for pvhip_conv2d_f32, shared by all.  dests[i] says where
+ * convolution i stores: y (an (n, k, oh, ow) tensor, or with channels_total > 0 the (n, channels_total, oh, ow) tensor
+ * whose channels [channel_offset, channel_offset + k) it fills).  Every output carries the bits of its own
+ * pvhip_conv2d_f32 call.                                                                                            */
+#define PVHIP_MAX_CONV_DESTS 6
+typedef struct pvhip_conv_dest {
+    float* y;
+    int    k;
+    int    channel_offset;
+    int    channels_total;
+} pvhip_conv_dest;
+int    pvhip_conv2d_multi_supported(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int n_dest);
+int    pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw,
+                              int oh, int ow, int sh, int sw, int pad_top, int pad_left,
+                              const float* bias, int act, float act_lo, float act_hi,
+                              int n_dest, const pvhip_conv_dest* dests);
 
 /* GroupConvolution.py:53-79 kernel_GroupConvolution_numpy, depthwise case only (weights
  * [G,1,1,kh,kw], one input and one output channel per group), applied to every image.  bias / act /

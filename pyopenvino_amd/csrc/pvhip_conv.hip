@@ -31,6 +31,7 @@ constexpr int kBK       = 16;   // reduction rows per stage
 constexpr int kTabSpare   = 2 * kBK;   // padding rows after the gather table (prefetch / unrolled look-ahead)
 constexpr int kPanelSpare = 2 * kBK;   // zero rows after the weight panel
 constexpr int kKoutAlign = 128;  // packed panel width is a multiple of this
+constexpr int kMaxConvDests = PVHIP_MAX_CONV_DESTS;
 
 struct ConvArgs {
     const float* x;
@@ -47,6 +48,15 @@ struct ConvArgs {
     int   relu;             // epilogue activation: 0 none, 1 ReLU (ReLU.py:11), 2 clamp to [act_lo, act_hi] (Clamp.py:11)
     float act_lo, act_hi;
     int y_ctotal, y_coff;   // channels of the tensor y points into, and this convolution's first channel in it
+    // Several convolutions of the same input as one launch (conv_igemm_dma_kernel only): the panel holds their output
+    // channels one after the other, each range padded to whole 32-channel tiles; a tile belongs to one range and stores
+    // into that range's tensor.  nseg == 0: the single destination above.
+    int nseg;
+    struct Seg {
+        float* y;
+        int m_begin, k;     // first panel row of the range, real output channels in it
+        int ctotal, coff;   // as y_ctotal / y_coff
+    } seg[kMaxConvDests];
 };
 
 // One gather element of the im2col tile: returns x[n, c, ih0 + r, iw0 + s] or 0 for a padding cell.
@@ -708,6 +718,13 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
 #undef PV3_LOAD_ENT
 #undef PV3_ADVANCE
 
+    // The destination table is read from the argument block HERE, through a pointer the compiler cannot see through:
+    // as ordinary arguments its 30 dwords would be loaded at kernel entry and held in scalar registers across the
+    // reduction loop, which has none to spare (the LDS-DMA statements need their operands in SGPRs).
+    typedef const __attribute__((address_space(4))) ConvArgs* kernarg_p;
+    kernarg_p ka = (kernarg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const int nseg_l = ka->nseg;
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
                                                                         a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
 #pragma unroll
@@ -722,11 +739,21 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
         if (gp >= a.P) continue;
         const int n   = gp / OHW;
         const int rem = gp - n * OHW;
-        float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff + row0) * OHW + rem;
+        float* __restrict__ yb = a.y;
+        int yct = a.y_ctotal, ycoff = a.y_coff, klim = a.K;
+        if (nseg_l > 0) {                   // the destination range this 32-channel tile belongs to (workgroup-uniform)
+            int sg = 0;
+            for (int q = 1; q < nseg_l; ++q) sg = (m0 + i * 32 >= ka->seg[q].m_begin) ? q : sg;
+            yb    = ka->seg[sg].y;
+            yct   = ka->seg[sg].ctotal;
+            ycoff = ka->seg[sg].coff - ka->seg[sg].m_begin;
+            klim  = ka->seg[sg].m_begin + ka->seg[sg].k;
+        }
+        float* __restrict__ yp = yb + ((size_t)n * yct + ycoff + row0) * OHW + rem;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < a.K) {
+            if (row0 + dr < klim) {
                 float v = acc[i][r];
                 if (a.bias != nullptr) v = v + bv[r];
                 if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
@@ -1031,6 +1058,7 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.act_hi = act_hi;
     a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
+    a.nseg     = 0;
 
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
 
@@ -1109,6 +1137,64 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     else if (bm == 64 && bn == 128) launch_conv<64, 128, 1, 4>(a, n_ptiles);
     else if (bm == 32 && bn == 256) launch_conv<32, 256, 1, 4>(a, n_ptiles);
     else launch_conv<32, 128, 1, 4>(a, n_ptiles);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_conv2d_multi_supported(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int n_dest) {
+    return (n_dest >= 1 && n_dest <= kMaxConvDests && kh == 1 && kw == 1 && sh == 1 && sw == 1 && pad_top == 0 && pad_left == 0 &&
+            rs_major(c, kh, kw)) ? 1 : 0;
+}
+
+int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw, int oh, int ow, int sh,
+                           int sw, int pad_top, int pad_left, const float* bias, int act, float act_lo, float act_hi, int n_dest,
+                           const pvhip_conv_dest* dests) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && oh >= 0 && ow >= 0 && dests != nullptr);
+    if (!pvhip_conv2d_multi_supported(c, kh, kw, sh, sw, pad_top, pad_left, n_dest) || oh != h || ow != w)
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_multi_f32: only 1x1 / stride 1 / unpadded convolutions with C %% 16 == 0 and at most %d destinations",
+                    kMaxConvDests);
+    ConvArgs a;
+    int k_panel = 0;
+    unsigned long long out_max = 0;
+    for (int i = 0; i < n_dest; ++i) {
+        const pvhip_conv_dest& d = dests[i];
+        PVHIP_CHECK_ARG(d.y != nullptr && d.k > 0);
+        PVHIP_CHECK_ARG(d.channels_total == 0 || (d.channel_offset >= 0 && d.channel_offset + d.k <= d.channels_total));
+        a.seg[i].y       = d.y;
+        a.seg[i].m_begin = k_panel;
+        a.seg[i].k       = d.k;
+        a.seg[i].ctotal  = d.channels_total > 0 ? d.channels_total : d.k;
+        a.seg[i].coff    = d.channels_total > 0 ? d.channel_offset : 0;
+        k_panel += round_up_int(d.k, 32);
+        const unsigned long long oe = (unsigned long long)n * a.seg[i].ctotal * oh * ow;
+        if (oe > out_max) out_max = oe;
+    }
+    const unsigned long long in_e = (unsigned long long)n * c * h * w;
+    if (in_e >= (1ull << 29) || out_max >= (1ull << 31))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_multi_f32: input exceeds 2^29 elements or an output 2^31");
+    if (in_e == 0 || oh == 0 || ow == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && wpack != nullptr);
+    a.nseg     = n_dest;
+    a.kred_pad = round_up_int(c, kBK);
+    a.kout_pad = round_up_int(k_panel, kKoutAlign);
+    a.x = x;
+    a.ktab = reinterpret_cast<const int*>(wpack);
+    a.wp   = wpack + 2 * (a.kred_pad + kTabSpare);
+    a.y    = dests[0].y;
+    a.bias = bias;
+    a.N = n; a.C = c; a.H = h; a.W = w; a.K = k_panel; a.OH = oh; a.OW = ow;
+    a.sh = 1; a.sw = 1; a.pt = 0; a.pl = 0; a.kh = 1; a.kw = 1;
+    a.x_bytes = (unsigned)(in_e * 4ull);
+    a.P = n * oh * ow;
+    a.relu = act; a.act_lo = act_lo; a.act_hi = act_hi;
+    a.y_ctotal = a.seg[0].ctotal; a.y_coff = a.seg[0].coff;
+    a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
+    a.n_mtiles = k_panel / 32;
+    const int n_ptiles = (a.P + 127) / 128;
+    const bool pw = (h * w) % 4 == 0;
+    if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+    else    hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -341,6 +341,8 @@ class Executable_Network:
         self._fused_away = set()        # node ids whose compute() is folded into their producer
         self._concat_direct = {}        # Concat node id -> total channels, when every input is written in place
         self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it
+        self._siblings = {}             # Convolution node id -> ids of the convolutions of the same input launched with it
+        self.fuse_siblings = os.environ.get('PVHIP_FUSE_SIBLINGS', '1') != '0'
         self._infer_serial = 0
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
         # Independent branches of the graph (the four arms of an inception module) go to separate compute
@@ -418,7 +420,7 @@ class Executable_Network:
         bit-identical to the three launches); the Add and ReLU nodes are not dispatched and their output
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
-        self._fusion, self._fused_away, self._lrn_pool = {}, set(), {}
+        self._fusion, self._fused_away, self._lrn_pool, self._siblings = {}, set(), {}, {}
         if not self.fuse_epilogues:
             return
         G = self.ienet.G
@@ -497,6 +499,28 @@ class Executable_Network:
             self._concat_direct[nid] = coff
             self._fused_away.add(nid)
 
+        # Third peephole: fused convolution chains that read the SAME tensor with the same geometry and activation (the
+        # 1x1, 3x3_reduce and 5x5_reduce arms of an inception module) are one launch of the first of them in schedule
+        # order: the input is read once and every output-channel tile stores into the tensor of its own convolution
+        # (Convolution.launch_siblings; each output has the bits of its own launch).
+        if self.fuse_siblings and getattr(conv_plugin, 'SUPPORTS_SIBLINGS', False):
+            position = {t: i for i, t in enumerate(self.task_list)}
+            groups = {}
+            for cid, f in self._fusion.items():
+                if G.nodes[cid]['type'] != 'Convolution':
+                    continue
+                src = next((G.edges[(p_, cid)]['connection'][:2] for p_ in G.pred[cid] if G.edges[(p_, cid)]['connection'][3] == 0), None)
+                if src is None or G.nodes[src[0]]['type'] == 'Const':
+                    continue
+                geometry = tuple(G.nodes[cid]['input'][1]['dims'][2:]) + tuple(G.nodes[cid]['data'].get(k_) for k_ in ('strides', 'pads_begin', 'pads_end', 'auto_pad'))
+                groups.setdefault((tuple(src), f['act'], geometry), []).append(cid)
+            for members in groups.values():
+                members.sort(key=position.get)
+                members = members[:6]
+                if len(members) >= 2 and conv_plugin.siblings_fusable([G.nodes[m] for m in members]):
+                    self._siblings[members[0]] = members[1:]
+                    self._fused_away.update(members[1:])
+
     def prepare_inputs_for_task(self, task) -> dict:
         """{sink port: tensor} gathered from the predecessors' output ports, in edge order."""
         G = self.ienet.G
@@ -532,6 +556,11 @@ class Executable_Network:
                     owner[nid] = cid
         for lid, pid in self._lrn_pool.items():
             owner[pid] = lid
+        for lead, sibs in self._siblings.items():
+            for sid in sibs:
+                for nid in (sid, self._fusion[sid]['add'], self._fusion[sid]['relu']):
+                    if nid is not None:
+                        owner[nid] = lead
 
         def producers(nid):
             if nid in self._concat_direct and nid in self._fused_away:
@@ -548,7 +577,9 @@ class Executable_Network:
                 out *= int(d)
             return out
 
-        def cost(task):                  # rough device time of a task in microseconds (ranking only)
+        def cost(task, alone=False):     # rough device time of a task in microseconds (ranking only)
+            if not alone and task in self._siblings:
+                return cost(task, True) + sum(cost(s_, True) for s_ in self._siblings[task])
             node = G.nodes[task]
             out = prod(next(iter(node['output'].values()))['dims']) if node.get('output') else 0
             if node['type'] == 'Convolution':
@@ -601,7 +632,7 @@ class Executable_Network:
                 arm_memo[task] = total
             return arm_memo[task]
 
-        stream_of, waits, records, rank_of, finish = {}, {}, set(), {}, {}
+        stream_of, waits, records, rank_of, finish, width_of = {}, {}, set(), {}, {}, {}
         for task in dispatched:
             preds = sorted(G.pred[task], key=lambda p: G.edges[(p, task)]['connection'][3])
             primary = next((p for p in preds if producers(p)), None)
@@ -610,11 +641,21 @@ class Executable_Network:
                 finish[task] = cost(task)
             else:
                 if primary not in rank_of:           # heaviest arm first; schedule order breaks ties
-                    arms = sorted(consumers(primary), key=lambda t: (-arm_cost(t), position[t]))
-                    rank_of[primary] = {t: j for j, t in enumerate(arms)}
+                    cons, writers_ = consumers(primary), producers(primary)
+                    if len(writers_) == 1 and writers_[0] in self._siblings:
+                        # one launch wrote several tensors: the arms behind ALL of them fan out from its stream
+                        cons = []
+                        for t in [writers_[0]] + list(self._siblings[writers_[0]]):
+                            if not joins(t):         # (a tensor assembled with others is ranked when its last writer is known)
+                                cons += [c for c in consumers(tail(t)) if c not in cons]
+                    arms = sorted(cons, key=lambda t: (-arm_cost(t), position[t]))
+                    # the lighter arms behind a sibling launch skip the streams taken by the arms the launch itself forked with
+                    skip = width_of.get(writers_[0], 1) - 1 if (len(writers_) == 1 and writers_[0] in self._siblings) else 0
+                    rank_of[primary] = {t: (j + skip if j else 0) for j, t in enumerate(arms)}
                 srcs = producers(primary)
                 base = max(srcs, key=lambda p: (finish[p], -position[p]))     # the producer expected to finish last
                 stream_of[task] = (stream_of[base] + rank_of[primary].get(task, 0)) % n
+                width_of[task] = len(rank_of[primary])
                 finish[task] = finish[base] + cost(task)
             deps = []
             for pred in preds:
@@ -669,6 +710,16 @@ class Executable_Network:
             else:
                 node.pop('_fuse_bias', None)
                 node.pop('_fuse_act', None)
+            sibs = self._siblings.get(task)
+            if sibs:
+                node['_siblings'] = []
+                for sid in sibs:
+                    sf = self._fusion[sid]
+                    node['_siblings'].append({'node': G.nodes[sid], 'inputs': self.prepare_inputs_for_task(sid),
+                                              'bias': G.nodes[sf['bias']]['output'][0]['data'],
+                                              'into': (self._concat_buffer(sf['into'][0]), sf['into'][1]) if sf['into'] is not None else None})
+            else:
+                node.pop('_siblings', None)
             pooled = self._lrn_pool.get(task)
             if pooled is not None:
                 node['_fuse_pool'] = G.nodes[pooled]
@@ -709,6 +760,13 @@ class Executable_Network:
                         if nid is not None:
                             out = G.nodes[nid]['output']
                             out[next(iter(out))]['data'] = fused
+                if sibs:                         # the launch wrote the siblings' tensors too
+                    for sid, tensor in zip(sibs, node.pop('_sibling_out')):
+                        chain = [sid, self._fusion[sid]['add'], self._fusion[sid]['relu']]
+                        for nid in chain:
+                            if nid is not None:
+                                out = G.nodes[nid]['output']
+                                out[next(iter(out))]['data'] = tensor
                 if pooled is not None:           # the folded MaxPool's port carries the tensor
                     out = G.nodes[pooled]['output']
                     out[next(iter(out))]['data'] = next(iter(res.values()))
@@ -807,7 +865,8 @@ class Executable_Network:
                 chain = [cid, f['add']] + ([f['relu']] if f['relu'] is not None else [])
                 if all(c in needed for c in chain):
                     keep[cid] = dict(f, into=None)      # Concat elimination is not applied to sub-graphs
-            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool)
+            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings)
+            self._siblings = {}                          # sub-graph runs launch every convolution on its own
             self._fusion = {c: f for c, f in keep.items()}
             self._fused_away = {n for f in self._fusion.values() for n in (f['add'], f['relu']) if n is not None}
             self._concat_direct = {}
@@ -816,7 +875,7 @@ class Executable_Network:
             try:
                 self.run_tasks(False)
             finally:
-                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool = saved
+                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings = saved
         finally:
             self.task_list = full
         out = {}

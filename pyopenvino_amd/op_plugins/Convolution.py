@@ -15,6 +15,11 @@ from .. import device as dev
 # (tensor, channel offset) makes the kernel write its channels straight into the output of the channel Concat
 # that consumes it.
 SUPPORTS_FUSED_EPILOGUE = True
+# Convolutions that read the same tensor (the 1x1 / 3x3_reduce / 5x5_reduce arms of an inception module) may be handed
+# over as ONE call: node['_siblings'] = [{'node', 'inputs', 'bias', 'into'}, ...] lists the others (same attributes,
+# same activation); the input is then read once, by one launch whose output-channel tiles store into the tensor of the
+# convolution they belong to.  The siblings' outputs are left in node['_sibling_out'], in the same order.
+SUPPORTS_SIBLINGS = True
 
 
 def name():
@@ -72,6 +77,90 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     return y
 
 
+def siblings_fusable(nodes) -> bool:
+    """True when libpvhip's multi-destination launch covers these Convolution nodes (IR port dims; no device needed)."""
+    try:
+        if not 2 <= len(nodes) <= dev.MAX_CONV_DESTS:
+            return False
+        first = nodes[0]
+        for node in nodes:
+            attrs, wd, xd = node['data'], node['input'][1]['dims'], node['input'][0]['dims']
+            if len(xd) != 4 or len(wd) != 4 or tuple(xd) != tuple(first['input'][0]['dims']):
+                return False
+            same = all(common_def.string_to_tuple(attrs[key]) == common_def.string_to_tuple(first['data'][key])
+                       for key in ('strides', 'pads_begin', 'pads_end'))
+            if not same or attrs['auto_pad'] != first['data']['auto_pad'] or attrs['auto_pad'] not in ('explicit', 'valid'):
+                return False
+            st, pb, pe = (common_def.string_to_tuple(attrs[key]) for key in ('strides', 'pads_begin', 'pads_end'))
+            if tuple(pe) != (0, 0) or wd[1] != xd[1]:
+                return False
+            if not dev.call('pvhip_conv2d_multi_supported', int(xd[1]), int(wd[2]), int(wd[3]), st[0], st[1], pb[0], pb[1], len(nodes)):
+                return False
+        return True
+    except (KeyError, ValueError, AssertionError):
+        return False
+
+
+def fused_panel(node: dict, ws, biases, h: int, wd: int):
+    """(packed panel, fused bias or None, padded channel counts) of the siblings' weights laid one after the other, each
+    padded to whole 32-channel tiles; built once and kept on the leading node."""
+    key = tuple(w._block for w in ws) + tuple(b._block if b is not None else None for b in biases) + (h, wd)
+    cached = node.get('_hip_sibpack')
+    if cached is not None and len(cached[0]) == len(key) and all(a is b for a, b in zip(cached[0], key)):
+        return cached[1]
+    c = ws[0].shape[1]
+    pads = [-(-w.shape[0] // 32) * 32 for w in ws]
+    host_w = np.zeros((sum(pads), c, 1, 1), dtype=np.float32)
+    host_b = np.zeros((sum(pads),), dtype=np.float32)
+    row = 0
+    for w, b, kp in zip(ws, biases, pads):
+        host_w[row:row + w.shape[0]] = w.numpy()
+        if b is not None:
+            host_b[row:row + w.shape[0]] = b.numpy().reshape(-1)
+        row += kp
+    wf = dev.DeviceTensor.from_numpy(host_w)
+    elems = dev.call('pvhip_conv2d_pack_elems', host_w.shape[0], c, 1, 1)
+    wpack = dev.DeviceTensor.empty((int(elems),))
+    dev.call('pvhip_conv2d_pack_f32', ctypes.c_void_p(wf.ptr), ctypes.c_void_p(wpack.ptr), host_w.shape[0], c, 1, 1, h, wd)
+    bias = dev.DeviceTensor.from_numpy(host_b) if any(b is not None for b in biases) else None
+    packed = (wpack, bias, pads)
+    node['_hip_sibpack'] = (key, packed)
+    return packed
+
+
+def launch_siblings(node, x, members, strides, pads_begin, act):
+    """members: [(weights, bias or None, into or None)], the node's own convolution first.  -> list of outputs."""
+    n, c, h, wd = x.shape
+    ws = [m[0] for m in members]
+    for w in ws:
+        if w.shape[1] != c or tuple(w.shape[2:]) != (1, 1):
+            raise ValueError('sibling convolutions must be 1x1 over the same {} channels, got {}'.format(c, w.shape))
+    wpack, bias, _ = fused_panel(node, ws, [m[1] for m in members], h, wd)
+    act_code, act_lo, act_hi = 0, 0.0, 0.0
+    if act is not None:
+        act_code = 1 if act[0] == 'relu' else 2
+        if act_code == 2:
+            act_lo, act_hi = float(act[1]), float(act[2])
+    dests = (dev.ConvDest * len(members))()
+    outs, keep = [], []
+    for i, (w, _, into) in enumerate(members):
+        kn = w.shape[0]
+        if into is None:
+            target, coff, ctotal = dev.DeviceTensor.empty((n, kn, h, wd)), 0, 0
+            outs.append(target)
+        else:
+            target, coff = into
+            ctotal = target.shape[1]
+            assert target.shape[0] == n and tuple(target.shape[2:]) == (h, wd) and coff + kn <= ctotal
+            outs.append(dev.ChannelSlice(target, coff, kn))
+        keep.append(target)
+        dests[i].y, dests[i].k, dests[i].channel_offset, dests[i].channels_total = target.ptr, kn, int(coff), int(ctotal)
+    dev.call('pvhip_conv2d_multi_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), n, c, h, wd, 1, 1, h, wd,
+             strides[0], strides[1], pads_begin[0], pads_begin[1], ctypes.c_void_p(bias.ptr if bias is not None else 0),
+             act_code, act_lo, act_hi, len(members), ctypes.cast(dests, ctypes.c_void_p))
+    return outs
+
+
 def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bool = False):
     if debug:
         print(node)
@@ -88,8 +177,18 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     if bias is not None:
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
-    y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'),
-               into=node.get('_out_into'))
+    siblings = node.get('_siblings')
+    if siblings:
+        members = [(w, bias, node.get('_out_into'))]
+        for sib in siblings:
+            common_def.validate_inputs(sib['node'], sib['inputs'])
+            sb = sib.get('bias')
+            members.append((dev.as_device(sib['inputs'][1]), dev.as_device(sb) if sb is not None else None, sib.get('into')))
+        outs = launch_siblings(node, x, members, strides, pads_begin, node.get('_fuse_act'))
+        y, node['_sibling_out'] = outs[0], outs[1:]
+    else:
+        y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'),
+                   into=node.get('_out_into'))
     port = common_def.first_output_port(node)
     assert common_def.type_convert_tbl[node['output'][port]['precision']] == np.float32
     return {port: y}

@@ -444,6 +444,54 @@ def test_lrn_generic_beta(hip):
     vs_oracle('LRN', [rnd(3, (2, 10, 6, 6), 10.0), np.array([1], dtype=np.int64)], data)
 
 
+@pytest.mark.parametrize('xs,ks', [((3, 192, 28, 28), (64, 96, 16)), ((2, 512, 14, 14), (160, 112, 24)), ((5, 832, 7, 7), (384, 192, 48)),
+                                   ((2, 32, 5, 9), (40, 8))])
+def test_sibling_convolutions_as_one_launch_are_bit_identical(hip, xs, ks):
+    """The 1x1 / 3x3_reduce / 5x5_reduce arms of an inception module (same input) handed over as one call
+    (node['_siblings']): every output has the bits of its own launch, including one written in place into a wider
+    (Concat) tensor, and matches the oracle."""
+    from pyopenvino_amd import device as dev
+    plugin = hip_plugin('Convolution')
+    x = rnd(11, xs)
+    data = conv_data((1, 1), (0, 0), (0, 0))
+    ws = [rnd(20 + i, (k, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5) for i, k in enumerate(ks)]
+    bs = [rnd(40 + i, (1, k, 1, 1), 0.1) for i, k in enumerate(ks)]
+    nodes = [make_node('Convolution', [x, w], data) for w in ws]
+    assert plugin.siblings_fusable(nodes)
+    alone = []
+    for node, w, b in zip(nodes, ws, bs):
+        nd = dict(node)
+        nd['_fuse_bias'], nd['_fuse_act'] = dev.DeviceTensor.from_numpy(b), ('relu',)
+        alone.append(first_out(plugin.compute(nd, {0: x, 1: w})))
+        want = np.maximum(first_out(oracle_plugin('Convolution').compute(node, {0: x, 1: w}, kernel_type='special')) + b, 0)
+        assert_close(alone[-1], want, helpers.REL_TOL, 'conv {}'.format(w.shape))
+    wide = dev.DeviceTensor.from_numpy(np.full((xs[0], ks[0] + 7, xs[2], xs[3]), -1.0, dtype=np.float32))
+    lead = dict(nodes[0])
+    lead['_fuse_bias'], lead['_fuse_act'], lead['_out_into'] = dev.DeviceTensor.from_numpy(bs[0]), ('relu',), (wide, 3)
+    lead['_siblings'] = [{'node': n_, 'inputs': {0: x, 1: w}, 'bias': dev.DeviceTensor.from_numpy(b), 'into': None}
+                         for n_, w, b in zip(nodes[1:], ws[1:], bs[1:])]
+    plugin.compute(lead, {0: x, 1: ws[0]})
+    got = [np.asarray(wide)[:, 3:3 + ks[0]]] + [np.asarray(t) for t in lead['_sibling_out']]
+    for g, a, k in zip(got, alone, ks):
+        assert_bit_exact(np.ascontiguousarray(g), a, 'sibling with {} channels'.format(k))
+    rest = np.asarray(wide)
+    assert np.all(rest[:, :3] == -1.0) and np.all(rest[:, 3 + ks[0]:] == -1.0)       # neighbours in the wider tensor untouched
+
+
+def test_sibling_convolutions_decline_other_geometries(hip):
+    plugin = hip_plugin('Convolution')
+    x = np.zeros((1, 32, 8, 8), dtype=np.float32)
+    one = lambda k, kk=1, data=None: make_node('Convolution', [x, np.zeros((k, 32, kk, kk), dtype=np.float32)], data or conv_data((1, 1), (0, 0), (0, 0)))
+    assert plugin.siblings_fusable([one(8), one(40)])
+    assert not plugin.siblings_fusable([one(8)])
+    assert not plugin.siblings_fusable([one(8), one(8, 3)])
+    assert not plugin.siblings_fusable([one(8), one(8, data=conv_data((2, 2), (0, 0), (0, 0)))])
+    assert not plugin.siblings_fusable([one(8)] * 7)
+    x24 = np.zeros((1, 24, 8, 8), dtype=np.float32)
+    odd = [make_node('Convolution', [x24, np.zeros((8, 24, 1, 1), dtype=np.float32)], conv_data((1, 1), (0, 0), (0, 0)))] * 2
+    assert not plugin.siblings_fusable(odd)                                           # 24 channels: not whole 16-row stages
+
+
 LRN_POOL_CASES = [
     # (x shape, pool stride, pads_begin, pads_end, rounding)
     ((2, 192, 56, 56), (2, 2), (0, 0), (0, 0), 'ceil'),      # conv2/norm2 -> pool2/3x3_s2: four bands of 7 pooled rows, clipped last window
