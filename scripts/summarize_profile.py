@@ -30,6 +30,10 @@ def main():
           'kernels of different passes overlapping) is summarised at the end.', '']
     stats = find(os.path.join(raw, 'stats'), '*kernel_stats.csv')
     conv_total_ns = conv_calls = 0
+    per_pass = 57                      # convolution launches per forward pass (bench.py says how many after fusion)
+    line = os.path.join(raw, 'bench_line_under_profiler.json')
+    if os.path.isfile(line) and os.path.getsize(line):
+        per_pass = int(json.loads(open(line).read())['roofline'].get('launches_per_step', per_pass))
     if stats:
         rows = list(csv.DictReader(open(stats)))
         with open(os.path.join(prof, tag + '_kernel_stats.csv'), 'w') as f:
@@ -45,13 +49,13 @@ def main():
                 conv_calls += int(r['Calls'])
         if conv_calls:
             md += ['', '**conv_wino_kernel + conv_igemm_dma_kernel (+ conv_igemm_kernel), all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
-                   '({:.3f} ms per forward pass of 57 launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
-                                                                         conv_total_ns / conv_calls * 57 / 1e6)]
+                   '({:.3f} ms per forward pass of {} launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
+                                                                         conv_total_ns / conv_calls * per_pass / 1e6, per_pass)]
     trace = find(os.path.join(raw, 'stats'), '*kernel_trace.csv')
     if trace and conv_calls:
         conv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(trace)) if 'conv_igemm' in r['Kernel_Name'] or 'conv_wino' in r['Kernel_Name'])
-        tail_ = conv[-5 * 57:]
-        head_ = conv[:3 * 57]
+        tail_ = conv[-5 * per_pass:]
+        head_ = conv[:3 * per_pass]
         md += ['', 'From the kernel trace of the same run: the first 3 forward passes (clocks ramping up from idle, cold caches) average {:.2f} us '
                'per convolution launch, the LAST 5 passes **{:.2f} us** -- the steady state the timed region of bench.py sees.'.format(
                    sum(e - b for b, e in head_) / len(head_) / 1e3, sum(e - b for b, e in tail_) / len(tail_) / 1e3)]
