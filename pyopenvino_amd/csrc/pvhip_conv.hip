@@ -1002,7 +1002,7 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     const size_t kred_pad = (size_t)round_up_int(c * kh * kw, kBK);
     const size_t kout_pad = (size_t)round_up_int(k_out, kKoutAlign);
     size_t elems = 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
-    if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c);   // 3x3: the Winograd-transformed panel rides along (stride / pad are not known yet)
+    if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c) + wino4_pack_elems(k_out, c);   // 3x3: the Winograd-transformed panels ride along (stride / pad are not known yet)
     return elems;
 }
 
@@ -1018,8 +1018,13 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kPanelSpare) * kout_pad)), dim3(kBlock), 0, state().stream,
                        w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad, rs_major(c, kh, kw) ? 1 : 0);
     if (kh == 3 && kw == 3 && wino_pack_elems(k_out, c) > 0) {
-        const int rc = wino_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out, c);
+        float* const u2 = wp + (size_t)(kred_pad + kPanelSpare) * kout_pad;
+        int rc = wino_pack(w_oihw, u2, k_out, c);
         if (rc) return rc;
+        if (h % 4 == 0 && w % 4 == 0) {       // the F(4x4, 3x3) panel behind it (whether it is used depends on the batch too)
+            rc = wino4_pack(w_oihw, u2 + wino_pack_elems(k_out, c), k_out, c);
+            if (rc) return rc;
+        }
     }
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
@@ -1063,6 +1068,13 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
 
     // ---- 3x3 / stride 1 / same padding: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (pvhip_wino.hip)
+    if (wino4_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) {
+        const int rc = wino4_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad + wino_pack_elems(k_out, c), y, n, c, h, w,
+                                  k_out, bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
+        if (rc) return rc;
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
     if (wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
         const int rc = wino_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, c, h, w, k_out, bias, relu, act_lo,
                                  act_hi, a.y_coff, a.y_ctotal);

@@ -11,4 +11,12 @@ int    wino_pack(const float* w_oihw, float* u, int k, int c);       // enqueue 
 int    wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
                  float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
 
+// F(4x4, 3x3): additionally H and W multiples of 4 and enough patches to fill the chip (PVHIP_CONV_WINOGRAD4=0 switches it off,
+// =force drops the size rule)
+bool   wino4_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n);
+size_t wino4_pack_elems(int k, int c);
+int    wino4_pack(const float* w_oihw, float* u, int k, int c);
+int    wino4_conv(const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
+                  float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
+
 }  // namespace pvhip

@@ -308,6 +308,324 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// F(4x4, 3x3): every 4x4 patch of outputs from the 6x6 input patch around it, 36 multiplies per channel and patch
+// instead of 144 -- 4x fewer matrix-core operations than the direct sum, 1.78x fewer than F(2x2, 3x3).  Used for the
+// layers whose extents are multiples of 4 and large enough to fill the chip (conv2/3x3 at 56x56, the 28x28 inception
+// layers).  fp32 throughout; the transforms have coefficients up to 8 and 1/24, so the result differs from the direct
+// sum at the 4e-6 level of the output's maximum (F(2x2): 3e-7; stated tolerance of the path 1e-4).
+//
+//   * U[xi][c][k] = (G g G^T)[xi], xi = 6*i + j, packed per (block of 32 output channels, stage of 4 input channels)
+//     as the dense [36][4][32] image the kernel stages by LDS-DMA.
+//   * A workgroup of 8 waves owns 32 output channels x 32 patches (= 512 output pixels).  Waves 0-5 are CONSUMERS:
+//     wave i holds the six accumulator tiles D_xi[k][patch], xi = 6*i .. 6*i+5, and issues 12 MFMAs per stage.  Waves
+//     6-7 are PRODUCERS: lane <-> (patch, channel of the stage); they gather the 6x6 patch (36 buffer loads, out-of-range
+//     sentinels for the rows in the padding, the two border columns zeroed by select), keep TWO stages of gathers in
+//     flight, transform V = B^T d B in registers (144 fused multiply-adds) and write V[xi][c][patch] to LDS.  The
+//     producers hold no accumulators and the consumers no patches, so the kernel needs 128 registers, not 200.
+//   * Epilogue: each consumer applies the column half of Y = A^T D A to its row in registers; the rows meet in LDS
+//     (16 channels at a time), then bias / activation and four 16-byte stores per (channel, patch).
+constexpr int kXi4 = 36;
+
+__global__ __launch_bounds__(kBlock) void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int K, int C,
+                                                             int n_stages) {
+    constexpr int KB = 32;
+    const int kUStage = kXi4 * kCB * KB;
+    const int total = ((K + KB - 1) / KB) * KB * C;
+    const float G[6][3] = {{0.25f, 0.0f, 0.0f},
+                           {-1.0f / 6.0f, -1.0f / 6.0f, -1.0f / 6.0f},
+                           {-1.0f / 6.0f, 1.0f / 6.0f, -1.0f / 6.0f},
+                           {1.0f / 24.0f, 1.0f / 12.0f, 1.0f / 6.0f},
+                           {1.0f / 24.0f, -1.0f / 12.0f, 1.0f / 6.0f},
+                           {0.0f, 0.0f, 1.0f}};
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int k = e / C, c = e - k * C;
+        float g[3][3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = (k < K) ? w[((size_t)k * C + c) * 9 + i] : 0.0f;
+        float r[6][3];                       // G g
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r[i][q] = G[i][0] * g[0][q] + G[i][1] * g[1][q] + G[i][2] * g[2][q];
+        const int kb = k / KB, kl = k % KB, st = c / kCB, cl = c % kCB;
+        float* up = u + ((size_t)kb * (n_stages + 1) + st) * kUStage + cl * KB + kl;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                up[(i * 6 + j) * kCB * KB] = r[i][0] * G[j][0] + r[i][1] * G[j][1] + r[i][2] * G[j][2];
+    }
+}
+
+// One 6-vector through B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]]
+__device__ __forceinline__ void wino4_bt(float d0, float d1, float d2, float d3, float d4, float d5, float& o0, float& o1,
+                                         float& o2, float& o3, float& o4, float& o5) {
+    o0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+    const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
+    o1 = a + b;
+    o2 = a - b;
+    const float e = d4 - d2, f = d3 - d1;
+    o3 = __builtin_fmaf(2.0f, f, e);
+    o4 = __builtin_fmaf(-2.0f, f, e);
+    o5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+}
+
+// One 6-vector through A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
+__device__ __forceinline__ void wino4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& o0, float& o1,
+                                         float& o2, float& o3) {
+    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    o0 = (m0 + s12) + s34;
+    o1 = __builtin_fmaf(2.0f, d34, d12);
+    o2 = __builtin_fmaf(4.0f, s34, s12);
+    o3 = __builtin_fmaf(8.0f, d34, d12) + m5;
+}
+
+template <int ABL>   // diagnostic ablations (wrong results on purpose): 1 no gather, 2 no transform, 3 no MFMA, 4 no U DMA, 5 no V store
+__global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
+    constexpr int KB = 32, NT = 32, WAVES = 8, CONSUMERS = 6;
+    constexpr unsigned kOob = 0x80000000u;
+    constexpr int U_PIECES = kXi4 * kCB * KB * 4 / 1024;      // 18 one-KiB pieces per U stage image
+    struct Stage {
+        float Us[2][kXi4][kCB][KB];
+        float Vs[2][kXi4][kCB][NT];
+    };
+    __shared__ __attribute__((aligned(1024))) Stage sm;
+    static_assert(sizeof(Stage) == 72 * 1024, "72 KB of LDS: two workgroups per CU");
+    auto& Us = sm.Us;
+    auto& Vs = sm.Vs;
+
+    const int nwg = gridDim.x;
+    int       lid;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int kb = lid % a.n_kb;
+    const int tb = lid / a.n_kb;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW   = a.H * a.W;
+    const int TPI  = a.TY * a.TX;
+    const unsigned chan_bytes = (unsigned)HW * 4u;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    constexpr unsigned u_stage_bytes = (unsigned)kXi4 * kCB * KB * 4u;
+    const unsigned u_base = (unsigned)(kb * (a.n_stages + 1)) * u_stage_bytes;
+    const unsigned u_lane = (unsigned)lane * 16u;
+
+#define PVW4_LOAD_U(s_, buf_)                                                                                   \
+    {                                                                                                           \
+        const unsigned soff = u_base + (unsigned)(s_) * u_stage_bytes;                                           \
+        _Pragma("unroll") for (int q = 0; q < (U_PIECES + WAVES - 1) / WAVES; ++q)                               \
+            if (ABL != 4 && wid + WAVES * q < U_PIECES)                                                          \
+                wino_dma_b128(ur, &Us[buf_][0][0][0] + (wid + WAVES * q) * 256, u_lane + (unsigned)(wid + WAVES * q) * 1024u, soff); \
+    }
+
+    floatx16 acc[6];
+    if (wid >= CONSUMERS) {
+        // ------------------------------------------------------------------ producers
+        const int g_chan = (wid - CONSUMERS) * 2 + lh;                // channel inside the stage
+        // Lane <-> (patch, channel of the stage).  Columns 1..4 of a patch row are ONE aligned 16-byte load (extents are
+        // multiples of 4; consecutive lanes = consecutive patches = consecutive 16-byte pieces: fully coalesced).  Column 0 is
+        // the left neighbour's column 4 and column 5 the right neighbour's column 1: they come from the adjacent lane by DPP
+        // (wave_shr / wave_shl) when the transform runs, so a stage in flight holds 24 registers, not 36; only the first
+        // and the last lane of a 32-patch row load their outer column themselves (one more dword load per row, two active
+        // lanes per half).  A row in the padding gets an out-of-range offset (the hardware returns 0); columns in the
+        // padding (first / last patch column) are zeroed by select.
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        typedef float    float4v __attribute__((ext_vector_type(4)));
+        unsigned rowo[6];                 // byte offset of (row, column 1) of this lane's channel
+        unsigned eoff;                    // edge lanes: byte distance of their outer column from column 1
+        bool     zlo, zhi;
+        const bool first = l31 == 0, last = l31 == 31;
+        {
+            const int  t    = tb * NT + l31;
+            const bool live = t < a.T;
+            const int  n = live ? t / TPI : 0, rem = live ? t - n * TPI : 0;
+            const int  ty = rem / a.TX, tx = rem - ty * a.TX;
+            const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + 4 * tx) * 4u;
+            zlo = tx == 0;
+            zhi = tx == a.TX - 1;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int iy = 4 * ty - 1 + r;
+                rowo[r] = (live && (unsigned)iy < (unsigned)a.H) ? base + (unsigned)(iy * a.W) * 4u : kOob + 16u;
+            }
+            // first lane: column 0 (4 bytes before column 1; on the left border the value is zeroed anyway: stay in place);
+            // last lane: column 5 (16 bytes after; on the right border: 12); other lanes: the load is masked off
+            eoff = first ? (zlo ? 0u : 0xFFFFFFFCu) : (zhi ? 12u : 16u);
+        }
+        float4v vA[6], vB[6];
+        float   eA[6], eB[6];
+#define PVW4_GATHER(v_, e_, s_)                                                                                  \
+    {                                                                                                            \
+        const int se_ = (s_) < a.n_stages ? (s_) : a.n_stages - 1;     /* past the end: the last stage again (unused) */ \
+        const unsigned soff = (unsigned)(se_ * kCB) * chan_bytes;                                                \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
+            if (ABL == 1) {                                                                                      \
+                v_[r] = (float4v)(__builtin_bit_cast(float, rowo[r] + soff));                                    \
+                e_[r] = 0.0f;                                                                                    \
+            } else {                                                                                             \
+                /* the WHOLE vector is cast: hipcc (ROCm 7.2) lowers a b128 load whose lanes are cast one by one to a dword load */ \
+                v_[r] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(xr, rowo[r], soff, 0)); \
+                e_[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (first || last) ? rowo[r] + eoff : kOob, soff, 0)); \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+#define PVW4_TRANSFORM_STORE(v_, e_, buf_)                                                                       \
+    {                                                                                                            \
+        float m[36];                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) {                 /* columns: m = B^T d */                  \
+            float c[6];                                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                      \
+                if (q == 0) {            /* left neighbour's column 4 (wave_shr:1), own load in the first lane */ \
+                    float src_ = v_[r].w;        /* opaque FLOAT copy first: an integer cast of the element folds back into */ \
+                    asm volatile("" : "+v"(src_));  /* "element of the loaded <4 x i32>", which hipcc lowers to element 0     */ \
+                    const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x138, 0xf, 0xf, false)); \
+                    c[r] = zlo ? 0.0f : (first ? e_[r] : nb);                                                    \
+                } else if (q == 5) {     /* right neighbour's column 1 (wave_shl:1), own load in the last lane */ \
+                    float src_ = v_[r].x;                                                                        \
+                    asm volatile("" : "+v"(src_));                                                               \
+                    const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x130, 0xf, 0xf, false)); \
+                    c[r] = zhi ? 0.0f : (last ? e_[r] : nb);                                                     \
+                } else {                                                                                         \
+                    c[r] = q == 1 ? v_[r].x : (q == 2 ? v_[r].y : (q == 3 ? v_[r].z : v_[r].w));                 \
+                }                                                                                                \
+            }                                                                                                    \
+            if (ABL == 2) { _Pragma("unroll") for (int r = 0; r < 6; ++r) m[r * 6 + q] = c[r]; }                 \
+            else wino4_bt(c[0], c[1], c[2], c[3], c[4], c[5], m[0 * 6 + q], m[1 * 6 + q], m[2 * 6 + q], m[3 * 6 + q], m[4 * 6 + q], m[5 * 6 + q]); \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                 /* rows: V = m B */                       \
+            float v0, v1, v2, v3, v4, v5;                                                                        \
+            if (ABL == 2) { v0 = m[i * 6 + 0]; v1 = m[i * 6 + 1]; v2 = m[i * 6 + 2]; v3 = m[i * 6 + 3]; v4 = m[i * 6 + 4]; v5 = m[i * 6 + 5]; } \
+            else wino4_bt(m[i * 6 + 0], m[i * 6 + 1], m[i * 6 + 2], m[i * 6 + 3], m[i * 6 + 4], m[i * 6 + 5], v0, v1, v2, v3, v4, v5); \
+            Vs[buf_][i * 6 + 0][g_chan][l31] = v0;                                                               \
+            Vs[buf_][i * 6 + 1][g_chan][l31] = v1;                                                               \
+            Vs[buf_][i * 6 + 2][g_chan][l31] = v2;                                                               \
+            Vs[buf_][i * 6 + 3][g_chan][l31] = v3;                                                               \
+            Vs[buf_][i * 6 + 4][g_chan][l31] = v4;                                                               \
+            Vs[buf_][i * 6 + 5][g_chan][l31] = v5;                                                               \
+        }                                                                                                        \
+    }
+        PVW4_LOAD_U(0, 0);
+        PVW4_GATHER(vA, eA, 0);
+        PVW4_GATHER(vB, eB, 1);
+        PVW4_TRANSFORM_STORE(vA, eA, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // stage s: V(s+1) from the gather issued one stage ago, gather of stage s+2 issued now (two stages in flight)
+        for (int s = 0; s < a.n_stages; s += 2) {
+            PVW4_LOAD_U(s + 1, 1);
+            PVW4_GATHER(vA, eA, s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            PVW4_TRANSFORM_STORE(vB, eB, 1);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // the U image of stage s+1 has landed (only the newest gather, 12 loads, may be pending)
+            __syncthreads();
+            if (s + 1 < a.n_stages) {
+                PVW4_LOAD_U(s + 2, 0);
+                PVW4_GATHER(vB, eB, s + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                PVW4_TRANSFORM_STORE(vA, eA, 0);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                __syncthreads();
+            }
+        }
+#undef PVW4_GATHER
+#undef PVW4_TRANSFORM_STORE
+    } else {
+        // ------------------------------------------------------------------ consumers: row i = wid of the 6x6 transform domain
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        PVW4_LOAD_U(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int s = 0; s < a.n_stages; ++s) {
+            const int buf = s & 1;
+            PVW4_LOAD_U(s + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < kCB / 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float af = Us[buf][wid * 6 + j][2 * kk + lh][l31];
+                    const float bf = Vs[buf][wid * 6 + j][2 * kk + lh][l31];
+                    if (ABL == 3) acc[j][0] += af * bf;
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+#undef PVW4_LOAD_U
+
+    // ---- output transform Y = A^T D A: the column half in registers (consumer i holds row i), the rows meet in LDS,
+    // 16 channels at a time: Ex[i][c'][k16][patch] = 48 KB of the 72.
+    float* Ex = &Us[0][0][0][0];
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
+                                                                        a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
+    const int OH = a.H, OW = a.W;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half == 1) __syncthreads();
+        if (wid < CONSUMERS) {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r  = half * 8 + r8;
+                const int kl = (r8 & 3) + 8 * (r8 >> 2) + 4 * lh;           // channel inside the half: 0..15
+                float s0, s1, s2, s3;
+                wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], s0, s1, s2, s3);
+                Ex[((wid * 4 + 0) * 16 + kl) * 32 + l31] = s0;
+                Ex[((wid * 4 + 1) * 16 + kl) * 32 + l31] = s1;
+                Ex[((wid * 4 + 2) * 16 + kl) * 32 + l31] = s2;
+                Ex[((wid * 4 + 3) * 16 + kl) * 32 + l31] = s3;
+            }
+        }
+        __syncthreads();
+        const int tl = tid & 31, kl = tid >> 5;                               // 512 threads = 16 channels x 32 patches
+        const int t  = tb * NT + tl;
+        const int kg = kb * KB + half * 16 + kl;
+        if (t < a.T && kg < a.K) {
+            const int n = t / TPI, rem = t - n * TPI;
+            const int ty = rem / a.TX, tx = rem - ty * a.TX;
+            const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)kg * 4u, 0, 0));
+            float* __restrict__ yp = a.y + (((size_t)n * a.y_ctotal + a.y_coff + kg) * OH + 4 * ty) * OW + 4 * tx;
+            float yv[4][4];
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                float e[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) e[i] = Ex[((i * 4 + c2) * 16 + kl) * 32 + tl];
+                wino4_at(e[0], e[1], e[2], e[3], e[4], e[5], yv[0][c2], yv[1][c2], yv[2][c2], yv[3][c2]);
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) {
+                float4 o;
+                float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    float v = yv[r2][c2];
+                    if (a.bias != nullptr) v = v + bv;
+                    if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;
+                    else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                    ov[c2] = v;
+                }
+                *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace pvhip {
@@ -374,6 +692,61 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     else if (kb == 64) hipLaunchKernelGGL((conv_wino_kernel<2, 1, 4>), grid, dim3(256), 0, state().stream, a);
     else if (waves == 8) hipLaunchKernelGGL((conv_wino_kernel<1, 2, 8>), grid, dim3(512), 0, state().stream, a);
     else hipLaunchKernelGGL((conv_wino_kernel<1, 2, 4>), grid, dim3(256), 0, state().stream, a);
+    return PVHIP_OK;
+}
+
+// ---- F(4x4, 3x3)
+bool wino4_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n) {
+    const char* e       = getenv("PVHIP_CONV_WINOGRAD4");     // "0": F(2x2, 3x3) everywhere
+    const bool  enabled = e == nullptr || e[0] != '0';
+    if (!enabled || !wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return false;
+    if (h % 4 != 0 || w % 4 != 0) return false;
+    // 512 output pixels per workgroup: worth it where the patch blocks alone give every CU a workgroup
+    const long patches = (long)n * (h / 4) * (w / 4);
+    const long min_patches = (e != nullptr && e[0] == 'f') ? 1 : 32L * kNumCU;           // "force": any size (tests)
+    return patches >= min_patches;
+}
+
+size_t wino4_pack_elems(int k, int c) {
+    if (c % kCB != 0) return 0;
+    return (size_t)((k + 31) / 32) * (size_t)(c / kCB + 1) * kXi4 * kCB * 32;
+}
+
+int wino4_pack(const float* w_oihw, float* u, int k, int c) {
+    const size_t elems = wino4_pack_elems(k, c);
+    hipError_t   e     = hipMemsetAsync(u, 0, elems * sizeof(float), state().stream);
+    if (e != hipSuccess) return fail(PVHIP_EHIP, "wino4_pack: hipMemsetAsync -> %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(grid_for((size_t)((k + 31) / 32) * 32 * c)), dim3(kBlock), 0, state().stream, w_oihw,
+                       u, k, c, c / kCB);
+    return PVHIP_OK;
+}
+
+int wino4_conv(const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
+               float act_lo, float act_hi, int out_channel_offset, int out_channels_total) {
+    WinoArgs a;
+    a.x = x; a.u = u; a.y = y; a.bias = bias;
+    a.N = n; a.C = c; a.H = h; a.W = w; a.K = k_out;
+    a.TY = h / 4; a.TX = w / 4;
+    a.T  = n * a.TY * a.TX;
+    a.n_kb = (k_out + 31) / 32;
+    a.n_stages = c / kCB;
+    a.x_bytes = (unsigned)((size_t)n * c * h * w * 4);
+    a.u_bytes = (unsigned)(wino4_pack_elems(k_out, c) * 4);
+    a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
+    a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
+    const long n_tb = ((long)a.T + 31) / 32;
+    if (n_tb * a.n_kb > 0x7fffffffL) return fail(PVHIP_EUNSUPPORTED, "wino4_conv: grid too large");
+    const dim3 grid((unsigned)(n_tb * a.n_kb));
+    int abl = 0;
+    if (const char* e = getenv("PVHIP_WINO4_ABLATE")) abl = atoi(e);      // diagnostic builds of the kernel: results are wrong on purpose
+    switch (abl) {
+        case 1: hipLaunchKernelGGL(conv_wino4_kernel<1>, grid, dim3(512), 0, state().stream, a); break;
+        case 2: hipLaunchKernelGGL(conv_wino4_kernel<2>, grid, dim3(512), 0, state().stream, a); break;
+        case 3: hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, dim3(512), 0, state().stream, a); break;
+        case 4: hipLaunchKernelGGL(conv_wino4_kernel<4>, grid, dim3(512), 0, state().stream, a); break;
+        case 5: hipLaunchKernelGGL(conv_wino4_kernel<5>, grid, dim3(512), 0, state().stream, a); break;
+        default: hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, dim3(512), 0, state().stream, a);
+    }
     return PVHIP_OK;
 }
 

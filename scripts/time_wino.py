@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""GPU-box tool: time the 3x3 / stride 1 / pad 1 GoogLeNet layers (batch 256) under the Winograd variants and the
+direct kernel, through the Convolution plugin (fused bias + ReLU).
+  python scripts/time_wino.py [substring of the layer name]"""
+import os, sys, ctypes
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from pyopenvino_amd import device as dev, synth
+from pyopenvino_amd.op_plugins import Convolution
+
+LAYERS = [('conv2/3x3', (256, 64, 56, 56), 192), ('3a/3x3', (256, 96, 28, 28), 128), ('3b/3x3', (256, 128, 28, 28), 192),
+          ('4e/3x3', (256, 160, 14, 14), 320)]
+dev.init(0)
+only = sys.argv[1] if len(sys.argv) > 1 else ''
+for name, xs, k in LAYERS:
+    if only not in name:
+        continue
+    n, c, h, w = xs
+    x = dev.DeviceTensor.from_numpy(synth.normal(1, 2, n * c * h * w).astype(np.float32).reshape(xs))
+    wt = dev.DeviceTensor.from_numpy((synth.normal(3, 4, k * c * 9) * (2.0 / (c * 9)) ** 0.5).astype(np.float32).reshape((k, c, 3, 3)))
+    b = dev.DeviceTensor.from_numpy(np.zeros((1, k, 1, 1), dtype=np.float32))
+    gf = 2.0 * n * k * c * 9 * h * w / 1e9
+    line = '{:10s} {:6.1f} GFLOP |'.format(name, gf)
+    outs = {}
+    variants = [('F(4x4)', {'PVHIP_CONV_WINOGRAD4': 'force'}), ('F(2x2)', {'PVHIP_CONV_WINOGRAD4': '0'}), ('direct', {'PVHIP_CONV_WINOGRAD': '0'})]
+    if os.environ.get('ABLATE'):
+        variants = [('F(4x4)', {'PVHIP_CONV_WINOGRAD4': 'force'})] + [('abl%s' % a_, {'PVHIP_CONV_WINOGRAD4': 'force', 'PVHIP_WINO4_ABLATE': a_}) for a_ in os.environ['ABLATE'].split(',')] + [('direct', {'PVHIP_CONV_WINOGRAD': '0'}), ('F(2x2)', {'PVHIP_CONV_WINOGRAD4': '0'})]
+    for tag, env in variants:
+        for k_, v_ in env.items():
+            os.environ[k_] = v_
+        node = {}
+        run = lambda: Convolution.launch(node, x, wt, (1, 1), (1, 1), (1, 1), 'explicit', bias=b, act=('relu',))
+        for _ in range(3):
+            y = run()
+        dev.synchronize()
+        e0 = dev.Event().record()
+        for _ in range(5):
+            run()
+        e1 = dev.Event().record(); e1.synchronize()
+        ms = e0.elapsed_ms(e1) / 5
+        outs[tag] = np.asarray(y)[:2]
+        line += ' {}: {:.3f} ms {:5.1f} TF |'.format(tag, ms, gf / ms)
+        for k_ in env:
+            del os.environ[k_]
+    ref = outs['direct']
+    sc = np.abs(ref).max()
+    line += ' max|F4-direct|/max {:.1e}  |F2-direct| {:.1e}'.format(np.abs(outs['F(4x4)'] - ref).max() / sc, np.abs(outs['F(2x2)'] - ref).max() / sc)
+    print(line, flush=True)

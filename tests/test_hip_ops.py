@@ -101,6 +101,31 @@ def test_conv_model_shapes_vs_oracle(hip, xs, ws, st, pb, pe):
     vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'conv {} * {}'.format(xs, ws))
 
 
+def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
+    """F(4x4, 3x3) (the layers with extents divisible by 4 and enough patches; forced here): one, odd and many channel
+    stages, ragged channel blocks, fewer patches than a workgroup holds, several images, fused bias + ReLU written in place
+    into a wider tensor; against the oracle and against the direct kernel."""
+    from pyopenvino_amd import device as dev
+    monkeypatch.setenv('PVHIP_CONV_WINOGRAD4', 'force')
+    cases = [((2, 4, 8, 8), 5), ((3, 20, 12, 16), 70), ((1, 64, 56, 56), 32), ((2, 96, 28, 28), 128), ((5, 8, 4, 4), 3), ((1, 12, 4, 20), 33)]
+    for xs, k in cases:
+        x = rnd(sum(xs), xs)
+        w = rnd(k, (k, xs[1], 3, 3), (2.0 / (xs[1] * 9)) ** 0.5)
+        err = vs_oracle('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)), 'winograd F(4x4) {} k{}'.format(xs, k))
+        assert err <= 5e-5, 'winograd F(4x4) {}: {:.2e}'.format(xs, err)
+    x, w, b = np.abs(rnd(1, (2, 32, 12, 8))), rnd(2, (40, 32, 3, 3), 0.1), rnd(3, (1, 40, 1, 1), 0.3)
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
+    wide = dev.DeviceTensor.from_numpy(np.full((2, 50, 12, 8), -1.0, dtype=np.float32))
+    fused = dict(node)
+    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
+    hip_plugin('Convolution').compute(fused, {0: x, 1: w})
+    got = np.asarray(wide)
+    monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
+    direct = np.maximum(first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w})) + b, 0)
+    assert_close(got[:, 7:47], direct, 2e-5, 'winograd F(4x4) fused vs direct')
+    assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
+
+
 @pytest.mark.parametrize('kb,waves', [(None, None), ('32', 'small'), ('32', '8'), ('64', '8'), ('32', '4'), ('64', '4')])
 def test_conv_winograd_3x3(hip, monkeypatch, kb, waves):
     """3x3 / stride 1 / pad 1 layers run Winograd F(2x2, 3x3) (the default): odd extents (half-empty last patches),
