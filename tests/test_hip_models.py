@@ -92,6 +92,21 @@ def test_googlenet_layerwise_vs_oracle(hip):
     print('worst layer', worst)
 
 
+def test_googlenet_winograd_f4x4_end_to_end(hip, monkeypatch):
+    """The F(4x4, 3x3) kernel forced onto every layer it covers at a small batch (at batch 256 it is the default for
+    conv2/3x3 and the 28x28 inception layers): the network output stays inside the stated tolerance of the reference's
+    recorded output, with margin."""
+    from pyopenvino_amd import synth
+    monkeypatch.setenv('PVHIP_CONV_WINOGRAD4', 'force')
+    z = np.load(os.path.join(GOLDEN, 'googlenet_e2e.npz'))
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), int(z['weight_seed']))
+    x = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
+    _, net, ex = build_network(HIP, 'googlenet-v1', weights=blob, batch=x.shape[0])
+    err = assert_close(infer_one(ex, net, x), z['out'], helpers.REL_TOL, 'GoogLeNet with F(4x4,3x3)')
+    print('GoogLeNet end to end with F(4x4,3x3): {:.2e}'.format(err))
+    assert err <= 3e-5, err
+
+
 def test_googlenet_batch256_properties(hip):
     """BASELINE config 3 at full size (no CPU oracle run at this size): rows sum to 1; images 0-1 of the
     256-batch equal the reference's N=1 answers; a permuted batch gives permuted rows (independence)."""
