@@ -1002,6 +1002,7 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     const size_t kred_pad = (size_t)round_up_int(c * kh * kw, kBK);
     const size_t kout_pad = (size_t)round_up_int(k_out, kKoutAlign);
     size_t elems = 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
+    elems += stem_pack_elems(k_out, c, kh, kw);      // the 7x7 / 3-channel stem keeps its own panel behind the general one
     if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c) + wino4_pack_elems(k_out, c);   // 3x3: the Winograd-transformed panels ride along (stride / pad are not known yet)
     return elems;
 }
@@ -1017,6 +1018,10 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
     float* wp   = wpack + 2 * (kred_pad + kTabSpare);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kPanelSpare) * kout_pad)), dim3(kBlock), 0, state().stream,
                        w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad, rs_major(c, kh, kw) ? 1 : 0);
+    if (stem_pack_elems(k_out, c, kh, kw) > 0) {
+        const int rc = stem_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out);
+        if (rc) return rc;
+    }
     if (kh == 3 && kw == 3 && wino_pack_elems(k_out, c) > 0) {
         float* const u2 = wp + (size_t)(kred_pad + kPanelSpare) * kout_pad;
         int rc = wino_pack(w_oihw, u2, k_out, c);
@@ -1068,6 +1073,14 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
 
     // ---- 3x3 / stride 1 / same padding: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (pvhip_wino.hip)
+    // ---- 7x7 / stride 2 / 3 input channels: the persistent stem kernel (pvhip_stem.hip)
+    if (stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, out_e)) {
+        const int rc = stem_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, h, w, k_out, oh, ow, pad_top, pad_left,
+                                 bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
+        if (rc) return rc;
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
     if (wino4_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) {
         const int rc = wino4_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad + wino_pack_elems(k_out, c), y, n, c, h, w,
                                   k_out, bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
@@ -1202,11 +1215,18 @@ int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int
     a.relu = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = a.seg[0].ctotal; a.y_coff = a.seg[0].coff;
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
-    a.n_mtiles = k_panel / 32;
+    int bm = 32;
+    if (const char* e = getenv("PVHIP_CONV_MULTI_BM")) bm = atoi(e) == 64 ? 64 : 32;       // tuning runs only
+    a.n_mtiles = (k_panel + bm - 1) / bm;          // a 64-channel tile may straddle two ranges: the epilogue looks the range up per 32 channels
     const int n_ptiles = (a.P + 127) / 128;
     const bool pw = (h * w) % 4 == 0;
-    if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
-    else    hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+    if (bm == 64) {
+        if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<64, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+        else    hipLaunchKernelGGL((conv_igemm_dma_kernel<64, true, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+    } else {
+        if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+        else    hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+    }
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -101,6 +101,32 @@ def test_conv_model_shapes_vs_oracle(hip, xs, ws, st, pb, pe):
     vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'conv {} * {}'.format(xs, ws))
 
 
+def test_conv_stem_7x7_stride2(hip, monkeypatch):
+    """The persistent 7x7 / stride 2 / 3-channel kernel (GoogLeNet conv1): ragged extents (half-empty tiles), fewer tiles
+    than workgroups and more, K below 64, asymmetric / no padding, fused bias + ReLU written in place into a wider tensor;
+    against the oracle and against the general kernel."""
+    from pyopenvino_amd import device as dev
+    cases = [((2, 3, 224, 224), 64, (3, 3), (3, 3)), ((1, 3, 23, 31), 40, (3, 3), (3, 3)), ((3, 3, 40, 17), 7, (0, 0), (0, 0)),
+             ((5, 3, 64, 64), 64, (2, 3), (1, 0)), ((1, 3, 7, 7), 3, (0, 0), (0, 0)), ((70, 3, 30, 30), 16, (3, 3), (3, 3))]
+    for xs, k, pb, pe in cases:
+        x = rnd(sum(xs), xs, 50.0)
+        w = rnd(k, (k, 3, 7, 7), (2.0 / 147) ** 0.5)
+        err = vs_oracle('Convolution', [x, w], conv_data((2, 2), pb, pe), 'stem {} k{} pads {} {}'.format(xs, k, pb, pe))
+        assert err <= 2e-5, 'stem {}: {:.2e}'.format(xs, err)
+    x, w, b = rnd(1, (2, 3, 37, 45), 20.0), rnd(2, (24, 3, 7, 7), 0.1), rnd(3, (1, 24, 1, 1), 0.3)
+    node = make_node('Convolution', [x, w], conv_data((2, 2), (3, 3), (3, 3)))
+    oh, ow = hip_plugin('Convolution').calc_output_shape((37, 45), (7, 7), (2, 2), (3, 3), (3, 3), 'floor', 'explicit')
+    wide = dev.DeviceTensor.from_numpy(np.full((2, 30, oh, ow), -1.0, dtype=np.float32))
+    fused = dict(node)
+    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 5)
+    hip_plugin('Convolution').compute(fused, {0: x, 1: w})
+    got = np.asarray(wide)
+    monkeypatch.setenv('PVHIP_CONV_STEM', '0')
+    general = np.maximum(first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w})) + b, 0)
+    assert_close(got[:, 5:29], general, 5e-6, 'stem fused vs the general kernel')
+    assert np.all(got[:, :5] == -1.0) and np.all(got[:, 29:] == -1.0)
+
+
 def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     """F(4x4, 3x3) (the layers with extents divisible by 4 and enough patches; forced here): one, odd and many channel
     stages, ragged channel blocks, fewer patches than a workgroup holds, several images, fused bias + ReLU written in place
