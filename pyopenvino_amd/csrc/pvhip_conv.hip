@@ -1216,11 +1216,14 @@ int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int
     a.y_ctotal = a.seg[0].ctotal; a.y_coff = a.seg[0].coff;
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
     int bm = 32;
-    if (const char* e = getenv("PVHIP_CONV_MULTI_BM")) bm = atoi(e) == 64 ? 64 : 32;       // tuning runs only
+    if (const char* e = getenv("PVHIP_CONV_MULTI_BM")) bm = atoi(e) == 64 ? 64 : (atoi(e) == 128 ? 128 : 32);       // tuning runs only
     a.n_mtiles = (k_panel + bm - 1) / bm;          // a 64-channel tile may straddle two ranges: the epilogue looks the range up per 32 channels
     const int n_ptiles = (a.P + 127) / 128;
     const bool pw = (h * w) % 4 == 0;
-    if (bm == 64) {
+    if (bm == 128) {
+        if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+        else    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, true, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
+    } else if (bm == 64) {
         if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<64, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
         else    hipLaunchKernelGGL((conv_igemm_dma_kernel<64, true, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
     } else {

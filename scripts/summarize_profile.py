@@ -13,6 +13,11 @@ import os
 import sys
 
 
+def is_conv(name):
+    """The kernels behind the Convolution nodes: implicit GEMM, both Winograd forms, the 7x7 stem."""
+    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_stem' in name
+
+
 def find(root, pattern):
     hits = glob.glob(os.path.join(root, '**', pattern), recursive=True)
     return hits[0] if hits else None
@@ -44,16 +49,16 @@ def main():
             short = name.replace('(anonymous namespace)::', '').split('(')[0][:70]
             md.append('| `{}` | {} | {:.3f} | {:.2f} | {} |'.format(short, r['Calls'], float(r['TotalDurationNs']) / 1e6,
                                                                   float(r['AverageNs']) / 1e3, r['Percentage']))
-            if 'conv_igemm' in name or 'conv_wino' in name:
+            if is_conv(name):
                 conv_total_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         if conv_calls:
-            md += ['', '**conv_wino_kernel + conv_igemm_dma_kernel (+ conv_igemm_kernel), all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+            md += ['', '**conv_wino4_kernel + conv_wino_kernel + conv_igemm_dma_kernel + conv_stem7x7_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of {} launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * per_pass / 1e6, per_pass)]
     trace = find(os.path.join(raw, 'stats'), '*kernel_trace.csv')
     if trace and conv_calls:
-        conv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(trace)) if 'conv_igemm' in r['Kernel_Name'] or 'conv_wino' in r['Kernel_Name'])
+        conv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(trace)) if is_conv(r['Kernel_Name']))
         tail_ = conv[-5 * per_pass:]
         head_ = conv[:3 * per_pass]
         md += ['', 'From the kernel trace of the same run: the first 3 forward passes (clocks ramping up from idle, cold caches) average {:.2f} us '
@@ -71,7 +76,7 @@ def main():
     if forked:
         tot = calls = 0.0
         for r in csv.DictReader(open(forked)):
-            if 'conv_igemm' in r['Name'] or 'conv_wino' in r['Name']:
+            if is_conv(r['Name']):
                 tot += float(r['TotalDurationNs'])
                 calls += int(r['Calls'])
         with open(os.path.join(prof, tag + '_kernel_stats_forked.csv'), 'w') as f:
@@ -93,7 +98,7 @@ def main():
         for r in csv.DictReader(open(cc)):
             if r['Counter_Name'] != counter:
                 continue
-            fam = 'conv_igemm_kernel' if ('conv_igemm' in r['Kernel_Name'] or 'conv_wino' in r['Kernel_Name']) else r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('<')[0].replace('void ', '')
+            fam = 'conv_igemm_kernel' if (is_conv(r['Kernel_Name'])) else r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('<')[0].replace('void ', '')
             agg = per_kernel.setdefault(fam, [0.0, 0])
             agg[0] += float(r['Counter_Value'])
             agg[1] += 1
@@ -116,11 +121,11 @@ def main():
     if sq:
         agg = {}
         for r in csv.DictReader(open(sq)):
-            if 'conv_igemm' in r['Kernel_Name'] or 'conv_wino' in r['Kernel_Name']:
+            if is_conv(r['Kernel_Name']):
                 agg[r['Counter_Name']] = agg.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
         if agg.get('GRBM_GUI_ACTIVE'):
             cyc = agg['GRBM_GUI_ACTIVE'] / 8.0
-            md += ['', '## convolution kernels (conv_wino + conv_igemm_dma), SQ counters summed over their launches', '']
+            md += ['', '## convolution kernels (conv_wino4 + conv_wino + conv_igemm_dma + conv_stem7x7), SQ counters summed over their launches', '']
             md += ['- MFMA pipe busy: {:.1f} % of SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))'.format(
                 100.0 * agg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / cyc)]
             if agg.get('SQ_BUSY_CU_CYCLES'):
@@ -128,7 +133,7 @@ def main():
                     100.0 * agg['SQ_BUSY_CU_CYCLES'] / 256.0 / cyc)]
             kt = find(os.path.join(raw, 'pmc_SQ'), '*kernel_trace.csv')
             if kt:
-                dur = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(kt)) if 'conv_igemm' in r['Kernel_Name'] or 'conv_wino' in r['Kernel_Name'])
+                dur = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(kt)) if is_conv(r['Kernel_Name']))
                 if dur:
                     ghz = cyc / dur
                     md += ['- shader clock while these kernels ran: {:.2f} GHz (GRBM_GUI_ACTIVE / 8 / summed kernel time) -> fp32 MFMA ceiling at that clock '
