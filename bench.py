@@ -102,7 +102,7 @@ def main():
     ap.add_argument('--cpu-images', type=int, default=60, help='images timed on the CPU baseline (0 = skip)')
     ap.add_argument('--no-node-timing', action='store_true')
     ap.add_argument('--streams', type=int, default=0, help='compute streams the scheduler forks branches onto (0 = engine default)')
-    ap.add_argument('--requests', type=int, default=4, help='infer requests in flight per GPU (each a whole batch; 1 = synchronous infer())')
+    ap.add_argument('--requests', type=int, default=8, help='infer requests in flight per GPU (each a whole batch; 1 = synchronous infer())')
     args = ap.parse_args()
 
     from pyopenvino_amd import IECore, device, shard, synth

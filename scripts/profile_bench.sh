@@ -8,7 +8,7 @@ TAG=${TAG:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# Two kernel-trace runs: the default bench command (4 whole-batch requests in flight: kernels of different passes
+# Two kernel-trace runs: the default bench command (8 whole-batch requests in flight: kernels of different passes
 # overlap, so a launch's start-to-end time includes its neighbours) and the same workload one request at a time on
 # ONE stream, where a launch's duration is its own -- that one is what bench.py's roofline (sampled steps that run
 # alone on one stream) must agree with.

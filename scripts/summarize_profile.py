@@ -31,7 +31,7 @@ def main():
     md = ['# rocprofv3 summary `{}`'.format(tag), '',
           'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0 --requests 1 --streams 1` '
           '(googlenet-v1, batch 256, 1 GPU; one request at a time on ONE compute stream, so that a launch\'s start-to-end time is its own: '
-          'this is what bench.py\'s roofline measures on its sampled steps).  The default command (4 whole-batch requests in flight, '
+          'this is what bench.py\'s roofline measures on its sampled steps).  The default command (several whole-batch requests in flight, '
           'kernels of different passes overlapping) is summarised at the end.', '']
     stats = find(os.path.join(raw, 'stats'), '*kernel_stats.csv')
     conv_total_ns = conv_calls = 0
@@ -81,7 +81,7 @@ def main():
                 calls += int(r['Calls'])
         with open(os.path.join(prof, tag + '_kernel_stats_forked.csv'), 'w') as f:
             f.write(open(forked).read())
-        forked_md = ['', '## Default command (4 requests in flight)', '',
+        forked_md = ['', '## Default command (requests in flight)', '',
                      '`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0`: per-kernel table in `{}_kernel_stats_forked.csv`.  '
                      'Convolution launches: {:.0f}, average start-to-end {:.2f} us -- longer than alone on one stream because launches of different '
                      'passes share the chip; the step is shorter.'.format(tag, calls, tot / max(1.0, calls) / 1e3)]
