@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   6
+#define PVHIP_ABI_VERSION   7
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -167,6 +167,17 @@ int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
                         const float* bias, int relu,
                         int out_channel_offset, int out_channels_total,
                         float act_lo, float act_hi);
+/* Add.py:9-14 of a per-channel constant (1,c,1,1) followed by the convolution, as one launch: y = conv(x + pre_add[c]) with zero
+ * padding applied AFTER the add, exactly as the two nodes do (the same fp32 add; bit-identical).  pre_add: c device floats.
+ * Only where the convolution's own kernel fetches its input through registers -- the 7x7 / stride 2 / 3-channel stem
+ * (pvhip_conv2d_preadd_supported; no device needed); PVHIP_EUNSUPPORTED otherwise.  Other arguments as pvhip_conv2d_f32. */
+int    pvhip_conv2d_preadd_supported(int n, int c, int kh, int kw, int sh, int sw, int k_out, int oh, int ow, int pad_top, int pad_left);
+int    pvhip_conv2d_preadd_f32(const float* x, const float* pre_add, const float* wpack, float* y,
+                               int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
+                               int sh, int sw, int pad_top, int pad_left,
+                               const float* bias, int relu,
+                               int out_channel_offset, int out_channels_total,
+                               float act_lo, float act_hi);
 /* Several Convolution.py:149-176 calls that share their input (the 1x1, 3x3_reduce and 5x5_reduce arms of an inception
  * module) as ONE launch: the input is read once and the small arms ride in the big one's grid.  Only 1x1 / stride 1 /
  * unpadded convolutions with c % 16 == 0 (pvhip_conv2d_multi_supported; no device needed).  wpack is the panel of

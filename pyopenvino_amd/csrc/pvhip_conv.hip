@@ -1035,9 +1035,9 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
     return PVHIP_OK;
 }
 
-int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh, int kw,
-                     int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
-                     int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+static int conv2d_impl(const float* x, const float* pre_add, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh,
+                       int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
+                       int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && k_out > 0 && kh > 0 && kw > 0 && oh >= 0 && ow >= 0);
     PVHIP_CHECK_ARG(sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0);
@@ -1075,12 +1075,14 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     // ---- 3x3 / stride 1 / same padding: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (pvhip_wino.hip)
     // ---- 7x7 / stride 2 / 3 input channels: the persistent stem kernel (pvhip_stem.hip)
     if (stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, out_e)) {
-        const int rc = stem_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, h, w, k_out, oh, ow, pad_top, pad_left,
-                                 bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
+        const int rc = stem_conv(x, pre_add, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, h, w, k_out, oh, ow, pad_top,
+                                 pad_left, bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
         if (rc) return rc;
         PVHIP_LAUNCH_CHECK();
         return PVHIP_OK;
     }
+    if (pre_add != nullptr)
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_preadd_f32: only the 7x7 / stride 2 / 3-channel stem kernel adds in its fetch (ask pvhip_conv2d_preadd_supported)");
     if (wino4_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) {
         const int rc = wino4_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad + wino_pack_elems(k_out, c), y, n, c, h, w,
                                   k_out, bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
@@ -1164,6 +1166,25 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
     else launch_conv<32, 128, 1, 4>(a, n_ptiles);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
+}
+
+int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh, int kw,
+                     int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
+                     int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+    return conv2d_impl(x, nullptr, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
+                       out_channels_total, act_lo, act_hi);
+}
+
+int pvhip_conv2d_preadd_supported(int n, int c, int kh, int kw, int sh, int sw, int k_out, int oh, int ow, int pad_top, int pad_left) {
+    return stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, (unsigned long long)n * k_out * oh * ow) ? 1 : 0;
+}
+
+int pvhip_conv2d_preadd_f32(const float* x, const float* pre_add, const float* wpack, float* y, int n, int c, int h, int w, int k_out,
+                            int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
+                            int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+    PVHIP_CHECK_ARG(pre_add != nullptr);
+    return conv2d_impl(x, pre_add, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
+                       out_channels_total, act_lo, act_hi);
 }
 
 int pvhip_conv2d_multi_supported(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int n_dest) {

@@ -9,6 +9,8 @@
 //     v_mfma_f32_32x32x2_f32 are kernel rows 2j and 2j+1 of the same (c, s) (row 7 = zero weights: 84 steps for 147 taps),
 //   * the zero-padded INPUT patch of its 8 x 16 output pixels (3 x 21 x 37 floats, row pitch 40, plus a row of zeros per channel), double-buffered: the patch
 //     of the next tile is fetched into registers while the current one is multiplied.
+// An Add of a per-channel constant in front of the convolution (GoogLeNet's data/mean) can ride in the patch fetch: x + m[c] for
+// the elements inside the image (the same fp32 add the Add node does), zeros for the padding.
 // The B operand of step (c, s, j) for lane (pixel, parity lh) is then patch[c][2*py + 2j + lh][2*px + s]: a per-lane base that never
 // changes plus a compile-time offset -- ds_read_b32 with an immediate, no address arithmetic, no window test (padding is zeros in
 // LDS), no global loads in the loop.  The A operand likewise.  D[k][pixel] as in pvhip_conv.hip: wave w owns output rows 2w, 2w+1
@@ -41,6 +43,7 @@ struct StemArgs {
     const float* wl;      // [84][2][64]
     float*       y;
     const float* bias;
+    const float* pre_add;   // optional [3]: added to every input element inside the image (the Add node in front of the convolution)
     int N, H, W, K, OH, OW;
     int pt, pl;
     int tiles_y, tiles_x, n_tiles;
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_stem7x7_kernel(StemArgs a) {
     // this thread's elements of an input patch: (channel, row, column) of idx = tid + 256*i, and their offset from the
     // patch origin in the tensor; a patch that lies wholly inside the image (most do) needs no window test
     int pr[kPerThread], pq[kPerThread], rel[kPerThread];
+    float padd[kPerThread];
     bool used[kPerThread];
 #pragma unroll
     for (int i = 0; i < kPerThread; ++i) {
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_stem7x7_kernel(StemArgs a) {
         pq[i] = idx % kPitch;
         used[i] = idx < kPatch && pq[i] < kPC && pr[i] < kPRin;
         rel[i] = c_ * HW + pr[i] * a.W + pq[i];
+        padd[i] = (a.pre_add != nullptr && c_ < kC) ? a.pre_add[c_] : 0.0f;
     }
     float pre[kPerThread];
 #define PVS_FETCH(t_)                                                                                       \
@@ -154,12 +159,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_stem7x7_kernel(StemArgs a) {
         const int iy0 = ty_ * kTR * kST - a.pt, ix0 = tx_ * kTC * kST - a.pl;                               \
         const float* __restrict__ xo = a.x + ((long)n_ * kC * HW + (long)iy0 * a.W + ix0);                  \
         if (iy0 >= 0 && ix0 >= 0 && iy0 + kPRin <= a.H && ix0 + kPC <= a.W) {                                 \
-            _Pragma("unroll") for (int i = 0; i < kPerThread; ++i) pre[i] = used[i] ? xo[rel[i]] : 0.0f;    \
+            _Pragma("unroll") for (int i = 0; i < kPerThread; ++i) pre[i] = used[i] ? xo[rel[i]] + padd[i] : 0.0f; \
         } else {                                                                                            \
             _Pragma("unroll") for (int i = 0; i < kPerThread; ++i) {                                        \
                 const int iy = iy0 + pr[i], ix = ix0 + pq[i];                                               \
                 const bool ok = used[i] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;    \
-                pre[i] = ok ? xo[rel[i]] : 0.0f;                                                            \
+                pre[i] = ok ? xo[rel[i]] + padd[i] : 0.0f;                                                  \
             }                                                                                               \
         }                                                                                                   \
     }
@@ -265,10 +270,10 @@ int stem_pack(const float* w_oihw, float* wl, int k) {
     return PVHIP_OK;
 }
 
-int stem_conv(const float* x, const float* wl, float* y, int n, int h, int w, int k_out, int oh, int ow, int pad_top, int pad_left,
-              const float* bias, int act, float act_lo, float act_hi, int out_channel_offset, int out_channels_total) {
+int stem_conv(const float* x, const float* pre_add, const float* wl, float* y, int n, int h, int w, int k_out, int oh, int ow, int pad_top,
+              int pad_left, const float* bias, int act, float act_lo, float act_hi, int out_channel_offset, int out_channels_total) {
     StemArgs a;
-    a.x = x; a.wl = wl; a.y = y; a.bias = bias;
+    a.x = x; a.wl = wl; a.y = y; a.bias = bias; a.pre_add = pre_add;
     a.N = n; a.H = h; a.W = w; a.K = k_out; a.OH = oh; a.OW = ow; a.pt = pad_top; a.pl = pad_left;
     a.tiles_y = (oh + kTR - 1) / kTR; a.tiles_x = (ow + kTC - 1) / kTC;
     const long tiles = (long)n * a.tiles_y * a.tiles_x;

@@ -23,7 +23,7 @@ int    wino4_conv(const float* x, const float* u, float* y, int n, int c, int h,
 bool   stem_eligible(int c, int kh, int kw, int sh, int sw, int k_out, int pad_top, int pad_left, unsigned long long out_elems);
 size_t stem_pack_elems(int k, int c, int kh, int kw);
 int    stem_pack(const float* w_oihw, float* wl, int k);
-int    stem_conv(const float* x, const float* wl, float* y, int n, int h, int w, int k_out, int oh, int ow, int pad_top, int pad_left,
-                 const float* bias, int act, float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
+int    stem_conv(const float* x, const float* pre_add, const float* wl, float* y, int n, int h, int w, int k_out, int oh, int ow, int pad_top,
+                 int pad_left, const float* bias, int act, float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
 
 }  // namespace pvhip

@@ -342,6 +342,7 @@ class Executable_Network:
         self._concat_direct = {}        # Concat node id -> total channels, when every input is written in place
         self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it
         self._siblings = {}             # Convolution node id -> ids of the convolutions of the same input launched with it
+        self._pre_add = {}              # Convolution node id -> (Add node folded into its input fetch, Const id, id of the Add's data input)
         self.fuse_siblings = os.environ.get('PVHIP_FUSE_SIBLINGS', '1') != '0'
         self._infer_serial = 0
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
@@ -420,7 +421,7 @@ class Executable_Network:
         bit-identical to the three launches); the Add and ReLU nodes are not dispatched and their output
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
-        self._fusion, self._fused_away, self._lrn_pool, self._siblings = {}, set(), {}, {}
+        self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pre_add = {}, set(), {}, {}, {}
         if not self.fuse_epilogues:
             return
         G = self.ienet.G
@@ -499,6 +500,27 @@ class Executable_Network:
             self._concat_direct[nid] = coff
             self._fused_away.add(nid)
 
+        # An Add of a per-channel Const whose only consumer is a convolution that adds in its own input fetch (the 7x7 stem
+        # behind data/mean): the Add is not dispatched, the convolution reads the Add's input and receives the constant.
+        if getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False):
+            for cid in G.nodes:
+                if G.nodes[cid]['type'] != 'Convolution' or cid in self._fused_away:
+                    continue
+                src = next((p_ for p_ in G.pred[cid] if G.edges[(p_, cid)]['connection'][3] == 0), None)
+                if src is None or G.nodes[src]['type'] != 'Add' or src in self._fused_away or len(list(G.successors(src))) != 1:
+                    continue
+                preds = sorted(G.pred[src], key=lambda p_: G.edges[(p_, src)]['connection'][3])
+                if len(preds) != 2 or G.nodes[preds[1]]['type'] != 'Const' or G.nodes[preds[0]]['type'] == 'Const':
+                    continue
+                chans = G.nodes[cid]['input'][0]['dims'][1]
+                cdata = G.nodes[preds[1]]['data']
+                if tuple(cdata['shape']) != (1, chans, 1, 1) or cdata['element_type'] != 'f32':
+                    continue
+                if tuple(G.nodes[src]['input'][0]['dims']) != tuple(G.nodes[cid]['input'][0]['dims']):
+                    continue
+                if conv_plugin.pre_add_fusable(G.nodes[cid]):
+                    self._pre_add[cid] = (src, preds[1], preds[0])
+                    self._fused_away.add(src)
         # Third peephole: fused convolution chains that read the SAME tensor with the same geometry and activation (the
         # 1x1, 3x3_reduce and 5x5_reduce arms of an inception module) are one launch of the first of them in schedule
         # order: the input is read once and every output-channel tile stores into the tensor of its own convolution
@@ -562,7 +584,11 @@ class Executable_Network:
                     if nid is not None:
                         owner[nid] = lead
 
+        folded_adds = {add_id: src_id for add_id, _, src_id in self._pre_add.values()}
+
         def producers(nid):
+            if nid in folded_adds:           # an Add folded into its consumer's fetch: whoever wrote the Add's input
+                return producers(folded_adds[nid])
             if nid in self._concat_direct and nid in self._fused_away:
                 return [p for pred in G.pred[nid] for p in producers(pred)]
             if nid in owner:
@@ -699,6 +725,15 @@ class Executable_Network:
                     device.select_stream(base + current)
                 for dep in waits[task]:
                     done_events[dep].wait()
+            pre = self._pre_add.get(task)
+            if pre is not None:              # the folded Add hands its own input on: the kernel adds the constant while it fetches
+                add_id, const_id, _ = pre
+                edge = next(G.edges[(p_, add_id)]['connection'] for p_ in G.pred[add_id] if G.edges[(p_, add_id)]['connection'][3] == 0)
+                out = G.nodes[add_id]['output']
+                out[next(iter(out))]['data'] = G.nodes[edge[0]]['output'][edge[1]]['data']
+                node['_fuse_pre_add'] = G.nodes[const_id]['output'][0]['data']
+            else:
+                node.pop('_fuse_pre_add', None)
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
             fusion = self._fusion.get(task)
             node.pop('_out_into', None)
@@ -865,8 +900,8 @@ class Executable_Network:
                 chain = [cid, f['add']] + ([f['relu']] if f['relu'] is not None else [])
                 if all(c in needed for c in chain):
                     keep[cid] = dict(f, into=None)      # Concat elimination is not applied to sub-graphs
-            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings)
-            self._siblings = {}                          # sub-graph runs launch every convolution on its own
+            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add)
+            self._siblings, self._pre_add = {}, {}       # sub-graph runs launch every convolution (and Add) on its own
             self._fusion = {c: f for c, f in keep.items()}
             self._fused_away = {n for f in self._fusion.values() for n in (f['add'], f['relu']) if n is not None}
             self._concat_direct = {}
@@ -875,7 +910,7 @@ class Executable_Network:
             try:
                 self.run_tasks(False)
             finally:
-                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings = saved
+                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add = saved
         finally:
             self.task_list = full
         out = {}

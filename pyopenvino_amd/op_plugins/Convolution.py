@@ -20,6 +20,11 @@ SUPPORTS_FUSED_EPILOGUE = True
 # same activation); the input is then read once, by one launch whose output-channel tiles store into the tensor of the
 # convolution they belong to.  The siblings' outputs are left in node['_sibling_out'], in the same order.
 SUPPORTS_SIBLINGS = True
+# An Add of a per-channel constant whose only consumer is a convolution that fetches its input through registers (the 7x7 /
+# stride 2 / 3-channel stem: GoogLeNet's data/mean in front of conv1) may be handed over with the convolution:
+# node['_fuse_pre_add'] = the (1, C, 1, 1) constant, inputs[0] = the Add's own input.  The kernel adds while it fetches (the same
+# fp32 add; zero padding stays zero), the Add launch and its tensor disappear.
+SUPPORTS_PRE_ADD = True
 
 
 def name():
@@ -46,7 +51,7 @@ def packed_weights(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
     return wpack
 
 
-def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None):
+def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, pre_add=None):
     n, c, h, wd = x.shape
     kn, kc, kh, kw = w.shape
     if kc != c:
@@ -71,10 +76,27 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         ctotal = target.shape[1]
         assert target.shape[0] == n and tuple(target.shape[2:]) == (oh, ow) and coff + kn <= ctotal
         y = dev.ChannelSlice(target, coff, kn)
-    dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr),
-             n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
-             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
+    tail = (n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
+            ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
+    if pre_add is not None:
+        assert pre_add.size == c
+        dev.call('pvhip_conv2d_preadd_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(pre_add.ptr), ctypes.c_void_p(wpack.ptr),
+                 ctypes.c_void_p(target.ptr), *tail)
+    else:
+        dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
     return y
+
+
+def pre_add_fusable(node: dict) -> bool:
+    """True when libpvhip adds a per-channel constant in this convolution's input fetch (IR port dims; no device needed)."""
+    try:
+        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+        strides, pb, pe = (common_def.string_to_tuple(attrs[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+        oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
+        return bool(dev.call('pvhip_conv2d_preadd_supported', int(xd[0]), int(xd[1]), int(wd[2]), int(wd[3]), strides[0], strides[1],
+                             int(wd[0]), oh, ow, pb[0], pb[1]))
+    except (KeyError, ValueError, AssertionError, IndexError):
+        return False
 
 
 def siblings_fusable(nodes) -> bool:
@@ -187,8 +209,9 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         outs = launch_siblings(node, x, members, strides, pads_begin, node.get('_fuse_act'))
         y, node['_sibling_out'] = outs[0], outs[1:]
     else:
+        pre_add = node.get('_fuse_pre_add')
         y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'),
-                   into=node.get('_out_into'))
+                   into=node.get('_out_into'), pre_add=dev.as_device(pre_add) if pre_add is not None else None)
     port = common_def.first_output_port(node)
     assert common_def.type_convert_tbl[node['output'][port]['precision']] == np.float32
     return {port: y}

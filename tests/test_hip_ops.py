@@ -127,6 +127,30 @@ def test_conv_stem_7x7_stride2(hip, monkeypatch):
     assert np.all(got[:, :5] == -1.0) and np.all(got[:, 29:] == -1.0)
 
 
+def test_conv_stem_with_the_add_in_front_folded_in_is_bit_identical(hip):
+    """Add(per-channel Const) -> 7x7 / stride 2 convolution handed over as one call (node['_fuse_pre_add']): the kernel adds
+    while it fetches its input patch, padding stays zero -- the bits of the two launches; other convolutions decline."""
+    from pyopenvino_amd import device as dev
+    conv, add = hip_plugin('Convolution'), hip_plugin('Add')
+    x = rnd(7, (3, 3, 45, 38), 60.0, 100.0)
+    m = np.array([-104.0, -117.0, -123.0], dtype=np.float32).reshape(1, 3, 1, 1)
+    w, b = rnd(8, (48, 3, 7, 7), 0.05), rnd(9, (1, 48, 1, 1), 0.2)
+    node = make_node('Convolution', [x, w], conv_data((2, 2), (3, 3), (3, 3)))
+    assert conv.pre_add_fusable(node)
+    summed = first_out(add.compute(make_node('Add', [x, m]), {0: x, 1: m}))
+    two = dict(node)
+    two['_fuse_bias'], two['_fuse_act'] = dev.DeviceTensor.from_numpy(b), ('relu',)
+    want = first_out(conv.compute(two, {0: summed, 1: w}))
+    one = dict(node)
+    one['_fuse_bias'], one['_fuse_act'], one['_fuse_pre_add'] = dev.DeviceTensor.from_numpy(b), ('relu',), dev.DeviceTensor.from_numpy(m)
+    got = first_out(conv.compute(one, {0: x, 1: w}))
+    assert_bit_exact(got, want, 'stem with the Add folded in')
+    oracle = np.maximum(first_out(oracle_plugin('Convolution').compute(node, {0: x + m, 1: w}, kernel_type='special')) + b, 0)
+    assert_close(got, oracle, helpers.REL_TOL, 'stem with the Add folded in vs oracle')
+    other = make_node('Convolution', [rnd(1, (1, 16, 8, 8)), rnd(2, (8, 16, 3, 3))], conv_data((1, 1), (1, 1), (1, 1)))
+    assert not conv.pre_add_fusable(other)
+
+
 def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     """F(4x4, 3x3) (the layers with extents divisible by 4 and enough patches; forced here): one, odd and many channel
     stages, ragged channel blocks, fewer patches than a workgroup holds, several images, fused bias + ReLU written in place

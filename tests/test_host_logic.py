@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', device.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r' T (pvhip_[a-z0-9_]+)', nm))
     assert declared <= exported
-    assert lib.pvhip_abi_version() == 6
+    assert lib.pvhip_abi_version() == 7
     assert isinstance(lib.pvhip_last_error(), bytes)
 
 
@@ -189,10 +189,15 @@ def test_stream_plan_orders_every_cross_stream_edge():
         G = net.G
         assert set(stream_of.values()) >= ({0, 1, 2} if fuse else {0, 1, 2, 3})      # fused siblings leave three arms per module
 
+        if fuse:                             # data/mean is folded into conv1's input fetch
+            assert {G.nodes[c]['name']: G.nodes[a]['name'] for c, (a, _, _) in ex._pre_add.items()} == {'conv1/7x7_s2/WithoutBiases': 'data/mean'}
+        folded = {a: s for a, _, s in ex._pre_add.values()}
         lead_of = {n: lead for lead, sibs in ex._siblings.items() for s in sibs
                    for n in (s, ex._fusion[s]['add'], ex._fusion[s]['relu']) if n is not None}
 
         def writers(nid):                    # dispatched nodes whose kernels write the tensor `nid` hands on
+            if nid in folded:                # an Add folded into its consumer: the tensor is the Add's own input
+                return writers(folded[nid])
             if nid in lead_of:               # a convolution launched with its sibling
                 return [lead_of[nid]]
             if nid in ex._fused_away and G.nodes[nid]['type'] == 'Concat':
