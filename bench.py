@@ -318,8 +318,9 @@ def main():
                 roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': tf / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic,
                         'kernel': 'conv_wino4_kernel (conv2/3x3, inception 3a / 3b 3x3: Winograd F(4x4,3x3), 36/144 of the algorithmic multiplies) + conv_wino_kernel '
-                                  '(the other seven 3x3 layers: F(2x2,3x3), 16/36) + conv_igemm_dma_kernel (1x1, 5x5; the 1x1 / 3x3_reduce / 5x5_reduce '
-                                  'convolutions of an inception module are one launch) + conv_stem7x7_kernel (conv1): {} launches per step for the 57 '
+                                  '(the other seven 3x3 layers: F(2x2,3x3), 16/36; conv_wino4_kernel<2>: seven 5x5 layers, F(2x2,5x5), 36/100) + conv_igemm_dma_kernel '
+                                  '(conv1, 1x1, the 7x7-sized 5x5; the 1x1 / 3x3_reduce / 5x5_reduce convolutions of an inception module are one launch): '
+                                  '{} launches per step for the 57 '
                                   'Convolution nodes, bias+ReLU fused'.format(n_launch),
                         'launches_per_step': n_launch, 'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_launch_ms * 1e3,
                         'algorithmic_bytes_per_launch': conv['bytes'] / n_launch,

@@ -1003,7 +1003,8 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     const size_t kout_pad = (size_t)round_up_int(k_out, kKoutAlign);
     size_t elems = 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
     elems += stem_pack_elems(k_out, c, kh, kw);      // the 7x7 / 3-channel stem keeps its own panel behind the general one
-    if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c) + wino4_pack_elems(k_out, c);   // 3x3: the Winograd-transformed panels ride along (stride / pad are not known yet)
+    if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c) + wino4_pack_elems(k_out, c);
+    if (kh == 5 && kw == 5) elems += wino4_pack_elems(k_out, c);       // 5x5: the F(2x2,5x5) panel   // 3x3: the Winograd-transformed panels ride along (stride / pad are not known yet)
     return elems;
 }
 
@@ -1020,6 +1021,10 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
                        w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad, rs_major(c, kh, kw) ? 1 : 0);
     if (stem_pack_elems(k_out, c, kh, kw) > 0) {
         const int rc = stem_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out);
+        if (rc) return rc;
+    }
+    if (kh == 5 && kw == 5 && wino4_pack_elems(k_out, c) > 0 && h % 2 == 0 && w % 2 == 0) {
+        const int rc = wino25_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out, c);
         if (rc) return rc;
     }
     if (kh == 3 && kw == 3 && wino_pack_elems(k_out, c) > 0) {
@@ -1083,8 +1088,15 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
     }
     if (pre_add != nullptr)
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_preadd_f32: only the 7x7 / stride 2 / 3-channel stem kernel adds in its fetch (ask pvhip_conv2d_preadd_supported)");
+    if (wino25_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) {
+        const int rc = wino4_conv(2, x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, c, h, w, k_out, bias, relu, act_lo,
+                                  act_hi, a.y_coff, a.y_ctotal);
+        if (rc) return rc;
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
     if (wino4_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) {
-        const int rc = wino4_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad + wino_pack_elems(k_out, c), y, n, c, h, w,
+        const int rc = wino4_conv(4, x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad + wino_pack_elems(k_out, c), y, n, c, h, w,
                                   k_out, bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
         if (rc) return rc;
         PVHIP_LAUNCH_CHECK();

@@ -16,8 +16,12 @@ int    wino_conv(const float* x, const float* u, float* y, int n, int c, int h, 
 bool   wino4_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n);
 size_t wino4_pack_elems(int k, int c);
 int    wino4_pack(const float* w_oihw, float* u, int k, int c);
-int    wino4_conv(const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
+int    wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
                   float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
+
+// F(2x2, 5x5) on the same kernel (m = 2): 5x5 / stride 1 / pad 2 layers with even extents; its panel has wino4_pack_elems floats
+bool   wino25_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n);
+int    wino25_pack(const float* w_oihw, float* u, int k, int c);
 
 // The 7x7 / stride 2 / 3-channel first convolution (pvhip_stem.hip): its own weight panel and persistent kernel
 bool   stem_eligible(int c, int kh, int kw, int sh, int sw, int k_out, int pad_top, int pad_left, unsigned long long out_elems);

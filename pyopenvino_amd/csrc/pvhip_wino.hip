@@ -382,8 +382,62 @@ __device__ __forceinline__ void wino4_at(float m0, float m1, float m2, float m3,
     o3 = __builtin_fmaf(8.0f, d34, d12) + m5;
 }
 
-template <int ABL>   // diagnostic ablations (wrong results on purpose): 1 no gather, 2 no transform, 3 no MFMA, 4 no U DMA, 5 no V store
+// One 6-vector through the A^T of F(2x2, 5x5) = [[1,1,1,1,1,0],[0,1,-1,2,-2,1]]
+__device__ __forceinline__ void wino2_at(float m0, float m1, float m2, float m3, float m4, float m5, float& o0, float& o1) {
+    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    o0 = (m0 + s12) + s34;
+    o1 = __builtin_fmaf(2.0f, d34, d12) + m5;
+}
+
+// U = G g G^T for one (k, c) of a 5x5 kernel: G (6x5) row p = scale_p * [1, p, p^2, p^3, p^4] for the points 0, 1, -1, 2, -2
+// (scales 1/4, -1/6, -1/6, 1/24, 1/24), last row [0,0,0,0,1]; same panel layout as wino4_pack_kernel.
+__global__ __launch_bounds__(kBlock) void wino25_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int K, int C,
+                                                              int n_stages) {
+    constexpr int KB = 32;
+    const int kUStage = kXi4 * kCB * KB;
+    const int total = ((K + KB - 1) / KB) * KB * C;
+    const float G[6][5] = {{0.25f, 0.0f, 0.0f, 0.0f, 0.0f},
+                           {-1.0f / 6.0f, -1.0f / 6.0f, -1.0f / 6.0f, -1.0f / 6.0f, -1.0f / 6.0f},
+                           {-1.0f / 6.0f, 1.0f / 6.0f, -1.0f / 6.0f, 1.0f / 6.0f, -1.0f / 6.0f},
+                           {1.0f / 24.0f, 2.0f / 24.0f, 4.0f / 24.0f, 8.0f / 24.0f, 16.0f / 24.0f},
+                           {1.0f / 24.0f, -2.0f / 24.0f, 4.0f / 24.0f, -8.0f / 24.0f, 16.0f / 24.0f},
+                           {0.0f, 0.0f, 0.0f, 0.0f, 1.0f}};
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int k = e / C, c = e - k * C;
+        float g[5][5];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) g[i / 5][i % 5] = (k < K) ? w[((size_t)k * C + c) * 25 + i] : 0.0f;
+        float r[6][5];                       // G g
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int z = 0; z < 5; ++z) acc += G[i][z] * g[z][q];
+                r[i][q] = acc;
+            }
+        const int kb = k / KB, kl = k % KB, st = c / kCB, cl = c % kCB;
+        float* up = u + ((size_t)kb * (n_stages + 1) + st) * kUStage + cl * KB + kl;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int z = 0; z < 5; ++z) acc += r[i][z] * G[j][z];
+                up[(i * 6 + j) * kCB * KB] = acc;
+            }
+    }
+}
+
+// M = 4: F(4x4, 3x3), pad 1.  M = 2: F(2x2, 5x5), pad 2 -- the same six interpolation points, hence the same B^T, the same 36 products
+// per channel and patch (for 4 outputs of a 5x5 window: 9 per output instead of 25) and the same kernel; only the gather geometry (an
+// aligned 8-byte load per row, TWO columns from each neighbour), the weight transform G (6x5) and the output transform A^T (2x6) differ.
+template <int M, int ABL>   // ABL: diagnostic ablations (wrong results on purpose): 1 no gather, 2 no transform, 3 no MFMA, 4 no U DMA
 __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
+    static_assert(M == 4 || M == 2, "F(4x4,3x3) or F(2x2,5x5)");
+    constexpr int PAD = (M == 4) ? 1 : 2;               // 6 = M + kernel - 1 input rows / columns starting at M*t - PAD
     constexpr int KB = 32, NT = 32, WAVES = 8, CONSUMERS = 6;
     constexpr unsigned kOob = 0x80000000u;
     constexpr int U_PIECES = kXi4 * kCB * KB * 4 / 1024;      // 18 one-KiB pieces per U stage image
@@ -439,10 +493,10 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         // and the last lane of a 32-patch row load their outer column themselves (one more dword load per row, two active
         // lanes per half).  A row in the padding gets an out-of-range offset (the hardware returns 0); columns in the
         // padding (first / last patch column) are zeroed by select.
-        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-        typedef float    float4v __attribute__((ext_vector_type(4)));
-        unsigned rowo[6];                 // byte offset of (row, column 1) of this lane's channel
-        unsigned eoff;                    // edge lanes: byte distance of their outer column from column 1
+        typedef float float4v __attribute__((ext_vector_type(4)));
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        unsigned rowo[6];                 // byte offset of (row, first inner column) of this lane's channel
+        unsigned eoff;                    // edge lanes: byte distance of their outer column(s) from the first inner column
         bool     zlo, zhi;
         const bool first = l31 == 0, last = l31 == 31;
         {
@@ -450,32 +504,41 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             const bool live = t < a.T;
             const int  n = live ? t / TPI : 0, rem = live ? t - n * TPI : 0;
             const int  ty = rem / a.TX, tx = rem - ty * a.TX;
-            const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + 4 * tx) * 4u;
+            const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + M * tx) * 4u;
             zlo = tx == 0;
             zhi = tx == a.TX - 1;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                const int iy = 4 * ty - 1 + r;
+                const int iy = M * ty - PAD + r;
                 rowo[r] = (live && (unsigned)iy < (unsigned)a.H) ? base + (unsigned)(iy * a.W) * 4u : kOob + 16u;
             }
-            // first lane: column 0 (4 bytes before column 1; on the left border the value is zeroed anyway: stay in place);
-            // last lane: column 5 (16 bytes after; on the right border: 12); other lanes: the load is masked off
-            eoff = first ? (zlo ? 0u : 0xFFFFFFFCu) : (zhi ? 12u : 16u);
+            // M = 4: inner columns 1..4 are the lane's own 16 bytes; first lane: column 0 (4 bytes before; on the left border the
+            // value is zeroed anyway: stay in place); last lane: column 5 (16 bytes after; on the right border: 12).
+            // M = 2: inner columns 2..3 are the lane's own 8 bytes; first lane: columns 0..1 (8 bytes before), last: 4..5 (8 after).
+            if (M == 4) eoff = first ? (zlo ? 0u : 0xFFFFFFFCu) : (zhi ? 12u : 16u);
+            else        eoff = first ? (zlo ? 0u : 0xFFFFFFF8u) : (zhi ? 0u : 8u);
         }
-        float4v vA[6], vB[6];
-        float   eA[6], eB[6];
+        float vA[6][4], vB[6][4];         // M = 2 uses [0..1]
+        float eA[6][2], eB[6][2];         // M = 4 uses [0]
 #define PVW4_GATHER(v_, e_, s_)                                                                                  \
     {                                                                                                            \
         const int se_ = (s_) < a.n_stages ? (s_) : a.n_stages - 1;     /* past the end: the last stage again (unused) */ \
         const unsigned soff = (unsigned)(se_ * kCB) * chan_bytes;                                                \
         _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
+            const unsigned eo_ = (first || last) ? rowo[r] + eoff : kOob;                                        \
             if (ABL == 1) {                                                                                      \
-                v_[r] = (float4v)(__builtin_bit_cast(float, rowo[r] + soff));                                    \
-                e_[r] = 0.0f;                                                                                    \
-            } else {                                                                                             \
+                v_[r][0] = v_[r][1] = v_[r][2] = v_[r][3] = __builtin_bit_cast(float, rowo[r] + soff);           \
+                e_[r][0] = e_[r][1] = 0.0f;                                                                      \
+            } else if (M == 4) {                                                                                 \
                 /* the WHOLE vector is cast: hipcc (ROCm 7.2) lowers a b128 load whose lanes are cast one by one to a dword load */ \
-                v_[r] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(xr, rowo[r], soff, 0)); \
-                e_[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (first || last) ? rowo[r] + eoff : kOob, soff, 0)); \
+                const float4v q4 = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(xr, rowo[r], soff, 0)); \
+                v_[r][0] = q4.x; v_[r][1] = q4.y; v_[r][2] = q4.z; v_[r][3] = q4.w;                              \
+                e_[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, eo_, soff, 0));    \
+            } else {                                                                                             \
+                const float2v q2 = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(xr, rowo[r], soff, 0)); \
+                const float2v e2 = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(xr, eo_, soff, 0)); \
+                v_[r][0] = q2.x; v_[r][1] = q2.y;                                                                \
+                e_[r][0] = e2.x; e_[r][1] = e2.y;                                                                \
             }                                                                                                    \
         }                                                                                                        \
     }
@@ -485,18 +548,19 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         _Pragma("unroll") for (int q = 0; q < 6; ++q) {                 /* columns: m = B^T d */                  \
             float c[6];                                                                                          \
             _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                      \
-                if (q == 0) {            /* left neighbour's column 4 (wave_shr:1), own load in the first lane */ \
-                    float src_ = v_[r].w;        /* opaque FLOAT copy first: an integer cast of the element folds back into */ \
-                    asm volatile("" : "+v"(src_));  /* "element of the loaded <4 x i32>", which hipcc lowers to element 0     */ \
+                constexpr int IN0 = (M == 4) ? 1 : 2, NIN = M;      /* own (inner) columns IN0 .. IN0 + NIN - 1 */ \
+                if (q < IN0) {           /* from the left neighbour's last inner columns (wave_shr:1), own load in the first lane */ \
+                    float src_ = v_[r][NIN - IN0 + q];   /* opaque FLOAT copy: an integer cast of a loaded element folds back into */ \
+                    asm volatile("" : "+v"(src_));        /* "element i of the loaded vector", which hipcc lowers to element 0      */ \
                     const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x138, 0xf, 0xf, false)); \
-                    c[r] = zlo ? 0.0f : (first ? e_[r] : nb);                                                    \
-                } else if (q == 5) {     /* right neighbour's column 1 (wave_shl:1), own load in the last lane */ \
-                    float src_ = v_[r].x;                                                                        \
+                    c[r] = zlo ? 0.0f : (first ? e_[r][q] : nb);                                                 \
+                } else if (q >= IN0 + NIN) {   /* from the right neighbour's first inner columns (wave_shl:1), own load in the last lane */ \
+                    float src_ = v_[r][q - IN0 - NIN];                                                           \
                     asm volatile("" : "+v"(src_));                                                               \
                     const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x130, 0xf, 0xf, false)); \
-                    c[r] = zhi ? 0.0f : (last ? e_[r] : nb);                                                     \
+                    c[r] = zhi ? 0.0f : (last ? e_[r][q - IN0 - NIN] : nb);                                      \
                 } else {                                                                                         \
-                    c[r] = q == 1 ? v_[r].x : (q == 2 ? v_[r].y : (q == 3 ? v_[r].z : v_[r].w));                 \
+                    c[r] = v_[r][q - IN0];                                                                       \
                 }                                                                                                \
             }                                                                                                    \
             if (ABL == 2) { _Pragma("unroll") for (int r = 0; r < 6; ++r) m[r * 6 + q] = c[r]; }                 \
@@ -569,58 +633,65 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     }
 #undef PVW4_LOAD_U
 
-    // ---- output transform Y = A^T D A: the column half in registers (consumer i holds row i), the rows meet in LDS,
-    // 16 channels at a time: Ex[i][c'][k16][patch] = 48 KB of the 72.
+    // ---- output transform Y = A^T D A (A^T: M x 6): the column half in registers (consumer i holds row i), the rows meet in
+    // LDS, CH channels at a time: Ex[i][c'][CH][patch] = 6 * M * CH * 32 floats = 48 KB of the 72 (M = 4: 16 channels, M = 2: 32).
+    constexpr int CH = (M == 4) ? 16 : 32, PASSES = 32 / CH;
     float* Ex = &Us[0][0][0][0];
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
                                                                         a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
     const int OH = a.H, OW = a.W;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (half == 1) __syncthreads();
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass == 1) __syncthreads();
         if (wid < CONSUMERS) {
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                const int r  = half * 8 + r8;
-                const int kl = (r8 & 3) + 8 * (r8 >> 2) + 4 * lh;           // channel inside the half: 0..15
-                float s0, s1, s2, s3;
-                wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], s0, s1, s2, s3);
-                Ex[((wid * 4 + 0) * 16 + kl) * 32 + l31] = s0;
-                Ex[((wid * 4 + 1) * 16 + kl) * 32 + l31] = s1;
-                Ex[((wid * 4 + 2) * 16 + kl) * 32 + l31] = s2;
-                Ex[((wid * 4 + 3) * 16 + kl) * 32 + l31] = s3;
+            for (int rr = 0; rr < CH / 2; ++rr) {
+                const int r  = pass * (CH / 2) + rr;                          // accumulator register
+                const int kl = (rr & 3) + 8 * (rr >> 2) + 4 * lh;             // channel inside the pass: 0 .. CH-1
+                float so[4];
+                if (M == 4) wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1], so[2], so[3]);
+                else        wino2_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1]);
+#pragma unroll
+                for (int c2 = 0; c2 < M; ++c2) Ex[((wid * M + c2) * CH + kl) * 32 + l31] = so[c2];
             }
         }
         __syncthreads();
-        const int tl = tid & 31, kl = tid >> 5;                               // 512 threads = 16 channels x 32 patches
+        const int tl = tid & 31;                                              // 512 threads = 16 channels x 32 patches per sweep
         const int t  = tb * NT + tl;
-        const int kg = kb * KB + half * 16 + kl;
-        if (t < a.T && kg < a.K) {
-            const int n = t / TPI, rem = t - n * TPI;
-            const int ty = rem / a.TX, tx = rem - ty * a.TX;
-            const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)kg * 4u, 0, 0));
-            float* __restrict__ yp = a.y + (((size_t)n * a.y_ctotal + a.y_coff + kg) * OH + 4 * ty) * OW + 4 * tx;
-            float yv[4][4];
 #pragma unroll
-            for (int c2 = 0; c2 < 4; ++c2) {
-                float e[6];
+        for (int sweep = 0; sweep < CH / 16; ++sweep) {
+            const int kl = (tid >> 5) + 16 * sweep;
+            const int kg = kb * KB + pass * CH + kl;
+            if (t < a.T && kg < a.K) {
+                const int n = t / TPI, rem = t - n * TPI;
+                const int ty = rem / a.TX, tx = rem - ty * a.TX;
+                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)kg * 4u, 0, 0));
+                float* __restrict__ yp = a.y + (((size_t)n * a.y_ctotal + a.y_coff + kg) * OH + M * ty) * OW + M * tx;
+                float yv[M][M];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) e[i] = Ex[((i * 4 + c2) * 16 + kl) * 32 + tl];
-                wino4_at(e[0], e[1], e[2], e[3], e[4], e[5], yv[0][c2], yv[1][c2], yv[2][c2], yv[3][c2]);
-            }
+                for (int c2 = 0; c2 < M; ++c2) {
+                    float e[6], col[4];
 #pragma unroll
-            for (int r2 = 0; r2 < 4; ++r2) {
-                float4 o;
-                float* ov = reinterpret_cast<float*>(&o);
+                    for (int i = 0; i < 6; ++i) e[i] = Ex[((i * M + c2) * CH + kl) * 32 + tl];
+                    if (M == 4) wino4_at(e[0], e[1], e[2], e[3], e[4], e[5], col[0], col[1], col[2], col[3]);
+                    else        wino2_at(e[0], e[1], e[2], e[3], e[4], e[5], col[0], col[1]);
 #pragma unroll
-                for (int c2 = 0; c2 < 4; ++c2) {
-                    float v = yv[r2][c2];
-                    if (a.bias != nullptr) v = v + bv;
-                    if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;
-                    else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
-                    ov[c2] = v;
+                    for (int r2 = 0; r2 < M; ++r2) yv[r2][c2] = col[r2];
                 }
-                *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = o;
+#pragma unroll
+                for (int r2 = 0; r2 < M; ++r2) {
+                    float ov[M];
+#pragma unroll
+                    for (int c2 = 0; c2 < M; ++c2) {
+                        float v = yv[r2][c2];
+                        if (a.bias != nullptr) v = v + bv;
+                        if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;
+                        else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                        ov[c2] = v;
+                    }
+                    if (M == 4) *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                    else        *reinterpret_cast<float2*>(yp + (size_t)r2 * OW) = make_float2(ov[0], ov[1]);
+                }
             }
         }
     }
@@ -707,6 +778,29 @@ bool wino4_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_
     return patches >= min_patches;
 }
 
+// F(2x2, 5x5): 5x5 / stride 1 / pad 2 ("same"), even extents, C a multiple of 4, enough patches (PVHIP_CONV_WINOGRAD5=0 switches it
+// off, =force drops the size rule)
+bool wino25_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n) {
+    const char* e = getenv("PVHIP_CONV_WINOGRAD5");
+    if (e != nullptr && e[0] == '0') return false;
+    const char* e3 = getenv("PVHIP_CONV_WINOGRAD");
+    if (e3 != nullptr && e3[0] == '0') return false;
+    if (!(kh == 5 && kw == 5 && sh == 1 && sw == 1 && pad_top == 2 && pad_left == 2 && oh == h && ow == w && c % kCB == 0 && c >= kCB))
+        return false;
+    if (h % 2 != 0 || w % 2 != 0) return false;
+    const long patches = (long)n * (h / 2) * (w / 2);
+    return patches >= ((e != nullptr && e[0] == 'f') ? 1 : 32L * kNumCU);
+}
+
+int wino25_pack(const float* w_oihw, float* u, int k, int c) {
+    const size_t elems = wino4_pack_elems(k, c);
+    hipError_t   e     = hipMemsetAsync(u, 0, elems * sizeof(float), state().stream);
+    if (e != hipSuccess) return fail(PVHIP_EHIP, "wino25_pack: hipMemsetAsync -> %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(wino25_pack_kernel, dim3(grid_for((size_t)((k + 31) / 32) * 32 * c)), dim3(kBlock), 0, state().stream, w_oihw,
+                       u, k, c, c / kCB);
+    return PVHIP_OK;
+}
+
 size_t wino4_pack_elems(int k, int c) {
     if (c % kCB != 0) return 0;
     return (size_t)((k + 31) / 32) * (size_t)(c / kCB + 1) * kXi4 * kCB * 32;
@@ -721,12 +815,12 @@ int wino4_pack(const float* w_oihw, float* u, int k, int c) {
     return PVHIP_OK;
 }
 
-int wino4_conv(const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
+int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, int h, int w, int k_out, const float* bias, int act,
                float act_lo, float act_hi, int out_channel_offset, int out_channels_total) {
     WinoArgs a;
     a.x = x; a.u = u; a.y = y; a.bias = bias;
     a.N = n; a.C = c; a.H = h; a.W = w; a.K = k_out;
-    a.TY = h / 4; a.TX = w / 4;
+    a.TY = h / m; a.TX = w / m;
     a.T  = n * a.TY * a.TX;
     a.n_kb = (k_out + 31) / 32;
     a.n_stages = c / kCB;
@@ -739,13 +833,16 @@ int wino4_conv(const float* x, const float* u, float* y, int n, int c, int h, in
     const dim3 grid((unsigned)(n_tb * a.n_kb));
     int abl = 0;
     if (const char* e = getenv("PVHIP_WINO4_ABLATE")) abl = atoi(e);      // diagnostic builds of the kernel: results are wrong on purpose
+    if (m == 2) {
+        hipLaunchKernelGGL((conv_wino4_kernel<2, 0>), grid, dim3(512), 0, state().stream, a);
+        return PVHIP_OK;
+    }
     switch (abl) {
-        case 1: hipLaunchKernelGGL(conv_wino4_kernel<1>, grid, dim3(512), 0, state().stream, a); break;
-        case 2: hipLaunchKernelGGL(conv_wino4_kernel<2>, grid, dim3(512), 0, state().stream, a); break;
-        case 3: hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, dim3(512), 0, state().stream, a); break;
-        case 4: hipLaunchKernelGGL(conv_wino4_kernel<4>, grid, dim3(512), 0, state().stream, a); break;
-        case 5: hipLaunchKernelGGL(conv_wino4_kernel<5>, grid, dim3(512), 0, state().stream, a); break;
-        default: hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, dim3(512), 0, state().stream, a);
+        case 1: hipLaunchKernelGGL((conv_wino4_kernel<4, 1>), grid, dim3(512), 0, state().stream, a); break;
+        case 2: hipLaunchKernelGGL((conv_wino4_kernel<4, 2>), grid, dim3(512), 0, state().stream, a); break;
+        case 3: hipLaunchKernelGGL((conv_wino4_kernel<4, 3>), grid, dim3(512), 0, state().stream, a); break;
+        case 4: hipLaunchKernelGGL((conv_wino4_kernel<4, 4>), grid, dim3(512), 0, state().stream, a); break;
+        default: hipLaunchKernelGGL((conv_wino4_kernel<4, 0>), grid, dim3(512), 0, state().stream, a);
     }
     return PVHIP_OK;
 }

@@ -502,7 +502,7 @@ class Executable_Network:
 
         # An Add of a per-channel Const whose only consumer is a convolution that adds in its own input fetch (the 7x7 stem
         # behind data/mean): the Add is not dispatched, the convolution reads the Add's input and receives the constant.
-        if getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False):
+        if getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False) and os.environ.get('PVHIP_FUSE_PREADD', '1') != '0':
             for cid in G.nodes:
                 if G.nodes[cid]['type'] != 'Convolution' or cid in self._fused_away:
                     continue

@@ -9,28 +9,33 @@ sys.path.insert(0, REPO)
 from pyopenvino_amd import device as dev, synth
 from pyopenvino_amd.op_plugins import Convolution
 
-LAYERS = [('conv2/3x3', (256, 64, 56, 56), 192), ('3a/3x3', (256, 96, 28, 28), 128), ('3b/3x3', (256, 128, 28, 28), 192),
-          ('4e/3x3', (256, 160, 14, 14), 320)]
+LAYERS = [('conv2/3x3', (256, 64, 56, 56), 192, 3), ('3a/3x3', (256, 96, 28, 28), 128, 3), ('3b/3x3', (256, 128, 28, 28), 192, 3),
+          ('4e/3x3', (256, 160, 14, 14), 320, 3),
+          ('3a/5x5', (256, 16, 28, 28), 32, 5), ('3b/5x5', (256, 32, 28, 28), 96, 5), ('4a/5x5', (256, 16, 14, 14), 48, 5),
+          ('4b/5x5', (256, 24, 14, 14), 64, 5), ('4d/5x5', (256, 32, 14, 14), 64, 5), ('4e/5x5', (256, 32, 14, 14), 128, 5)]
 dev.init(0)
 only = sys.argv[1] if len(sys.argv) > 1 else ''
-for name, xs, k in LAYERS:
+for name, xs, k, ks in LAYERS:
     if only not in name:
         continue
     n, c, h, w = xs
     x = dev.DeviceTensor.from_numpy(synth.normal(1, 2, n * c * h * w).astype(np.float32).reshape(xs))
-    wt = dev.DeviceTensor.from_numpy((synth.normal(3, 4, k * c * 9) * (2.0 / (c * 9)) ** 0.5).astype(np.float32).reshape((k, c, 3, 3)))
+    wt = dev.DeviceTensor.from_numpy((synth.normal(3, 4, k * c * ks * ks) * (2.0 / (c * ks * ks)) ** 0.5).astype(np.float32).reshape((k, c, ks, ks)))
     b = dev.DeviceTensor.from_numpy(np.zeros((1, k, 1, 1), dtype=np.float32))
-    gf = 2.0 * n * k * c * 9 * h * w / 1e9
+    gf = 2.0 * n * k * c * ks * ks * h * w / 1e9
     line = '{:10s} {:6.1f} GFLOP |'.format(name, gf)
     outs = {}
     variants = [('F(4x4)', {'PVHIP_CONV_WINOGRAD4': 'force'}), ('F(2x2)', {'PVHIP_CONV_WINOGRAD4': '0'}), ('direct', {'PVHIP_CONV_WINOGRAD': '0'})]
+    if ks == 5:
+        variants = [('F(4x4)', {'PVHIP_CONV_WINOGRAD5': 'force'}), ('F(2x2)', {'PVHIP_CONV_WINOGRAD5': 'force'}), ('direct', {'PVHIP_CONV_WINOGRAD5': '0'})]
     if os.environ.get('ABLATE'):
         variants = [('F(4x4)', {'PVHIP_CONV_WINOGRAD4': 'force'})] + [('abl%s' % a_, {'PVHIP_CONV_WINOGRAD4': 'force', 'PVHIP_WINO4_ABLATE': a_}) for a_ in os.environ['ABLATE'].split(',')] + [('direct', {'PVHIP_CONV_WINOGRAD': '0'}), ('F(2x2)', {'PVHIP_CONV_WINOGRAD4': '0'})]
     for tag, env in variants:
         for k_, v_ in env.items():
             os.environ[k_] = v_
         node = {}
-        run = lambda: Convolution.launch(node, x, wt, (1, 1), (1, 1), (1, 1), 'explicit', bias=b, act=('relu',))
+        pd = (ks // 2, ks // 2)
+        run = lambda: Convolution.launch(node, x, wt, (1, 1), pd, pd, 'explicit', bias=b, act=('relu',))
         for _ in range(3):
             y = run()
         dev.synchronize()

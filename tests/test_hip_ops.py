@@ -106,6 +106,7 @@ def test_conv_stem_7x7_stride2(hip, monkeypatch):
     than workgroups and more, K below 64, asymmetric / no padding, fused bias + ReLU written in place into a wider tensor;
     against the oracle and against the general kernel."""
     from pyopenvino_amd import device as dev
+    monkeypatch.setenv('PVHIP_CONV_STEM', '1')
     cases = [((2, 3, 224, 224), 64, (3, 3), (3, 3)), ((1, 3, 23, 31), 40, (3, 3), (3, 3)), ((3, 3, 40, 17), 7, (0, 0), (0, 0)),
              ((5, 3, 64, 64), 64, (2, 3), (1, 0)), ((1, 3, 7, 7), 3, (0, 0), (0, 0)), ((70, 3, 30, 30), 16, (3, 3), (3, 3))]
     for xs, k, pb, pe in cases:
@@ -127,10 +128,11 @@ def test_conv_stem_7x7_stride2(hip, monkeypatch):
     assert np.all(got[:, :5] == -1.0) and np.all(got[:, 29:] == -1.0)
 
 
-def test_conv_stem_with_the_add_in_front_folded_in_is_bit_identical(hip):
+def test_conv_stem_with_the_add_in_front_folded_in_is_bit_identical(hip, monkeypatch):
     """Add(per-channel Const) -> 7x7 / stride 2 convolution handed over as one call (node['_fuse_pre_add']): the kernel adds
     while it fetches its input patch, padding stays zero -- the bits of the two launches; other convolutions decline."""
     from pyopenvino_amd import device as dev
+    monkeypatch.setenv('PVHIP_CONV_STEM', '1')
     conv, add = hip_plugin('Convolution'), hip_plugin('Add')
     x = rnd(7, (3, 3, 45, 38), 60.0, 100.0)
     m = np.array([-104.0, -117.0, -123.0], dtype=np.float32).reshape(1, 3, 1, 1)
@@ -149,6 +151,31 @@ def test_conv_stem_with_the_add_in_front_folded_in_is_bit_identical(hip):
     assert_close(got, oracle, helpers.REL_TOL, 'stem with the Add folded in vs oracle')
     other = make_node('Convolution', [rnd(1, (1, 16, 8, 8)), rnd(2, (8, 16, 3, 3))], conv_data((1, 1), (1, 1), (1, 1)))
     assert not conv.pre_add_fusable(other)
+
+
+def test_conv_winograd_f2x2_5x5(hip, monkeypatch):
+    """F(2x2, 5x5) on the F(4x4, 3x3) kernel (5x5 / stride 1 / pad 2 layers with even extents; forced here): one, odd and many
+    channel stages, ragged channel blocks, fewer patches than a workgroup holds, patch rows that end inside a 32-patch block,
+    fused bias + ReLU written in place into a wider tensor; against the oracle and against the direct kernel."""
+    from pyopenvino_amd import device as dev
+    monkeypatch.setenv('PVHIP_CONV_WINOGRAD5', 'force')
+    cases = [((2, 4, 8, 8), 5), ((3, 20, 12, 14), 70), ((1, 16, 28, 28), 32), ((2, 32, 14, 14), 96), ((5, 8, 2, 2), 3), ((1, 12, 4, 22), 33)]
+    for xs, k in cases:
+        x = rnd(sum(xs), xs)
+        w = rnd(k, (k, xs[1], 5, 5), (2.0 / (xs[1] * 25)) ** 0.5)
+        err = vs_oracle('Convolution', [x, w], conv_data((1, 1), (2, 2), (2, 2)), 'winograd F(2x2,5x5) {} k{}'.format(xs, k))
+        assert err <= 5e-5, 'winograd F(2x2,5x5) {}: {:.2e}'.format(xs, err)
+    x, w, b = np.abs(rnd(1, (2, 24, 10, 6))), rnd(2, (40, 24, 5, 5), 0.1), rnd(3, (1, 40, 1, 1), 0.3)
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (2, 2), (2, 2)))
+    wide = dev.DeviceTensor.from_numpy(np.full((2, 50, 10, 6), -1.0, dtype=np.float32))
+    fused = dict(node)
+    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
+    hip_plugin('Convolution').compute(fused, {0: x, 1: w})
+    got = np.asarray(wide)
+    monkeypatch.setenv('PVHIP_CONV_WINOGRAD5', '0')
+    direct = np.maximum(first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w})) + b, 0)
+    assert_close(got[:, 7:47], direct, 2e-5, 'winograd F(2x2,5x5) fused vs direct')
+    assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
 
 
 def test_conv_winograd_f4x4_3x3(hip, monkeypatch):

@@ -178,19 +178,26 @@ def test_bench_work_model_matches_survey_totals():
     assert abs(relu_bytes / 1e6 - 2 * 12.905) < 0.01
 
 
-def test_stream_plan_orders_every_cross_stream_edge():
-    """plan_streams on GoogLeNet (fused, Concat-eliminated) and on the unfused graph: every producer a node
-    reads from is either on the node's own stream or in its wait list (and records an event); the four arms
-    of an inception module land on four different streams; a host plugin set gets no plan."""
-    for fuse in (True, False):
+def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
+    """plan_streams on GoogLeNet (fused, Concat-eliminated; with and without the opt-in stem kernel, which folds data/mean
+    into conv1) and on the unfused graph: every producer a node reads from is either on the node's own stream or in its
+    wait list (and records an event); the four arms of an inception module land on four different streams; a host plugin
+    set gets no plan."""
+    for fuse, stem in ((True, False), (True, True), (False, False)):
+        if stem:
+            monkeypatch.setenv('PVHIP_CONV_STEM', '1')
+        else:
+            monkeypatch.delenv('PVHIP_CONV_STEM', raising=False)
         _, net, ex = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=fuse)
         ex.compute_streams = 4
         stream_of, waits, records = ex.plan_streams()
         G = net.G
         assert set(stream_of.values()) >= ({0, 1, 2} if fuse else {0, 1, 2, 3})      # fused siblings leave three arms per module
 
-        if fuse:                             # data/mean is folded into conv1's input fetch
+        if fuse and stem:                    # data/mean is folded into conv1's input fetch
             assert {G.nodes[c]['name']: G.nodes[a]['name'] for c, (a, _, _) in ex._pre_add.items()} == {'conv1/7x7_s2/WithoutBiases': 'data/mean'}
+        else:
+            assert not ex._pre_add
         folded = {a: s for a, _, s in ex._pre_add.values()}
         lead_of = {n: lead for lead, sibs in ex._siblings.items() for s in sibs
                    for n in (s, ex._fusion[s]['add'], ex._fusion[s]['relu']) if n is not None}
