@@ -285,6 +285,9 @@ def main():
                         fl, by = fl + sfl, by + sby - in_bytes
                     work[nid] = (fl, by)
                     all_nodes[nid] = [typ, name + ' (+{} siblings)'.format(len(sibs)), ms]
+                pin = getattr(ex, '_pool_conv', {}).get(nid)
+                if pin is not None:      # MaxPool folded into this 1x1 convolution (still a Convolution launch: same flops, same bytes)
+                    all_nodes[nid] = [typ, net.G.nodes[pin[0]]['name'] + ' + ' + name, ms]
                 pooled = getattr(ex, '_lrn_pool', {}).get(nid)
                 if pooled is not None:   # LRN and the MaxPool behind it as one launch: reads the LRN input once, writes the pooled tensor once
                     typ = 'LRN+MaxPool'

@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   7
+#define PVHIP_ABI_VERSION   8
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -177,6 +177,15 @@ int    pvhip_conv2d_preadd_f32(const float* x, const float* pre_add, const float
                                int sh, int sw, int pad_top, int pad_left,
                                const float* bias, int relu,
                                int out_channel_offset, int out_channels_total,
+                               float act_lo, float act_hi);
+/* MaxPool.py:41-72 (3x3 window, stride 1, pad 1 all round: output extent = input extent) followed by a 1x1 / stride 1 / unpadded
+ * Convolution.py:57-87, as one launch: y = conv1x1(maxpool(x)); the pooled tensor is never written.  Bit-identical to
+ * pvhip_maxpool2d_f32 followed by pvhip_conv2d_f32.  x is (n, c, h, w); wpack the pvhip_conv2d_pack_f32 panel of the (k_out, c, 1, 1)
+ * weights; bias / act / out_channel_offset / out_channels_total / act_lo / act_hi as for pvhip_conv2d_f32.  Covers c % 16 == 0,
+ * even w, k_out <= 128 (pvhip_conv2d_pooled_supported; no device needed); PVHIP_EUNSUPPORTED otherwise.                           */
+int    pvhip_conv2d_pooled_supported(int n, int c, int h, int w, int k_out);
+int    pvhip_conv2d_pooled_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out,
+                               const float* bias, int act, int out_channel_offset, int out_channels_total,
                                float act_lo, float act_hi);
 /* Several Convolution.py:149-176 calls that share their input (the 1x1, 3x3_reduce and 5x5_reduce arms of an inception
  * module) as ONE launch: the input is read once and the small arms ride in the big one's grid.  Only 1x1 / stride 1 /

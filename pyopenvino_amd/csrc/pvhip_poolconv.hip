@@ -1,0 +1,296 @@
+// 3x3 / stride 1 / pad 1 MaxPool followed by a 1x1 convolution (the pool -> pool_proj arm of an inception module) as ONE
+// launch: the pooled tensor -- as large as the module's input, written once and read once -- never exists.
+//
+// Replaces MaxPool.py:41-72 followed by Convolution.py:57-87 for that pair.  The 1x1 convolution is the implicit GEMM of
+// pvhip_conv.hip (D[k_out][pixel], v_mfma_f32_32x32x2_f32, weights from the packed K-major panel by LDS-DMA, same
+// reduction order: the result carries the bits of the two launches); what changes is where the B tile [16 channels][128
+// pixels] of a stage comes from.  Waves 0-3 are CONSUMERS (wave w: pixels 32w .. 32w+31 of the tile, all BM output
+// channels).  Waves 4-7 are PRODUCERS: lane <-> (group of VEC adjacent pixels, channel); per channel it loads the three
+// rows of its group (one aligned vector each) and the two neighbouring columns, takes the 3x3 max and writes VEC pooled
+// values into the B tile.  Zero padding is what the reference pools over (MaxPool.py:53: the pad cells hold 0.0 and take
+// part in the max): a row or column outside the image is an out-of-range buffer offset, for which the hardware returns
+// 0.0 -- no window logic at all.  NaN wins, as np.max.  The loads of the next stage's groups are issued as soon as a
+// group's registers are free, so a whole stage of them is always in flight.
+#include <cstdlib>
+
+#include "pvhip_common.h"
+
+using namespace pvhip;
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int kBK = 16;
+
+struct PoolConvArgs {
+    const float* x;
+    const float* wp;      // [kred_pad + spare][kout_pad], rows = input channels (the pointwise panel of pvhip_conv2d_pack_f32)
+    float*       y;
+    const float* bias;
+    int N, C, H, W, K;
+    int kout_pad, n_mtiles;
+    int P;                // N*H*W
+    unsigned x_bytes, wp_bytes;
+    int   relu;
+    float act_lo, act_hi;
+    int y_ctotal, y_coff;
+};
+
+__device__ __forceinline__ void pc_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds = (unsigned)(unsigned long)(lds_ptr_t)dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
+}
+
+template <int BM, int VEC>
+__global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
+    constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
+    constexpr int CONSUMERS = 4, PRODUCERS = 4;
+    constexpr int A_PIECES = kBK * BM * 4 / 1024, A_PER_WAVE = (A_PIECES + CONSUMERS - 1) / CONSUMERS;
+    constexpr int GROUPS = BN / VEC;                 // pixel groups per channel row of the tile
+    constexpr int CSUB = PRODUCERS * kWave / GROUPS;  // channels the producer lanes cover at once
+    constexpr int ITER = kBK / CSUB;                 // producer iterations per stage
+    constexpr unsigned kOob = 0x80000000u;
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+
+    __shared__ __attribute__((aligned(1024))) float As[2][kBK][BM];
+    __shared__ __attribute__((aligned(1024))) float Bs[2][kBK][BN];
+
+    const int nwg = gridDim.x;
+    int       lid;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt    = lid % a.n_mtiles;
+    const int ptile = lid / a.n_mtiles;
+    const int m0    = mt * BM;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW = a.H * a.W;
+    const int nk = a.C / kBK;
+    const unsigned chan_bytes = (unsigned)HW * 4u;
+
+    floatx16 acc[TM];
+    if (wid >= CONSUMERS) {
+        // ------------------------------------------------------------------ producers
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+        const int pl = (wid - CONSUMERS) * kWave + lane;       // 0 .. 255
+        const int g = pl % GROUPS, cc = pl / GROUPS;
+        // byte offsets of this lane's group in rows y-1, y, y+1 (channel cc of the stage; image and pixel folded in) and of
+        // the columns left and right of it; whatever lies outside the image is out of range and reads as the pad value 0.0
+        unsigned offv[3], offl[3], offr[3];
+        {
+            const int gp = ptile * BN + g * VEC;
+            const bool live = gp < a.P;
+            const int n = live ? gp / HW : 0, rem = live ? gp - n * HW : 0;
+            const int y = rem / a.W, x0 = rem - y * a.W;
+            const unsigned base = (unsigned)((n * a.C + cc) * HW + x0) * 4u;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int  iy = y - 1 + r;
+                const bool ok = live && (unsigned)iy < (unsigned)a.H;
+                offv[r] = ok ? base + (unsigned)(iy * a.W) * 4u : kOob;
+                offl[r] = (ok && x0 > 0) ? base + (unsigned)(iy * a.W) * 4u - 4u : kOob;
+                offr[r] = (ok && x0 + VEC < a.W) ? base + (unsigned)(iy * a.W) * 4u + (unsigned)VEC * 4u : kOob;
+            }
+        }
+        float ring[ITER][3][VEC + 2];       // per iteration and row: left neighbour, the group, right neighbour
+#define PVP_LOAD(it_, s_)                                                                                        \
+    {                                                                                                            \
+        const int se_ = (s_) < nk ? (s_) : nk - 1;                 /* past the end: the last stage again (unused) */ \
+        const unsigned soff = (unsigned)(se_ * kBK + (it_) * CSUB) * chan_bytes;                                 \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
+            ring[it_][r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offl[r], soff, 0)); \
+            if (VEC == 4) {                                                                                      \
+                typedef float f4_ __attribute__((ext_vector_type(4)));     /* whole-vector cast: see pvhip_wino.hip */ \
+                const f4_ q_ = __builtin_bit_cast(f4_, __builtin_amdgcn_raw_buffer_load_b128(xr, offv[r], soff, 0)); \
+                ring[it_][r][1] = q_.x; ring[it_][r][2] = q_.y; ring[it_][r][3] = q_.z; ring[it_][r][VEC] = q_.w; \
+            } else {                                                                                             \
+                typedef float f2_ __attribute__((ext_vector_type(2)));                                           \
+                const f2_ q_ = __builtin_bit_cast(f2_, __builtin_amdgcn_raw_buffer_load_b64(xr, offv[r], soff, 0)); \
+                ring[it_][r][1] = q_.x; ring[it_][r][VEC] = q_.y;                                                \
+            }                                                                                                    \
+            ring[it_][r][VEC + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offr[r], soff, 0)); \
+        }                                                                                                        \
+    }
+        // 3x3 max of iteration it_ into the B tile of buffer buf_ (columns first: one max3 and one NaN test per column of the
+        // group's 3 x (VEC + 2) patch, then a max3 over three adjacent columns per pixel), then the same registers fetch stage s_next_
+#define PVP_POOL(it_, buf_, s_next_)                                                                             \
+    {                                                                                                            \
+        float cm_[VEC + 2];                                                                                      \
+        bool  cn_[VEC + 2];                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < VEC + 2; ++c) {                                                    \
+            const float e0 = ring[it_][0][c], e1 = ring[it_][1][c], e2 = ring[it_][2][c];                        \
+            cm_[c] = fmaxf(fmaxf(e0, e1), e2);                                                                   \
+            cn_[c] = __builtin_isunordered(e0, e1) | (e2 != e2);                                                 \
+        }                                                                                                        \
+        vec_t o_;                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < VEC; ++i)                                                          \
+            o_[i] = (cn_[i] | cn_[i + 1] | cn_[i + 2]) ? NAN : fmaxf(fmaxf(cm_[i], cm_[i + 1]), cm_[i + 2]);     \
+        *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = o_;                                   \
+        PVP_LOAD(it_, s_next_);                                                                                  \
+    }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) PVP_LOAD(it, 0);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) PVP_POOL(it, 0, 1);
+        __syncthreads();
+        for (int s = 0; s < nk; ++s) {
+            const int buf = s & 1;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) PVP_POOL(it, buf ^ 1, s + 2);     // B(s+1); past the end: an unused tile
+            __syncthreads();
+        }
+#undef PVP_LOAD
+#undef PVP_POOL
+    } else {
+        // ------------------------------------------------------------------ consumers
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wp_bytes, 0x00020000);
+        unsigned avoff[A_PER_WAVE];
+#pragma unroll
+        for (int q = 0; q < A_PER_WAVE; ++q) {
+            const int f = (wid + CONSUMERS * q) * 256 + lane * 4;
+            avoff[q]    = (unsigned)((f / BM) * a.kout_pad + m0 + (f % BM)) * 4u;
+        }
+        const unsigned a_stage_bytes = (unsigned)(kBK * a.kout_pad) * 4u;
+#define PVP_LOAD_A(s_, buf_)                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < A_PER_WAVE; ++q)                                                       \
+        if (A_PIECES % CONSUMERS == 0 || wid + CONSUMERS * q < A_PIECES)                                         \
+            pc_dma_b128(wr, &As[buf_][0][0] + (wid + CONSUMERS * q) * 256, avoff[q], (unsigned)(s_) * a_stage_bytes);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        PVP_LOAD_A(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int b_col = wid * 32 + l31;
+        for (int s = 0; s < nk; ++s) {
+            const int buf = s & 1;
+            PVP_LOAD_A(s + 1, buf ^ 1);          // past the end: the spare zero stages of the panel
+            __builtin_amdgcn_sched_barrier(0);
+            float af[2][TM], bf[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lh][l31 + i * 32];
+            bf[0] = Bs[buf][lh][b_col];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < KK) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[nxt][i] = As[buf][2 * (kk + 1) + lh][l31 + i * 32];
+                    bf[nxt] = Bs[buf][2 * (kk + 1) + lh][b_col];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur], acc[i], 0, 0, 0);
+                if (kk + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, TM + 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#undef PVP_LOAD_A
+
+        // epilogue (consumers only): bias, activation, NCHW stores -- 128-byte runs of consecutive pixels
+        const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
+                                                                            a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
+        const int gp = ptile * BN + wid * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row0 = m0 + i * 32 + 4 * lh;
+            float     bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * 4u, 0, 0));
+            if (gp >= a.P) continue;
+            const int n = gp / HW, rem = gp - n * HW;
+            float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff + row0) * HW + rem;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (row0 + dr < a.K) {
+                    float v = acc[i][r];
+                    if (a.bias != nullptr) v = v + bv[r];
+                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
+                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                    yp[(size_t)dr * HW] = v;
+                }
+            }
+        }
+    }
+}
+
+inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
+
+bool pooled_supported(int n, int c, int h, int w, int k_out) {
+    // Default: only rows that are whole 16-byte groups (the 28x28 modules: 3a 0.118 -> 0.099 ms, 3b 0.176 -> 0.138).  The 8-byte
+    // form (14x14 modules, PVHIP_FUSE_POOLCONV=2) issues 4.5 loads per pooled value and is slower than the two launches
+    // (0.081 -> 0.095 ms on 4a); with it the pass loses what the 28x28 modules gain.
+    int min_vec = 4;
+    if (const char* e = getenv("PVHIP_FUSE_POOLCONV")) {
+        if (e[0] == '0') return false;
+        if (e[0] == '2') min_vec = 2;
+    }
+    if (w % min_vec != 0) return false;
+    if (n <= 0 || c < kBK || c % kBK != 0 || h <= 0 || w <= 0 || k_out <= 0 || k_out > 128) return false;
+    if (w % 2 != 0) return false;                                       // aligned 8- or 16-byte groups that never straddle a row
+    if ((unsigned long long)n * c * h * w >= (1ull << 29)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pvhip_conv2d_pooled_supported(int n, int c, int h, int w, int k_out) { return pooled_supported(n, c, h, w, k_out) ? 1 : 0; }
+
+int pvhip_conv2d_pooled_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, const float* bias,
+                            int act, int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+    PVHIP_REQUIRE_INIT();
+    if (!pooled_supported(n, c, h, w, k_out))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_pooled_f32: shape outside the fused kernel (ask pvhip_conv2d_pooled_supported first)");
+    PVHIP_CHECK_ARG(x != nullptr && wpack != nullptr && y != nullptr && act >= 0 && act <= 2);
+    PVHIP_CHECK_ARG(out_channels_total == 0 || (out_channel_offset >= 0 && out_channel_offset + k_out <= out_channels_total));
+    const unsigned long long out_e = (unsigned long long)n * (out_channels_total > 0 ? out_channels_total : k_out) * h * w;
+    if (out_e >= (1ull << 31)) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_pooled_f32: output exceeds 2^31 elements");
+    PoolConvArgs a;
+    constexpr int kTabSpare = 2 * kBK, kPanelSpare = 2 * kBK, kKoutAlign = 128;      // the panel layout of pvhip_conv2d_pack_f32
+    const int kred_pad = round_up_int(c, kBK);
+    a.kout_pad = round_up_int(k_out, kKoutAlign);
+    a.x = x; a.wp = wpack + 2 * (kred_pad + kTabSpare); a.y = y; a.bias = bias;
+    a.N = n; a.C = c; a.H = h; a.W = w; a.K = k_out;
+    a.P = n * h * w;
+    a.x_bytes  = (unsigned)((unsigned long long)n * c * h * w * 4ull);
+    a.wp_bytes = (unsigned)((size_t)(kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
+    a.relu = act; a.act_lo = act_lo; a.act_hi = act_hi;
+    a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
+    a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
+    const int bm = k_out <= 32 ? 32 : (k_out <= 64 ? 64 : 128);
+    a.n_mtiles = (k_out + bm - 1) / bm;
+    const int n_ptiles = (a.P + 127) / 128;
+    const dim3 grid((unsigned)(a.n_mtiles * n_ptiles)), block(512);
+    const bool v4 = w % 4 == 0;
+#define PVP_LAUNCH(BM_)                                                                                           \
+    do {                                                                                                          \
+        if (v4) hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 4>), grid, block, 0, state().stream, a);             \
+        else    hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 2>), grid, block, 0, state().stream, a);             \
+    } while (0)
+    if (bm == 32) PVP_LAUNCH(32);
+    else if (bm == 64) PVP_LAUNCH(64);
+    else PVP_LAUNCH(128);
+#undef PVP_LAUNCH
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+}  // extern "C"

@@ -343,6 +343,7 @@ class Executable_Network:
         self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it
         self._siblings = {}             # Convolution node id -> ids of the convolutions of the same input launched with it
         self._pre_add = {}              # Convolution node id -> (Add node folded into its input fetch, Const id, id of the Add's data input)
+        self._pool_conv = {}            # Convolution node id -> (MaxPool node folded into its input tile, id of the MaxPool's data input)
         self.fuse_siblings = os.environ.get('PVHIP_FUSE_SIBLINGS', '1') != '0'
         self._infer_serial = 0
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
@@ -421,7 +422,7 @@ class Executable_Network:
         bit-identical to the three launches); the Add and ReLU nodes are not dispatched and their output
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
-        self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pre_add = {}, set(), {}, {}, {}
+        self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pre_add, self._pool_conv = {}, set(), {}, {}, {}, {}
         if not self.fuse_epilogues:
             return
         G = self.ienet.G
@@ -521,6 +522,19 @@ class Executable_Network:
                 if conv_plugin.pre_add_fusable(G.nodes[cid]):
                     self._pre_add[cid] = (src, preds[1], preds[0])
                     self._fused_away.add(src)
+        # A 3x3 / stride 1 / pad 1 MaxPool whose only consumer is a fused 1x1 convolution (pool -> pool_proj): the MaxPool is not
+        # dispatched, the convolution reads the MaxPool's input and pools while it builds its input tile.
+        if getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and os.environ.get('PVHIP_FUSE_POOLCONV', '1') != '0':
+            for cid in list(self._fusion):
+                if G.nodes[cid]['type'] != 'Convolution':
+                    continue
+                src = next((p_ for p_ in G.pred[cid] if G.edges[(p_, cid)]['connection'][3] == 0), None)
+                if src is None or G.nodes[src]['type'] != 'MaxPool' or src in self._fused_away or len(list(G.successors(src))) != 1:
+                    continue
+                psrc = next((p_ for p_ in G.pred[src] if G.edges[(p_, src)]['connection'][3] == 0), None)
+                if psrc is not None and conv_plugin.pooled_fusable(G.nodes[cid], G.nodes[src]):
+                    self._pool_conv[cid] = (src, psrc)
+                    self._fused_away.add(src)
         # Third peephole: fused convolution chains that read the SAME tensor with the same geometry and activation (the
         # 1x1, 3x3_reduce and 5x5_reduce arms of an inception module) are one launch of the first of them in schedule
         # order: the input is read once and every output-channel tile stores into the tensor of its own convolution
@@ -585,6 +599,7 @@ class Executable_Network:
                         owner[nid] = lead
 
         folded_adds = {add_id: src_id for add_id, _, src_id in self._pre_add.values()}
+        folded_adds.update({pool_id: src_id for pool_id, src_id in self._pool_conv.values()})      # ... and MaxPools folded likewise
 
         def producers(nid):
             if nid in folded_adds:           # an Add folded into its consumer's fetch: whoever wrote the Add's input
@@ -631,8 +646,8 @@ class Executable_Network:
         def consumers(nid):              # dispatched tasks that read the tensor of graph node nid
             out = []
             for succ in G.successors(nid):
-                if succ in self._concat_direct and succ in self._fused_away:
-                    out += consumers(succ)
+                if (succ in self._concat_direct and succ in self._fused_away) or succ in folded_adds:
+                    out += [c_ for c_ in consumers(succ) if c_ not in out]     # (a folded Add / MaxPool hands the tensor on)
                 elif succ in position and succ not in out:
                     out.append(succ)
             return sorted(out, key=position.get)
@@ -662,6 +677,8 @@ class Executable_Network:
         for task in dispatched:
             preds = sorted(G.pred[task], key=lambda p: G.edges[(p, task)]['connection'][3])
             primary = next((p for p in preds if producers(p)), None)
+            while primary in folded_adds:        # read through a folded Add / MaxPool: the arms fork at ITS input
+                primary = folded_adds[primary]
             if primary is None:
                 stream_of[task] = 0
                 finish[task] = cost(task)
@@ -734,6 +751,15 @@ class Executable_Network:
                 node['_fuse_pre_add'] = G.nodes[const_id]['output'][0]['data']
             else:
                 node.pop('_fuse_pre_add', None)
+            pooled_in = self._pool_conv.get(task)
+            if pooled_in is not None:        # the folded MaxPool hands its own input on: the kernel pools while it builds its tile
+                pool_id, _ = pooled_in
+                edge = next(G.edges[(p_, pool_id)]['connection'] for p_ in G.pred[pool_id] if G.edges[(p_, pool_id)]['connection'][3] == 0)
+                out = G.nodes[pool_id]['output']
+                out[next(iter(out))]['data'] = G.nodes[edge[0]]['output'][edge[1]]['data']
+                node['_fuse_pool_in'] = G.nodes[pool_id]
+            else:
+                node.pop('_fuse_pool_in', None)
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
             fusion = self._fusion.get(task)
             node.pop('_out_into', None)
@@ -900,8 +926,8 @@ class Executable_Network:
                 chain = [cid, f['add']] + ([f['relu']] if f['relu'] is not None else [])
                 if all(c in needed for c in chain):
                     keep[cid] = dict(f, into=None)      # Concat elimination is not applied to sub-graphs
-            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add)
-            self._siblings, self._pre_add = {}, {}       # sub-graph runs launch every convolution (and Add) on its own
+            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add, self._pool_conv)
+            self._siblings, self._pre_add, self._pool_conv = {}, {}, {}      # sub-graph runs launch every convolution (Add, MaxPool) on its own
             self._fusion = {c: f for c, f in keep.items()}
             self._fused_away = {n for f in self._fusion.values() for n in (f['add'], f['relu']) if n is not None}
             self._concat_direct = {}
@@ -910,7 +936,7 @@ class Executable_Network:
             try:
                 self.run_tasks(False)
             finally:
-                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add = saved
+                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add, self._pool_conv = saved
         finally:
             self.task_list = full
         out = {}

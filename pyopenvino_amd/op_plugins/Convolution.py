@@ -25,6 +25,10 @@ SUPPORTS_SIBLINGS = True
 # node['_fuse_pre_add'] = the (1, C, 1, 1) constant, inputs[0] = the Add's own input.  The kernel adds while it fetches (the same
 # fp32 add; zero padding stays zero), the Add launch and its tensor disappear.
 SUPPORTS_PRE_ADD = True
+# A 3x3 / stride 1 / pad 1 MaxPool whose only consumer is a 1x1 convolution (the pool -> pool_proj arm of an inception module) may
+# be handed over with the convolution: node['_fuse_pool_in'] = the MaxPool's node dict, inputs[0] = the MaxPool's own input.  The
+# kernel pools while it builds its input tile; the pooled tensor is never written.
+SUPPORTS_POOLED_INPUT = True
 
 
 def name():
@@ -97,6 +101,52 @@ def pre_add_fusable(node: dict) -> bool:
                              int(wd[0]), oh, ow, pb[0], pb[1]))
     except (KeyError, ValueError, AssertionError, IndexError):
         return False
+
+
+def pooled_fusable(node: dict, pool_node: dict) -> bool:
+    """True when libpvhip's MaxPool + 1x1 convolution kernel covers this pair (IR attributes and port dims; no device needed)."""
+    try:
+        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+        strides, pb, pe = (common_def.string_to_tuple(attrs[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+        if tuple(wd[2:]) != (1, 1) or tuple(strides) != (1, 1) or tuple(pb) != (0, 0) or tuple(pe) != (0, 0):
+            return False
+        if attrs['auto_pad'] not in ('explicit', 'valid'):
+            return False
+        pa = pool_node['data']
+        pk, ps, ppb, ppe = (common_def.string_to_tuple(pa[k]) for k in ('kernel', 'strides', 'pads_begin', 'pads_end'))
+        if tuple(pk) != (3, 3) or tuple(ps) != (1, 1) or tuple(ppb) != (1, 1) or tuple(ppe) != (1, 1) or pa['auto_pad'] != 'explicit':
+            return False
+        pin = pool_node['input'][0]['dims']
+        if len(pin) != 4 or tuple(pin) != tuple(xd) or tuple(pool_node['output'][common_def.first_output_port(pool_node)]['dims']) != tuple(xd):
+            return False
+        return bool(dev.call('pvhip_conv2d_pooled_supported', int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0])))
+    except (KeyError, ValueError, AssertionError, IndexError):
+        return False
+
+
+def launch_pooled(node, x, w, bias=None, act=None, into=None):
+    """conv1x1(maxpool3x3/s1/p1(x)) in one launch; arguments as launch()."""
+    n, c, h, wd = x.shape
+    kn = w.shape[0]
+    if w.shape[1] != c or tuple(w.shape[2:]) != (1, 1):
+        raise ValueError('the pooled-input launch is for 1x1 convolutions over the same {} channels, got {}'.format(c, w.shape))
+    wpack = packed_weights(node, w, h, wd)
+    act_code, act_lo, act_hi = 0, 0.0, 0.0
+    if act is not None:
+        act_code = 1 if act[0] == 'relu' else 2
+        if act_code == 2:
+            act_lo, act_hi = float(act[1]), float(act[2])
+    if into is None:
+        target, coff, ctotal = dev.DeviceTensor.empty((n, kn, h, wd)), 0, 0
+        y = target
+    else:
+        target, coff = into
+        ctotal = target.shape[1]
+        assert target.shape[0] == n and tuple(target.shape[2:]) == (h, wd) and coff + kn <= ctotal
+        y = dev.ChannelSlice(target, coff, kn)
+    dev.call('pvhip_conv2d_pooled_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), n, c, h, wd, kn,
+             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
+    return y
 
 
 def siblings_fusable(nodes) -> bool:
@@ -200,7 +250,9 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
     siblings = node.get('_siblings')
-    if siblings:
+    if node.get('_fuse_pool_in') is not None:
+        y = launch_pooled(node, x, w, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'))
+    elif siblings:
         members = [(w, bias, node.get('_out_into'))]
         for sib in siblings:
             common_def.validate_inputs(sib['node'], sib['inputs'])

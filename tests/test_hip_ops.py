@@ -594,6 +594,56 @@ def test_sibling_convolutions_decline_other_geometries(hip):
     assert not plugin.siblings_fusable(odd)                                           # 24 channels: not whole 16-row stages
 
 
+@pytest.mark.parametrize('xs,k', [((3, 192, 28, 28), 32), ((2, 480, 14, 14), 64), ((2, 528, 14, 14), 128), ((1, 32, 6, 10), 40),
+                                  ((5, 16, 4, 4), 7), ((1, 48, 9, 36), 100)])
+def test_maxpool_then_1x1_convolution_as_one_launch_is_bit_identical(hip, monkeypatch, xs, k):
+    """3x3 / stride 1 / pad 1 MaxPool -> 1x1 convolution handed over as one call (node['_fuse_pool_in']): the bits of the two
+    launches (zero pad cells take part in the max, NaN wins), also with fused bias + ReLU and written in place into a wider
+    tensor; within the tolerance of the oracle's MaxPool -> Convolution."""
+    from pyopenvino_amd import device as dev
+    monkeypatch.setenv('PVHIP_FUSE_POOLCONV', '2')          # also the 8-byte form (rows that are not whole 16-byte groups: off by default)
+    conv, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
+    x = rnd(sum(xs), xs, 1.0, -0.4)
+    x[0, 1, 2, 3] = np.nan if k == 40 else x[0, 1, 2, 3]
+    w, b = rnd(k, (k, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5), rnd(k + 1, (1, k, 1, 1), 0.2)
+    pnode = make_node('MaxPool', [x], pool_data((3, 3), (1, 1), (1, 1), (1, 1), 'ceil'))
+    pnode['output'][1]['dims'] = tuple(xs)
+    cnode = make_node('Convolution', [x, w], conv_data((1, 1), (0, 0), (0, 0)))
+    assert conv.pooled_fusable(cnode, pnode)
+    pooled = pool.compute(pnode, {0: x})[1]
+    two = dict(cnode)
+    two['_fuse_bias'], two['_fuse_act'] = dev.DeviceTensor.from_numpy(b), ('relu',)
+    want = first_out(conv.compute(two, {0: pooled, 1: w}))
+    wide = dev.DeviceTensor.from_numpy(np.full((xs[0], k + 9, xs[2], xs[3]), -1.0, dtype=np.float32))
+    one = dict(cnode)
+    one['_fuse_bias'], one['_fuse_act'], one['_fuse_pool_in'], one['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), pnode, (wide, 4)
+    conv.compute(one, {0: x, 1: w})
+    got = np.asarray(wide)
+    assert_bit_exact(np.ascontiguousarray(got[:, 4:4 + k]), want, 'MaxPool + 1x1 convolution {} k{}'.format(xs, k))
+    assert np.all(got[:, :4] == -1.0) and np.all(got[:, 4 + k:] == -1.0)
+    opool = first_out(oracle_plugin('MaxPool').compute(pnode, {0: x}, kernel_type='special'))
+    oracle = np.maximum(first_out(oracle_plugin('Convolution').compute(cnode, {0: opool, 1: w}, kernel_type='special')) + b, 0)
+    assert_close(np.ascontiguousarray(got[:, 4:4 + k]), oracle, helpers.REL_TOL, 'MaxPool + 1x1 convolution vs oracle')
+
+
+def test_maxpool_then_convolution_declines_other_geometries(hip):
+    conv = hip_plugin('Convolution')
+    def pair(xs, k=8, kk=1, pool=((3, 3), (1, 1), (1, 1), (1, 1))):
+        x = np.zeros(xs, dtype=np.float32)
+        pn = make_node('MaxPool', [x], pool_data(pool[0], pool[1], pool[2], pool[3], 'ceil'))
+        pn['output'][1]['dims'] = tuple(xs)
+        pad = (kk // 2, kk // 2)
+        return make_node('Convolution', [x, np.zeros((k, xs[1], kk, kk), dtype=np.float32)], conv_data((1, 1), pad, pad)), pn
+    assert conv.pooled_fusable(*pair((2, 32, 12, 12)))
+    assert not conv.pooled_fusable(*pair((2, 32, 14, 14)))               # rows of 14: the 8-byte form is opt-in (slower than two launches)
+    assert not conv.pooled_fusable(*pair((2, 32, 7, 7)))                 # odd width
+    assert not conv.pooled_fusable(*pair((2, 24, 12, 12)))               # 24 channels: not whole 16-row stages
+    assert not conv.pooled_fusable(*pair((2, 32, 12, 12), k=200))
+    assert not conv.pooled_fusable(*pair((2, 32, 12, 12), kk=3))
+    assert not conv.pooled_fusable(*pair((2, 32, 12, 12), pool=((3, 3), (2, 2), (1, 1), (1, 1))))
+    assert not conv.pooled_fusable(*pair((2, 32, 12, 12), pool=((3, 3), (1, 1), (0, 0), (0, 0))))
+
+
 LRN_POOL_CASES = [
     # (x shape, pool stride, pads_begin, pads_end, rounding)
     ((2, 192, 56, 56), (2, 2), (0, 0), (0, 0), 'ceil'),      # conv2/norm2 -> pool2/3x3_s2: four bands of 7 pooled rows, clipped last window

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', device.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r' T (pvhip_[a-z0-9_]+)', nm))
     assert declared <= exported
-    assert lib.pvhip_abi_version() == 7
+    assert lib.pvhip_abi_version() == 8
     assert isinstance(lib.pvhip_last_error(), bytes)
 
 
@@ -199,6 +199,8 @@ def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
         else:
             assert not ex._pre_add
         folded = {a: s for a, _, s in ex._pre_add.values()}
+        folded.update({p_: s for p_, s in ex._pool_conv.values()})       # MaxPools folded into the pool_proj convolutions
+        assert len(ex._pool_conv) == (2 if fuse else 0)                  # the 28x28 modules (rows of whole 16-byte groups)
         lead_of = {n: lead for lead, sibs in ex._siblings.items() for s in sibs
                    for n in (s, ex._fusion[s]['add'], ex._fusion[s]['relu']) if n is not None}
 
@@ -225,7 +227,8 @@ def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
         conv = lambda a: by_name['inception_3a/' + a + '/WithoutBiases']
         if fuse:     # 1x1 + 3x3_reduce + 5x5_reduce are one launch; behind it and the pool three arms run side by side
             assert ex._siblings[conv('1x1')] == [conv('3x3_reduce'), conv('5x5_reduce')] and len(ex._siblings) == 9
-            assert stream_of[conv('1x1')] != stream_of[by_name['inception_3a/pool']]
+            assert by_name['inception_3a/pool'] not in stream_of                 # folded into pool_proj, which forks off the module's input
+            assert stream_of[conv('1x1')] != stream_of[conv('pool_proj')]
             assert len({stream_of[conv('3x3')], stream_of[conv('5x5')], stream_of[conv('pool_proj')]}) == 3
             assert stream_of[conv('3x3')] == stream_of[conv('1x1')]          # the heaviest arm stays on the producer's stream
         else:
