@@ -14,8 +14,8 @@ import sys
 
 
 def is_conv(name):
-    """The kernels behind the Convolution nodes: implicit GEMM, both Winograd forms, the 7x7 stem."""
-    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_stem' in name
+    """The kernels behind the Convolution nodes: implicit GEMM (also with the MaxPool in front folded in), the Winograd forms, the 7x7 stem."""
+    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_stem' in name or 'conv_pool1x1' in name
 
 
 def find(root, pattern):
@@ -53,7 +53,7 @@ def main():
                 conv_total_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         if conv_calls:
-            md += ['', '**conv_wino4_kernel + conv_wino_kernel + conv_igemm_dma_kernel + conv_stem7x7_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+            md += ['', '**conv_wino4_kernel + conv_wino_kernel + conv_igemm_dma_kernel + conv_pool1x1_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of {} launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * per_pass / 1e6, per_pass)]
     trace = find(os.path.join(raw, 'stats'), '*kernel_trace.csv')
@@ -125,7 +125,7 @@ def main():
                 agg[r['Counter_Name']] = agg.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
         if agg.get('GRBM_GUI_ACTIVE'):
             cyc = agg['GRBM_GUI_ACTIVE'] / 8.0
-            md += ['', '## convolution kernels (conv_wino4 + conv_wino + conv_igemm_dma + conv_stem7x7), SQ counters summed over their launches', '']
+            md += ['', '## convolution kernels (conv_wino4 + conv_wino + conv_igemm_dma + conv_pool1x1), SQ counters summed over their launches', '']
             md += ['- MFMA pipe busy: {:.1f} % of SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))'.format(
                 100.0 * agg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / cyc)]
             if agg.get('SQ_BUSY_CU_CYCLES'):
