@@ -447,6 +447,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     };
     __shared__ __attribute__((aligned(1024))) Stage sm;
     static_assert(sizeof(Stage) == 72 * 1024, "72 KB of LDS: two workgroups per CU");
+    static_assert(U_PIECES % CONSUMERS == 0, "whole pieces per consumer wave");
     auto& Us = sm.Us;
     auto& Vs = sm.Vs;
 
@@ -474,12 +475,13 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     const unsigned u_base = (unsigned)(kb * (a.n_stages + 1)) * u_stage_bytes;
     const unsigned u_lane = (unsigned)lane * 16u;
 
+    // the U image of a stage: 18 one-KiB pieces, three per consumer wave (the producers' loop stays free of hand-counted waits)
 #define PVW4_LOAD_U(s_, buf_)                                                                                   \
     {                                                                                                           \
         const unsigned soff = u_base + (unsigned)(s_) * u_stage_bytes;                                           \
-        _Pragma("unroll") for (int q = 0; q < (U_PIECES + WAVES - 1) / WAVES; ++q)                               \
-            if (ABL != 4 && wid + WAVES * q < U_PIECES)                                                          \
-                wino_dma_b128(ur, &Us[buf_][0][0][0] + (wid + WAVES * q) * 256, u_lane + (unsigned)(wid + WAVES * q) * 1024u, soff); \
+        _Pragma("unroll") for (int q = 0; q < U_PIECES / CONSUMERS; ++q)                                         \
+            if (ABL != 4)                                                                                        \
+                wino_dma_b128(ur, &Us[buf_][0][0][0] + (wid + CONSUMERS * q) * 256, u_lane + (unsigned)(wid + CONSUMERS * q) * 1024u, soff); \
     }
 
     floatx16 acc[6];
@@ -578,26 +580,20 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             Vs[buf_][i * 6 + 5][g_chan][l31] = v5;                                                               \
         }                                                                                                        \
     }
-        PVW4_LOAD_U(0, 0);
         PVW4_GATHER(vA, eA, 0);
         PVW4_GATHER(vB, eB, 1);
         PVW4_TRANSFORM_STORE(vA, eA, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // stage s: V(s+1) from the gather issued one stage ago, gather of stage s+2 issued now (two stages in flight)
         for (int s = 0; s < a.n_stages; s += 2) {
-            PVW4_LOAD_U(s + 1, 1);
             PVW4_GATHER(vA, eA, s + 2);
             __builtin_amdgcn_sched_barrier(0);
             PVW4_TRANSFORM_STORE(vB, eB, 1);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // the U image of stage s+1 has landed (only the newest gather, 12 loads, may be pending)
             __syncthreads();
             if (s + 1 < a.n_stages) {
-                PVW4_LOAD_U(s + 2, 0);
                 PVW4_GATHER(vB, eB, s + 3);
                 __builtin_amdgcn_sched_barrier(0);
                 PVW4_TRANSFORM_STORE(vA, eA, 0);
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 __syncthreads();
             }
         }
