@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   8
+#define PVHIP_ABI_VERSION   9
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -42,7 +42,9 @@ extern "C" {
 int         pvhip_abi_version(void);
 const char* pvhip_last_error(void);
 int         pvhip_device_count(int* count);
-int         pvhip_init(int device);                     /* select device, create the compute stream  */
+int         pvhip_init(int device);                     /* select device, create the compute stream, read the PVHIP_* variables */
+int         pvhip_settings_reload(void);                /* read the PVHIP_* environment variables again (they are parsed once, by
+                                                           pvhip_init, never on a launch path): tests and tuning scripts that flip one */
 int         pvhip_shutdown(void);                       /* free pool, destroy stream                 */
 int         pvhip_device_name(char* buf, size_t buflen);
 int         pvhip_malloc(void** ptr, size_t bytes);     /* pooled: freed blocks are reused by size   */

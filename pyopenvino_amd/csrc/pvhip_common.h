@@ -21,6 +21,42 @@ struct State {
 };
 State& state();
 
+// Every PVHIP_* environment variable the library understands, parsed ONCE by pvhip_init (and again by
+// pvhip_settings_reload, for tests and tuning scripts that flip them): no getenv on any launch path.
+struct Settings {
+    int generation = 0;          // bumped by every (re)load: host-side plan caches key on it
+    // ---- product switches
+    int  conv_kernel    = 0;     // PVHIP_CONV_KERNEL: 0 = LDS-DMA kernels (default), 1 = "lds" (register-staged), 2 = "wave"
+    bool conv_winograd  = true;  // PVHIP_CONV_WINOGRAD=0: direct kernels for the 3x3 / 5x5 layers
+    int  conv_winograd4 = 1;     // PVHIP_CONV_WINOGRAD4: 0 off, 1 by size rule, 2 ("force") any size
+    int  conv_winograd5 = 1;     // PVHIP_CONV_WINOGRAD5: likewise for F(2x2,5x5)
+    bool conv_pointwise = true;  // PVHIP_CONV_POINTWISE=0: 1x1 layers on the general LDS-DMA kernel
+    bool conv_stem      = false; // PVHIP_CONV_STEM=1: the persistent 7x7 / stride 2 / 3-channel kernel for the first layer (opt-in)
+    int  fuse_poolconv  = 1;     // PVHIP_FUSE_POOLCONV: 0 off, 1 rows of whole 16-byte groups, 2 also 8-byte groups
+    bool pool3          = true;  // PVHIP_POOL3=0: the one-shot MaxPool kernel for 3x3 windows too
+    // ---- tuning runs (scripts/): defaults are what the product uses
+    int  tile_bm = 0, tile_bn = 0;         // PVHIP_CONV_TILE=BMxBN
+    int  wtile_m = 2, wtile_n = 1;         // PVHIP_CONV_WTILE=TMxTN (wave kernel, units of 32)
+    int  conv_lds_pad_kb = 0;              // PVHIP_CONV_LDS_PAD_KB: extra dynamic LDS caps workgroups per CU
+    bool conv_nopw = false;                // PVHIP_CONV_NOPW: general kernel without its pointwise copy
+    bool conv_pw16 = false;                // PVHIP_CONV_PW: 16-byte gather of the register-staged kernel
+    int  multi_bm = 32;                    // PVHIP_CONV_MULTI_BM
+    int  pw_tn = 0;                        // PVHIP_PW_TN=1|2: channel tiles per workgroup of the pointwise kernel (0 = by panel size)
+    int  pw_stagger_pct = 0;               // PVHIP_PW_STAGGER: start-time stagger of the pointwise kernel, percent of its rule (0 = off)
+    int  pool3_kb = 16, pool3_stage = 1, pool3_wg = 0, pool3_g = 0, pool3_s = 0, pool3_band = 0;   // PVHIP_POOL3_KB/_STAGE/_WG/_CFG
+    bool pool3_verbose = false;
+    int  pool_lds_kb = 16;                 // PVHIP_POOL_LDS_KB
+    int  stem_wg = 0;                      // PVHIP_STEM_WG
+    int  wino_kb = 0;                      // PVHIP_WINO_KB=32|64
+    bool wino_small = true;                // PVHIP_WINO_SMALL=0
+    int  wino_waves = 8;                   // PVHIP_WINO_WAVES=4
+    // ---- wrong-on-purpose ablations: honoured only by the diagnostic build (make diag -> libpvhip_diag.so, -DPVHIP_DIAG)
+    int  conv_ablate = 0, stem_ablate = 0, wino4_ablate = 0, pw_ablate = 0;
+    bool pool3_tuning() const { return pool3_kb != 16 || pool3_stage != 1 || pool3_wg != 0 || pool3_g != 0; }
+};
+const Settings& settings();
+void            load_settings();
+
 // Records a formatted message for pvhip_last_error() and returns `code`.
 int fail(int code, const char* fmt, ...);
 
@@ -81,6 +117,28 @@ inline int lrn_beta_mode(float beta, float bias) {
     if (beta == 1.0f) return 3;
     return 0;
 }
+
+// Global -> LDS loads (LDS-DMA), written as asm statements on purpose: hipcc treats the builtin form as a store to all
+// of LDS and puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialise the loads of stage t+1 with the
+// MFMAs of stage t.  The asm loads are invisible to its counters; a kernel waits for them itself (lds_dma_wait_all, or a
+// counted s_waitcnt) before the barrier that publishes the stage.  `dst` is wave-uniform: lane l's bytes land at dst + l*4
+// (b32) or dst + l*16 (b128); an out-of-range source offset writes 0.
+typedef __attribute__((address_space(3))) void* lds_void_p;
+__device__ __forceinline__ void lds_dma_b32(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds = (unsigned)(unsigned long)(lds_void_p)dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
+}
+__device__ __forceinline__ void lds_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds = (unsigned)(unsigned long)(lds_void_p)dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 }  // namespace pvhip
 

@@ -523,29 +523,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
 // M0); the weight tile [16][BM] is a dense copy of BM/16 one-KiB pieces (16 bytes per lane).  A stage is
 // 8 gather instructions + at most 2 weight pieces per wave; the loads of stage t+1 are issued before the
 // MFMAs of stage t and waited for only at the end of it.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(4))) int* const_int_p;
 
-// Global -> LDS loads (LDS-DMA), written as asm statements on purpose: hipcc treats the builtin form as a
-// store to all of LDS and puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialise the
-// loads of stage t+1 with the MFMAs of stage t.  The asm loads are invisible to its counters; the kernel
-// waits for them itself (dma_wait_all) before the barrier that publishes the stage.  `dst` is wave-uniform:
-// lane l's bytes land at dst + l*4 (b32) or dst + l*16 (b128); an out-of-range source offset writes 0.
-__device__ __forceinline__ void dma_b32(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned lds = (unsigned)(unsigned long)(lds_ptr_t)dst;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
-#endif
-}
-__device__ __forceinline__ void dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned lds = (unsigned)(unsigned long)(lds_ptr_t)dst;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
-#endif
-}
-__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Global -> LDS loads: lds_dma_b32 / lds_dma_b128 / lds_dma_wait_all of pvhip_common.h (asm statements on purpose, see there).
+#define dma_b32 lds_dma_b32
+#define dma_b128 lds_dma_b128
+#define dma_wait_all lds_dma_wait_all
 
 // kPW (pointwise: 1x1, stride 1, no padding, H*W % 4 == 0, (r,s)-major): the im2col tile is then a plain copy of 16
 // channel rows x 128 consecutive pixels, moved as 8 one-KiB pieces (16 bytes per lane, two tile rows per piece) instead
@@ -955,18 +938,14 @@ inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 // The LDS-DMA kernel is the default for (r,s)-major shapes; PVHIP_CONV_KERNEL=lds selects the register-staged
 // conv_igemm_rs_kernel instead (kept as a tested variant and for A/B measurements).
-inline bool dma_enabled() {
-    const char* e = getenv("PVHIP_CONV_KERNEL");
-    return e == nullptr || strcmp(e, "lds") != 0;
-}
+inline bool dma_enabled() { return settings().conv_kernel != 1; }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
     if (BN == 128 && WAVES_M == 1 && dma_enabled() && (rs_major(a.C, a.kh, a.kw) || a.kh * a.kw < 64)) {
-        const char* pad = getenv("PVHIP_CONV_LDS_PAD_KB");     // diagnostic: extra dynamic LDS caps workgroups per CU
-        const size_t dyn = pad ? (size_t)atoi(pad) * 1024 : 0;
+        const size_t dyn = (size_t)settings().conv_lds_pad_kb * 1024;     // tuning: extra dynamic LDS caps workgroups per CU
         const bool pw = rs_major(a.C, a.kh, a.kw) && a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
-                        a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && getenv("PVHIP_CONV_NOPW") == nullptr;
+                        a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && !settings().conv_nopw;
         if (pw)
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
         else if (rs_major(a.C, a.kh, a.kw))
@@ -975,9 +954,8 @@ void launch_conv(const ConvArgs& a, int n_ptiles) {
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
     } else if (rs_major(a.C, a.kh, a.kw)) {
         const bool pointwise = a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
-                               a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && getenv("PVHIP_CONV_PW") != nullptr;   // 16-byte gather measured slower: opt-in
-        const char* pad = getenv("PVHIP_CONV_LDS_PAD_KB");     // diagnostic: extra dynamic LDS caps workgroups per CU
-        const size_t dyn = pad ? (size_t)atoi(pad) * 1024 : 0;
+                               a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && settings().conv_pw16;   // 16-byte gather measured slower: opt-in
+        const size_t dyn = (size_t)settings().conv_lds_pad_kb * 1024;
         if (pointwise)
             hipLaunchKernelGGL((conv_igemm_rs_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock),
                                dyn, state().stream, a);
@@ -1004,6 +982,7 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     size_t elems = 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
     elems += stem_pack_elems(k_out, c, kh, kw);      // the 7x7 / 3-channel stem keeps its own panel behind the general one
     if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c) + wino4_pack_elems(k_out, c);
+    if (kh == 1 && kw == 1) elems += pw_pack_elems(k_out, c);         // 1x1: the fragment-ordered panel of the pointwise kernel
     if (kh == 5 && kw == 5) elems += wino4_pack_elems(k_out, c);       // 5x5: the F(2x2,5x5) panel   // 3x3: the Winograd-transformed panels ride along (stride / pad are not known yet)
     return elems;
 }
@@ -1021,6 +1000,10 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
                        w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad, rs_major(c, kh, kw) ? 1 : 0);
     if (stem_pack_elems(k_out, c, kh, kw) > 0) {
         const int rc = stem_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out);
+        if (rc) return rc;
+    }
+    if (kh == 1 && kw == 1 && pw_pack_elems(k_out, c) > 0) {
+        const int rc = pw_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out, c);
         if (rc) return rc;
     }
     if (kh == 5 && kw == 5 && wino4_pack_elems(k_out, c) > 0 && h % 2 == 0 && w % 2 == 0) {
@@ -1088,6 +1071,13 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
     }
     if (pre_add != nullptr)
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_preadd_f32: only the 7x7 / stride 2 / 3-channel stem kernel adds in its fetch (ask pvhip_conv2d_preadd_supported)");
+    if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
+        const PwDest d{y, 0, k_out, a.y_ctotal, a.y_coff};
+        const int rc = pw_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, n, c, h * w, k_out, bias, relu, act_lo, act_hi, 1, &d);
+        if (rc) return rc;
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
     if (wino25_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) {
         const int rc = wino4_conv(2, x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, c, h, w, k_out, bias, relu, act_lo,
                                   act_hi, a.y_coff, a.y_ctotal);
@@ -1111,12 +1101,9 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
     }
 
     // ---- wave-direct kernel (PVHIP_CONV_KERNEL=wave, PVHIP_CONV_WTILE=TMxTN in units of 32)
-    const char* kenv = getenv("PVHIP_CONV_KERNEL");
     const size_t tab_bytes = (size_t)(a.kred_pad + kTabSpare) * sizeof(int2);
-    if (kenv != nullptr && strcmp(kenv, "wave") == 0 && tab_bytes <= 60 * 1024 && !rs_major(c, kh, kw)) {
-        int tm = 2, tn = 1;
-        const char* wenv = getenv("PVHIP_CONV_WTILE");
-        if (wenv != nullptr) sscanf(wenv, "%dx%d", &tm, &tn);
+    if (settings().conv_kernel == 2 && tab_bytes <= 60 * 1024 && !rs_major(c, kh, kw)) {
+        const int tm = settings().wtile_m, tn = settings().wtile_n;
         a.n_mtiles = (k_out + 32 * tm - 1) / (32 * tm);
         a.n_ptiles = (a.P + 32 * tn - 1) / (32 * tn);
         const long n_tiles = (long)a.n_mtiles * a.n_ptiles;
@@ -1127,8 +1114,8 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
         if (mask) hipLaunchKernelGGL((conv_wave_kernel<TM_, TN_, true>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);  \
         else hipLaunchKernelGGL((conv_wave_kernel<TM_, TN_, false>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);      \
     } while (0)
-        if (const char* ab = getenv("PVHIP_CONV_ABLATE")) {   // diagnostic: results are wrong on purpose
-            const int v = atoi(ab);
+#ifdef PVHIP_DIAG
+        if (const int v = settings().conv_ablate) {   // diagnostic build only (libpvhip_diag.so): results are wrong on purpose
             if (tm == 2 && tn == 1) {
                 if (v == 1) hipLaunchKernelGGL((conv_wave_kernel<2, 1, true, 1>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
                 else if (v == 2) hipLaunchKernelGGL((conv_wave_kernel<2, 1, true, 2>), dim3(grid), dim3(kBlock), tab_bytes, state().stream, a);
@@ -1141,6 +1128,7 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
             PVHIP_LAUNCH_CHECK();
             return PVHIP_OK;
         }
+#endif
         if (tm == 1 && tn == 1) PV_WAVE_LAUNCH(1, 1);
         else if (tm == 1 && tn == 2) PV_WAVE_LAUNCH(1, 2);
         else if (tm == 2 && tn == 1) PV_WAVE_LAUNCH(2, 1);
@@ -1159,13 +1147,7 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
     int bm = (k_out % 64 == 0 || k_out % 64 > 32) ? 64 : 32, bn = 128;
     if (bm == 64 && (long)((a.P + 127) / 128) * ((k_out + 63) / 64) < 4 * kNumCU) bm = 32;
     if (kh == 1 && kw == 1) bm = 32;      // 1x1 layers: the smaller tile wins on every GoogLeNet shape (more workgroups per CU)
-    const char* env = getenv("PVHIP_CONV_TILE");
-    if (env != nullptr) {
-        int ebm = 0, ebn = 0;
-        if (sscanf(env, "%dx%d", &ebm, &ebn) == 2 && (ebm == 32 || ebm == 64 || ebm == 128) && (ebn == 128 || ebn == 256)) {
-            bm = ebm; bn = ebn;
-        }
-    }
+    if (settings().tile_bm > 0) { bm = settings().tile_bm; bn = settings().tile_bn; }      // PVHIP_CONV_TILE: tuning runs only
     a.n_mtiles       = (k_out + bm - 1) / bm;
     const int n_ptiles = (a.P + bn - 1) / bn;
 
@@ -1233,6 +1215,16 @@ int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_multi_f32: input exceeds 2^29 elements or an output 2^31");
     if (in_e == 0 || oh == 0 || ow == 0) return PVHIP_OK;
     PVHIP_CHECK_ARG(x != nullptr && wpack != nullptr);
+    if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
+        PwDest pd[kMaxConvDests];
+        for (int i = 0; i < n_dest; ++i) pd[i] = PwDest{a.seg[i].y, a.seg[i].m_begin, a.seg[i].k, a.seg[i].ctotal, a.seg[i].coff};
+        const int kred_pad = round_up_int(c, kBK), kout_pad = round_up_int(k_panel, kKoutAlign);
+        const float* ap = wpack + 2 * (kred_pad + kTabSpare) + (size_t)(kred_pad + kPanelSpare) * kout_pad;
+        const int rc = pw_conv(x, ap, n, c, h * w, k_panel, bias, act, act_lo, act_hi, n_dest, pd);
+        if (rc) return rc;
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
     a.nseg     = n_dest;
     a.kred_pad = round_up_int(c, kBK);
     a.kout_pad = round_up_int(k_panel, kKoutAlign);
@@ -1248,8 +1240,7 @@ int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int
     a.relu = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = a.seg[0].ctotal; a.y_coff = a.seg[0].coff;
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
-    int bm = 32;
-    if (const char* e = getenv("PVHIP_CONV_MULTI_BM")) bm = atoi(e) == 64 ? 64 : (atoi(e) == 128 ? 128 : 32);       // tuning runs only
+    const int bm = settings().multi_bm;       // PVHIP_CONV_MULTI_BM: tuning runs only
     a.n_mtiles = (k_panel + bm - 1) / bm;          // a 64-channel tile may straddle two ranges: the epilogue looks the range up per 32 channels
     const int n_ptiles = (a.P + 127) / 128;
     const bool pw = (h * w) % 4 == 0;

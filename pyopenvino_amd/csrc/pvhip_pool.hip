@@ -337,13 +337,11 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
     if (pt > 2 || pl > 2 || (oh - 1) * st > pt + h - 1 || (ow - 1) * st > pl + w - 1) return false;   // clamped taps stay in their window
     if (ow > kBlock || hp < pt + h || wp < pl + w) return false;
     const int hw = h * w, ohw = oh * ow;
-    size_t budget = 16 * 1024;
-    if (const char* e = getenv("PVHIP_POOL3_KB")) budget = (size_t)atoi(e) * 1024;
-    bool stage = true;
-    if (const char* e = getenv("PVHIP_POOL3_STAGE")) stage = atoi(e) != 0;
-    int G = 0, S = 0, band = 0;
-    bool forced = false;
-    if (const char* e = getenv("PVHIP_POOL3_CFG")) forced = (sscanf(e, "%d,%d,%d", &G, &S, &band) == 3 && G > 0 && S > 0 && band > 0);
+    const Settings& cfg = settings();                   // PVHIP_POOL3_KB / _STAGE / _CFG / _WG: tuning runs only
+    const size_t budget = (size_t)cfg.pool3_kb * 1024;
+    const bool stage = cfg.pool3_stage != 0;
+    int G = cfg.pool3_g, S = cfg.pool3_s, band = cfg.pool3_band;
+    const bool forced = G > 0 && S > 0 && band > 0;
     const bool need4 = (hw % 4 != 0) || (ohw % 4 != 0);      // group starts must stay 16-byte aligned
     if (!forced) {
         double best = -1.0;
@@ -394,7 +392,7 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
     int per_cu = (int)((size_t)(160 * 1024) / out.lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    if (const char* e = getenv("PVHIP_POOL3_WG")) per_cu = max(1, atoi(e));
+    if (cfg.pool3_wg > 0) per_cu = cfg.pool3_wg;
     out.grid  = min(a.n_tiles, per_cu * kNumCU);
     out.a     = a;
     out.stage = stage;
@@ -404,10 +402,10 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
 // The search above costs tens of microseconds; a forward pass asks for the same few shapes over and over.
 bool plan_pool3(const float* x, float* y, int planes, int h, int w, int oh, int ow, int st, int pt, int pl, int hp, int wp,
                 Pool3Plan& out) {
-    if (const char* e = getenv("PVHIP_POOL3")) if (atoi(e) == 0) return false;
-    struct Entry { int key[10]; bool ok; Pool3Plan plan; };
+    if (!settings().pool3) return false;
+    struct Entry { int key[11]; bool ok; Pool3Plan plan; };
     static std::vector<Entry> cache;
-    const int key[10] = {planes, h, w, oh, ow, st, pt, pl, hp, wp};
+    const int key[11] = {planes, h, w, oh, ow, st, pt, pl, hp, wp, settings().generation};
     for (const Entry& e : cache)
         if (memcmp(e.key, key, sizeof key) == 0) {
             if (!e.ok) return false;
@@ -417,11 +415,11 @@ bool plan_pool3(const float* x, float* y, int planes, int h, int w, int oh, int 
     Entry e;
     memcpy(e.key, key, sizeof key);
     e.ok = plan_pool3_search(x, y, planes, h, w, oh, ow, st, pt, pl, hp, wp, e.plan);
-    if (getenv("PVHIP_POOL3_VERBOSE"))
+    if (settings().pool3_verbose)
         fprintf(stderr, "pool3 planes=%d %dx%d->%dx%d s%d: %s G=%d S=%d band=%d bands=%d tiles=%d lds=%zu grid=%d\n", planes, h, w, oh, ow, st,
                 e.ok ? "ok" : "fallback", e.plan.a.G, e.plan.a.S, e.plan.a.band_rows, e.plan.a.n_bands, e.plan.a.n_tiles, e.plan.lds, e.plan.grid);
-    const bool tuning = getenv("PVHIP_POOL3_CFG") || getenv("PVHIP_POOL3_KB") || getenv("PVHIP_POOL3_WG") || getenv("PVHIP_POOL3_STAGE");
-    if (cache.size() < 256 && !tuning) cache.push_back(e);
+    if (cache.size() >= 256) cache.clear();
+    cache.push_back(e);
     if (!e.ok) return false;
     out = e.plan;
     return true;
@@ -676,8 +674,7 @@ int pvhip_maxpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
     // LDS-staged path.  ~16 KB of LDS per workgroup (8-10 workgroups per CU overlap each other's load and
     // compute phases; measured best on the GoogLeNet shapes): several whole planes per workgroup when planes
     // are small, bands of output rows of one plane when a plane is larger than the budget.
-    size_t group_bytes = 16 * 1024;
-    if (const char* e = getenv("PVHIP_POOL_LDS_KB")) group_bytes = (size_t)atoi(e) * 1024;   // tuning runs only
+    const size_t group_bytes = (size_t)settings().pool_lds_kb * 1024;       // PVHIP_POOL_LDS_KB: tuning runs only
     const size_t row_bytes   = (size_t)a.wp * sizeof(float);
     const size_t plane_bytes = (size_t)a.hp * row_bytes;
     const size_t min_band    = (size_t)(kh + sh) * row_bytes;       // at least two output rows per band

@@ -236,11 +236,8 @@ bool pooled_supported(int n, int c, int h, int w, int k_out) {
     // Default: only rows that are whole 16-byte groups (the 28x28 modules: 3a 0.118 -> 0.099 ms, 3b 0.176 -> 0.138).  The 8-byte
     // form (14x14 modules, PVHIP_FUSE_POOLCONV=2) issues 4.5 loads per pooled value and is slower than the two launches
     // (0.081 -> 0.095 ms on 4a); with it the pass loses what the 28x28 modules gain.
-    int min_vec = 4;
-    if (const char* e = getenv("PVHIP_FUSE_POOLCONV")) {
-        if (e[0] == '0') return false;
-        if (e[0] == '2') min_vec = 2;
-    }
+    if (settings().fuse_poolconv == 0) return false;
+    const int min_vec = settings().fuse_poolconv == 2 ? 2 : 4;
     if (w % min_vec != 0) return false;
     if (n <= 0 || c < kBK || c % kBK != 0 || h <= 0 || w <= 0 || k_out <= 0 || k_out > 128) return false;
     if (w % 2 != 0) return false;                                       // aligned 8- or 16-byte groups that never straddle a row

@@ -3,6 +3,7 @@
 // pool (the scheduler keeps every activation alive between infer() calls and re-produces the same
 // shapes every call, so exact-size reuse makes steady-state allocation free), copies, events and
 // hipGraph capture of a whole forward pass.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -16,6 +17,61 @@ namespace pvhip {
 State& state() {
     static State s;
     return s;
+}
+
+static Settings g_settings;
+const Settings& settings() {
+    if (g_settings.generation == 0) load_settings();     // a *_supported query before pvhip_init (no device needed)
+    return g_settings;
+}
+
+void load_settings() {
+    Settings s;
+    s.generation = g_settings.generation + 1;
+    auto env   = [](const char* name) -> const char* { const char* e = getenv(name); return (e != nullptr && e[0] != 0) ? e : nullptr; };
+    auto is0   = [&](const char* name) { const char* e = env(name); return e != nullptr && e[0] == '0'; };
+    auto is1   = [&](const char* name) { const char* e = env(name); return e != nullptr && e[0] == '1'; };
+    auto num   = [&](const char* name, int dflt) { const char* e = env(name); return e != nullptr ? atoi(e) : dflt; };
+    auto tri   = [&](const char* name) { const char* e = env(name); return e == nullptr ? 1 : (e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1)); };
+    if (const char* e = env("PVHIP_CONV_KERNEL")) s.conv_kernel = strcmp(e, "lds") == 0 ? 1 : (strcmp(e, "wave") == 0 ? 2 : 0);
+    s.conv_winograd  = !is0("PVHIP_CONV_WINOGRAD");
+    s.conv_winograd4 = tri("PVHIP_CONV_WINOGRAD4");
+    s.conv_winograd5 = tri("PVHIP_CONV_WINOGRAD5");
+    s.conv_pointwise = !is0("PVHIP_CONV_POINTWISE");
+    s.conv_stem      = is1("PVHIP_CONV_STEM");
+    if (const char* e = env("PVHIP_FUSE_POOLCONV")) s.fuse_poolconv = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+    s.pool3 = !(env("PVHIP_POOL3") != nullptr && num("PVHIP_POOL3", 1) == 0);
+    if (const char* e = env("PVHIP_CONV_TILE")) {
+        int bm = 0, bn = 0;
+        if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 32 || bm == 64 || bm == 128) && (bn == 128 || bn == 256)) { s.tile_bm = bm; s.tile_bn = bn; }
+    }
+    if (const char* e = env("PVHIP_CONV_WTILE")) sscanf(e, "%dx%d", &s.wtile_m, &s.wtile_n);
+    s.conv_lds_pad_kb = num("PVHIP_CONV_LDS_PAD_KB", 0);
+    s.conv_nopw = env("PVHIP_CONV_NOPW") != nullptr;
+    s.conv_pw16 = env("PVHIP_CONV_PW") != nullptr;
+    { const int v = num("PVHIP_CONV_MULTI_BM", 32); s.multi_bm = (v == 64 || v == 128) ? v : 32; }
+    s.pw_stagger_pct = num("PVHIP_PW_STAGGER", 0);
+    s.pw_tn = num("PVHIP_PW_TN", 0);
+    s.pool3_kb    = num("PVHIP_POOL3_KB", 16);
+    s.pool3_stage = num("PVHIP_POOL3_STAGE", 1) != 0;
+    s.pool3_wg    = num("PVHIP_POOL3_WG", 0);
+    if (const char* e = env("PVHIP_POOL3_CFG")) {
+        int g = 0, sg = 0, band = 0;
+        if (sscanf(e, "%d,%d,%d", &g, &sg, &band) == 3 && g > 0 && sg > 0 && band > 0) { s.pool3_g = g; s.pool3_s = sg; s.pool3_band = band; }
+    }
+    s.pool3_verbose = env("PVHIP_POOL3_VERBOSE") != nullptr;
+    s.pool_lds_kb   = num("PVHIP_POOL_LDS_KB", 16);
+    s.stem_wg       = num("PVHIP_STEM_WG", 0);
+    { const int v = num("PVHIP_WINO_KB", 0); s.wino_kb = (v == 32 || v == 64) ? v : 0; }
+    s.wino_small = !is0("PVHIP_WINO_SMALL");
+    s.wino_waves = num("PVHIP_WINO_WAVES", 8) == 4 ? 4 : 8;
+#ifdef PVHIP_DIAG
+    s.conv_ablate  = num("PVHIP_CONV_ABLATE", 0);
+    s.stem_ablate  = num("PVHIP_STEM_ABLATE", 0);
+    s.wino4_ablate = num("PVHIP_WINO4_ABLATE", 0);
+    s.pw_ablate    = num("PVHIP_PW_ABLATE", 0);
+#endif
+    g_settings = s;
 }
 
 static thread_local char g_err[512] = "no error";
@@ -109,6 +165,12 @@ int pvhip_init(int device) {
     s.forked  = false;
     s.device = device;
     s.ready  = true;
+    load_settings();
+    return PVHIP_OK;
+}
+
+int pvhip_settings_reload(void) {
+    load_settings();
     return PVHIP_OK;
 }
 

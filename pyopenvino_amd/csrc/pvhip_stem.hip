@@ -261,8 +261,7 @@ bool stem_eligible(int c, int kh, int kw, int sh, int sw, int k_out, int pad_top
     // Opt-in (PVHIP_CONV_STEM=1).  Alone on the chip this kernel beats the general one (0.74 against 0.83 ms on conv1), but in the
     // forward pass with several requests in flight it LOSES 2 % of the images/s: its persistent workgroups hold 128 KB of every
     // CU's LDS for the whole launch, so the bandwidth-bound kernels of the other requests cannot move in beside it.
-    const char* e = getenv("PVHIP_CONV_STEM");
-    if (e == nullptr || e[0] != '1') return false;
+    if (!settings().conv_stem) return false;
     return c == kC && kh == kKH && kw == kKW && sh == kST && sw == kST && k_out <= 64 && pad_top >= 0 && pad_left >= 0;
 }
 
@@ -286,17 +285,17 @@ int stem_conv(const float* x, const float* pre_add, const float* wl, float* y, i
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
     a.wl_bytes = (unsigned)(kPanel * sizeof(float));
     a.y_bytes  = (unsigned)((size_t)n * out_channels_total * oh * ow * sizeof(float));      // pvhip_conv2d_f32 keeps outputs below 2^31 elements... and this kernel below 2^31 bytes
-    int per_cu = 2;
-    if (const char* e = getenv("PVHIP_STEM_WG")) per_cu = atoi(e) > 0 ? atoi(e) : 2;     // tuning runs only
+    const int per_cu = settings().stem_wg > 0 ? settings().stem_wg : 2;     // PVHIP_STEM_WG: tuning runs only
     const int grid = (int)(tiles < (long)per_cu * kNumCU ? tiles : (long)per_cu * kNumCU);
-    int abl = 0;
-    if (const char* e = getenv("PVHIP_STEM_ABLATE")) abl = atoi(e);     // diagnostic builds: results are wrong on purpose
-    switch (abl) {
-        case 1: hipLaunchKernelGGL(conv_stem7x7_kernel<1>, dim3(grid), dim3(kBlock), 0, state().stream, a); break;
-        case 2: hipLaunchKernelGGL(conv_stem7x7_kernel<2>, dim3(grid), dim3(kBlock), 0, state().stream, a); break;
-        case 3: hipLaunchKernelGGL(conv_stem7x7_kernel<3>, dim3(grid), dim3(kBlock), 0, state().stream, a); break;
-        default: hipLaunchKernelGGL(conv_stem7x7_kernel<0>, dim3(grid), dim3(kBlock), 0, state().stream, a);
+#ifdef PVHIP_DIAG
+    switch (settings().stem_ablate) {     // diagnostic build only (libpvhip_diag.so): results are wrong on purpose
+        case 1: hipLaunchKernelGGL(conv_stem7x7_kernel<1>, dim3(grid), dim3(kBlock), 0, state().stream, a); return PVHIP_OK;
+        case 2: hipLaunchKernelGGL(conv_stem7x7_kernel<2>, dim3(grid), dim3(kBlock), 0, state().stream, a); return PVHIP_OK;
+        case 3: hipLaunchKernelGGL(conv_stem7x7_kernel<3>, dim3(grid), dim3(kBlock), 0, state().stream, a); return PVHIP_OK;
+        default: break;
     }
+#endif
+    hipLaunchKernelGGL(conv_stem7x7_kernel<0>, dim3(grid), dim3(kBlock), 0, state().stream, a);
     return PVHIP_OK;
 }
 

@@ -30,4 +30,17 @@ int    stem_pack(const float* w_oihw, float* wl, int k);
 int    stem_conv(const float* x, const float* pre_add, const float* wl, float* y, int n, int h, int w, int k_out, int oh, int ow, int pad_top,
                  int pad_left, const float* bias, int act, float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
 
+// Pointwise (1x1 / stride 1 / unpadded, C a multiple of 16) convolutions (pvhip_pw.hip): weights in MFMA-fragment order, one
+// workgroup per pixel tile and group of <= 8 32-channel tiles; PVHIP_CONV_POINTWISE=0 selects the general kernel
+struct PwDest {
+    float* y;
+    int    m_begin, k;      // first panel row of this destination's channels, real channels in it
+    int    ctotal, coff;    // channels of the tensor y points into, first channel of this convolution in it
+};
+bool   pw_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow);
+size_t pw_pack_elems(int k, int c);
+int    pw_pack(const float* w_oihw, float* ap, int k, int c);
+int    pw_conv(const float* x, const float* ap, int n, int c, int hw, int k_panel, const float* bias, int act, float act_lo, float act_hi,
+               int ndest, const PwDest* dests);
+
 }  // namespace pvhip

@@ -698,19 +698,15 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
 namespace pvhip {
 
 bool wino_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow) {
-    const char* e       = getenv("PVHIP_CONV_WINOGRAD");      // "0": the direct kernels (A/B measurements, their tests)
-    const bool  enabled = e == nullptr || e[0] != '0';
-    return enabled && kh == 3 && kw == 3 && sh == 1 && sw == 1 && pad_top == 1 && pad_left == 1 && oh == h && ow == w &&
+    return settings().conv_winograd &&      // PVHIP_CONV_WINOGRAD=0: the direct kernels (A/B measurements, their tests)
+           kh == 3 && kw == 3 && sh == 1 && sw == 1 && pad_top == 1 && pad_left == 1 && oh == h && ow == w &&
            c % kCB == 0 && c >= kCB;
 }
 
 // Output channels per workgroup (and per block of the transformed panel): 64 when K is made of whole 64-channel blocks
 // (each input patch is then gathered and transformed once per 64 output channels), else 32.
 static int wino_kb(int k) {
-    if (const char* e = getenv("PVHIP_WINO_KB")) {       // tuning runs only
-        const int v = atoi(e);
-        if (v == 32 || v == 64) return v;
-    }
+    if (settings().wino_kb) return settings().wino_kb;       // PVHIP_WINO_KB: tuning runs only
     return ((k + 63) / 64 * 64) * 100 <= k * 112 ? 64 : 32;      // whole 64-channel blocks, or at most 12 % of padding
 }
 
@@ -746,13 +742,11 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
     // 32-channel blocks run as 32 channels x 32 patches on four waves (more, smaller workgroups: the layers whose K is not
     // made of 64-channel blocks are the small 14x14 ones); PVHIP_WINO_SMALL=0 selects 32 x 64 on eight waves (tuning runs)
-    const char* se    = getenv("PVHIP_WINO_SMALL");
-    const bool  small = kb == 32 && !(se != nullptr && se[0] == '0');
+    const bool  small = kb == 32 && settings().wino_small;
     const int  nt   = (kb == 64 || small) ? 32 : 64;
     const long n_tb = ((long)a.T + nt - 1) / nt;
     if (n_tb * a.n_kb > 0x7fffffffL) return fail(PVHIP_EUNSUPPORTED, "wino_conv: grid too large");
-    const char* we    = getenv("PVHIP_WINO_WAVES");       // tuning runs only
-    const int   waves = (we != nullptr && atoi(we) == 4) ? 4 : 8;
+    const int   waves = settings().wino_waves;         // PVHIP_WINO_WAVES: tuning runs only
     const dim3  grid((unsigned)(n_tb * a.n_kb));
     if (small) hipLaunchKernelGGL((conv_wino_kernel<1, 1, 4>), grid, dim3(256), 0, state().stream, a);
     else if (kb == 64 && waves == 8) hipLaunchKernelGGL((conv_wino_kernel<2, 1, 8>), grid, dim3(512), 0, state().stream, a);
@@ -764,28 +758,25 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
 
 // ---- F(4x4, 3x3)
 bool wino4_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n) {
-    const char* e       = getenv("PVHIP_CONV_WINOGRAD4");     // "0": F(2x2, 3x3) everywhere
-    const bool  enabled = e == nullptr || e[0] != '0';
-    if (!enabled || !wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return false;
+    const int mode = settings().conv_winograd4;                // PVHIP_CONV_WINOGRAD4: 0 = F(2x2, 3x3) everywhere, 2 = "force"
+    if (mode == 0 || !wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return false;
     if (h % 4 != 0 || w % 4 != 0) return false;
     // 512 output pixels per workgroup: worth it where the patch blocks alone give every CU a workgroup
     const long patches = (long)n * (h / 4) * (w / 4);
-    const long min_patches = (e != nullptr && e[0] == 'f') ? 1 : 32L * kNumCU;           // "force": any size (tests)
+    const long min_patches = mode == 2 ? 1 : 32L * kNumCU;           // "force": any size (tests)
     return patches >= min_patches;
 }
 
 // F(2x2, 5x5): 5x5 / stride 1 / pad 2 ("same"), even extents, C a multiple of 4, enough patches (PVHIP_CONV_WINOGRAD5=0 switches it
 // off, =force drops the size rule)
 bool wino25_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n) {
-    const char* e = getenv("PVHIP_CONV_WINOGRAD5");
-    if (e != nullptr && e[0] == '0') return false;
-    const char* e3 = getenv("PVHIP_CONV_WINOGRAD");
-    if (e3 != nullptr && e3[0] == '0') return false;
+    const int mode = settings().conv_winograd5;
+    if (mode == 0 || !settings().conv_winograd) return false;
     if (!(kh == 5 && kw == 5 && sh == 1 && sw == 1 && pad_top == 2 && pad_left == 2 && oh == h && ow == w && c % kCB == 0 && c >= kCB))
         return false;
     if (h % 2 != 0 || w % 2 != 0) return false;
     const long patches = (long)n * (h / 2) * (w / 2);
-    return patches >= ((e != nullptr && e[0] == 'f') ? 1 : 32L * kNumCU);
+    return patches >= (mode == 2 ? 1 : 32L * kNumCU);
 }
 
 int wino25_pack(const float* w_oihw, float* u, int k, int c) {
@@ -827,19 +818,20 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     const long n_tb = ((long)a.T + 31) / 32;
     if (n_tb * a.n_kb > 0x7fffffffL) return fail(PVHIP_EUNSUPPORTED, "wino4_conv: grid too large");
     const dim3 grid((unsigned)(n_tb * a.n_kb));
-    int abl = 0;
-    if (const char* e = getenv("PVHIP_WINO4_ABLATE")) abl = atoi(e);      // diagnostic builds of the kernel: results are wrong on purpose
     if (m == 2) {
         hipLaunchKernelGGL((conv_wino4_kernel<2, 0>), grid, dim3(512), 0, state().stream, a);
         return PVHIP_OK;
     }
-    switch (abl) {
-        case 1: hipLaunchKernelGGL((conv_wino4_kernel<4, 1>), grid, dim3(512), 0, state().stream, a); break;
-        case 2: hipLaunchKernelGGL((conv_wino4_kernel<4, 2>), grid, dim3(512), 0, state().stream, a); break;
-        case 3: hipLaunchKernelGGL((conv_wino4_kernel<4, 3>), grid, dim3(512), 0, state().stream, a); break;
-        case 4: hipLaunchKernelGGL((conv_wino4_kernel<4, 4>), grid, dim3(512), 0, state().stream, a); break;
-        default: hipLaunchKernelGGL((conv_wino4_kernel<4, 0>), grid, dim3(512), 0, state().stream, a);
+#ifdef PVHIP_DIAG
+    switch (settings().wino4_ablate) {      // diagnostic build only (libpvhip_diag.so): results are wrong on purpose
+        case 1: hipLaunchKernelGGL((conv_wino4_kernel<4, 1>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        case 2: hipLaunchKernelGGL((conv_wino4_kernel<4, 2>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        case 3: hipLaunchKernelGGL((conv_wino4_kernel<4, 3>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        case 4: hipLaunchKernelGGL((conv_wino4_kernel<4, 4>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        default: break;
     }
+#endif
+    hipLaunchKernelGGL((conv_wino4_kernel<4, 0>), grid, dim3(512), 0, state().stream, a);
     return PVHIP_OK;
 }
 

@@ -26,6 +26,7 @@ SIGNATURES = {
     'pvhip_last_error': (_c.c_char_p, []),
     'pvhip_device_count': (_c.c_int, [_c.POINTER(_c.c_int)]),
     'pvhip_init': (_c.c_int, [_c.c_int]),
+    'pvhip_settings_reload': (_c.c_int, []),
     'pvhip_shutdown': (_c.c_int, []),
     'pvhip_device_name': (_c.c_int, [_c.c_char_p, _c.c_size_t]),
     'pvhip_malloc': (_c.c_int, [_c.POINTER(_c.c_void_p), _c.c_size_t]),
@@ -152,6 +153,12 @@ def init(device: int = None) -> int:
     call('pvhip_init', int(device))
     _initialised_device = device
     return device
+
+
+def reload_settings():
+    """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
+    query that needs them; no device needed)."""
+    call('pvhip_settings_reload')
 
 
 def ensure_init():

@@ -20,3 +20,13 @@ def hip():
     assert device.device_count() >= 1, 'no HIP device visible'
     device.init(0)
     return device
+
+
+@pytest.fixture(autouse=True)
+def _pvhip_settings_follow_the_environment():
+    """libpvhip parses the PVHIP_* variables once; tests flip them through helpers.setenv (which re-reads them).  Autouse
+    fixtures are set up first and torn down last, i.e. after monkeypatch has restored the environment: re-read it then."""
+    yield
+    from pyopenvino_amd import device
+    if device._lib is not None:
+        device.reload_settings()

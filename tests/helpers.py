@@ -16,6 +16,17 @@ BIT_EXACT = {'ReLU', 'MaxPool', 'Add', 'Multiply', 'Concat', 'Transpose', 'Resha
 REL_TOL = 1e-4
 
 
+def setenv(monkeypatch, name, value):
+    """Set (value None: unset) a PVHIP_* variable for this test and make libpvhip read its variables again: the library parses
+    them once, never on a launch path.  conftest.py re-reads them after every test (when monkeypatch has restored them)."""
+    from pyopenvino_amd import device
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, value)
+    device.reload_settings()
+
+
 def op_case_files():
     return sorted(glob.glob(os.path.join(GOLDEN, 'ops', '*.npz'))) + [os.path.join(GOLDEN, 'conv_node6_crop.npz')]
 

@@ -97,7 +97,7 @@ def test_googlenet_winograd_f4x4_end_to_end(hip, monkeypatch):
     conv2/3x3 and the 28x28 inception layers): the network output stays inside the stated tolerance of the reference's
     recorded output, with margin."""
     from pyopenvino_amd import synth
-    monkeypatch.setenv('PVHIP_CONV_WINOGRAD4', 'force')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD4', 'force')
     z = np.load(os.path.join(GOLDEN, 'googlenet_e2e.npz'))
     blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), int(z['weight_seed']))
     x = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)

@@ -106,7 +106,7 @@ def test_conv_stem_7x7_stride2(hip, monkeypatch):
     than workgroups and more, K below 64, asymmetric / no padding, fused bias + ReLU written in place into a wider tensor;
     against the oracle and against the general kernel."""
     from pyopenvino_amd import device as dev
-    monkeypatch.setenv('PVHIP_CONV_STEM', '1')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', '1')
     cases = [((2, 3, 224, 224), 64, (3, 3), (3, 3)), ((1, 3, 23, 31), 40, (3, 3), (3, 3)), ((3, 3, 40, 17), 7, (0, 0), (0, 0)),
              ((5, 3, 64, 64), 64, (2, 3), (1, 0)), ((1, 3, 7, 7), 3, (0, 0), (0, 0)), ((70, 3, 30, 30), 16, (3, 3), (3, 3))]
     for xs, k, pb, pe in cases:
@@ -122,7 +122,7 @@ def test_conv_stem_7x7_stride2(hip, monkeypatch):
     fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 5)
     hip_plugin('Convolution').compute(fused, {0: x, 1: w})
     got = np.asarray(wide)
-    monkeypatch.setenv('PVHIP_CONV_STEM', '0')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', '0')
     general = np.maximum(first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w})) + b, 0)
     assert_close(got[:, 5:29], general, 5e-6, 'stem fused vs the general kernel')
     assert np.all(got[:, :5] == -1.0) and np.all(got[:, 29:] == -1.0)
@@ -132,7 +132,7 @@ def test_conv_stem_with_the_add_in_front_folded_in_is_bit_identical(hip, monkeyp
     """Add(per-channel Const) -> 7x7 / stride 2 convolution handed over as one call (node['_fuse_pre_add']): the kernel adds
     while it fetches its input patch, padding stays zero -- the bits of the two launches; other convolutions decline."""
     from pyopenvino_amd import device as dev
-    monkeypatch.setenv('PVHIP_CONV_STEM', '1')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', '1')
     conv, add = hip_plugin('Convolution'), hip_plugin('Add')
     x = rnd(7, (3, 3, 45, 38), 60.0, 100.0)
     m = np.array([-104.0, -117.0, -123.0], dtype=np.float32).reshape(1, 3, 1, 1)
@@ -158,7 +158,7 @@ def test_conv_winograd_f2x2_5x5(hip, monkeypatch):
     channel stages, ragged channel blocks, fewer patches than a workgroup holds, patch rows that end inside a 32-patch block,
     fused bias + ReLU written in place into a wider tensor; against the oracle and against the direct kernel."""
     from pyopenvino_amd import device as dev
-    monkeypatch.setenv('PVHIP_CONV_WINOGRAD5', 'force')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD5', 'force')
     cases = [((2, 4, 8, 8), 5), ((3, 20, 12, 14), 70), ((1, 16, 28, 28), 32), ((2, 32, 14, 14), 96), ((5, 8, 2, 2), 3), ((1, 12, 4, 22), 33)]
     for xs, k in cases:
         x = rnd(sum(xs), xs)
@@ -172,7 +172,7 @@ def test_conv_winograd_f2x2_5x5(hip, monkeypatch):
     fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
     hip_plugin('Convolution').compute(fused, {0: x, 1: w})
     got = np.asarray(wide)
-    monkeypatch.setenv('PVHIP_CONV_WINOGRAD5', '0')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD5', '0')
     direct = np.maximum(first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w})) + b, 0)
     assert_close(got[:, 7:47], direct, 2e-5, 'winograd F(2x2,5x5) fused vs direct')
     assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
@@ -183,7 +183,7 @@ def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     stages, ragged channel blocks, fewer patches than a workgroup holds, several images, fused bias + ReLU written in place
     into a wider tensor; against the oracle and against the direct kernel."""
     from pyopenvino_amd import device as dev
-    monkeypatch.setenv('PVHIP_CONV_WINOGRAD4', 'force')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD4', 'force')
     cases = [((2, 4, 8, 8), 5), ((3, 20, 12, 16), 70), ((1, 64, 56, 56), 32), ((2, 96, 28, 28), 128), ((5, 8, 4, 4), 3), ((1, 12, 4, 20), 33)]
     for xs, k in cases:
         x = rnd(sum(xs), xs)
@@ -197,7 +197,7 @@ def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
     hip_plugin('Convolution').compute(fused, {0: x, 1: w})
     got = np.asarray(wide)
-    monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD', '0')
     direct = np.maximum(first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w})) + b, 0)
     assert_close(got[:, 7:47], direct, 2e-5, 'winograd F(4x4) fused vs direct')
     assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
@@ -209,10 +209,10 @@ def test_conv_winograd_3x3(hip, monkeypatch, kb, waves):
     one and many channel stages, ragged channel blocks, fewer patches than a workgroup holds, fused bias + activation;
     every workgroup shape (32 / 64 output channels, 8 / 4 waves, the 32 x 32 four-wave form), the library's own choice first."""
     if kb is not None:
-        monkeypatch.setenv('PVHIP_WINO_KB', kb)
-        monkeypatch.setenv('PVHIP_WINO_SMALL', '1' if waves == 'small' else '0')
+        helpers.setenv(monkeypatch, 'PVHIP_WINO_KB', kb)
+        helpers.setenv(monkeypatch, 'PVHIP_WINO_SMALL', '1' if waves == 'small' else '0')
         if waves != 'small':
-            monkeypatch.setenv('PVHIP_WINO_WAVES', waves)
+            helpers.setenv(monkeypatch, 'PVHIP_WINO_WAVES', waves)
     cases = [((2, 4, 7, 7), 5), ((3, 20, 13, 11), 70), ((1, 64, 14, 14), 32), ((2, 96, 28, 28), 128), ((5, 8, 1, 1), 3),
              ((1, 12, 2, 9), 33)]
     for xs, k in cases:
@@ -224,11 +224,8 @@ def test_conv_winograd_3x3(hip, monkeypatch, kb, waves):
     x, w = rnd(1, (2, 32, 9, 9)), rnd(2, (40, 32, 3, 3), 0.1)
     node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
     wino = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
-    os.environ['PVHIP_CONV_WINOGRAD'] = '0'
-    try:
-        direct = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
-    finally:
-        del os.environ['PVHIP_CONV_WINOGRAD']
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD', '0')
+    direct = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
     assert_close(wino, direct, 5e-6, 'winograd vs direct')
     assert not np.array_equal(wino, direct)          # (they are different summations)
 
@@ -268,14 +265,14 @@ def test_conv_seeded_random_shapes(hip):
 
 def test_conv_every_tile_config(hip, monkeypatch):
     """Force each (BM, BN) instantiation on one shape that has ragged edges in both tile dimensions."""
-    monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD', '0')
     x = rnd(1, (3, 20, 13, 11))
     w = rnd(2, (150, 20, 3, 3), 0.1)
     x2 = rnd(3, (3, 32, 13, 11))
     w2 = rnd(4, (150, 32, 3, 3), 0.1)
-    monkeypatch.setenv('PVHIP_CONV_KERNEL', 'lds')      # register-staged kernels: c-major (C=20) and (r,s)-major (C=32)
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_KERNEL', 'lds')      # register-staged kernels: c-major (C=20) and (r,s)-major (C=32)
     for tile in ('32x128', '32x256', '64x128', '64x256', '128x128', '128x256'):
-        monkeypatch.setenv('PVHIP_CONV_TILE', tile)
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_TILE', tile)
         vs_oracle('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)), 'tile ' + tile)
         vs_oracle('Convolution', [x2, w2], conv_data((1, 1), (1, 1), (1, 1)), 'rs tile ' + tile)
 
@@ -283,13 +280,13 @@ def test_conv_every_tile_config(hip, monkeypatch):
 def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
     """The LDS-free wave-direct kernel, every wave tile, on shapes with ragged edges, padding, stride 2,
     an odd number of reduction stages and a 7x7 (64-bit mask) window."""
-    monkeypatch.setenv('PVHIP_CONV_KERNEL', 'wave')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_KERNEL', 'wave')
     cases = [((3, 20, 13, 11), (150, 20, 3, 3), (1, 1), (1, 1), (1, 1)),
              ((2, 48, 7, 7), (24, 48, 1, 1), (1, 1), (0, 0), (0, 0)),
              ((1, 3, 37, 37), (16, 3, 7, 7), (2, 2), (3, 3), (3, 3)),
              ((2, 9, 10, 10), (70, 9, 5, 5), (1, 1), (2, 2), (2, 2))]
     for tile in ('1x1', '1x2', '2x1', '2x2', '4x1', '1x4'):
-        monkeypatch.setenv('PVHIP_CONV_WTILE', tile)
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_WTILE', tile)
         for xs, ws, st, pb, pe in cases:
             x = rnd(sum(xs), xs)
             w = rnd(sum(ws), ws, 0.1)
@@ -299,7 +296,7 @@ def test_conv_wave_direct_kernel_every_tile(hip, monkeypatch):
 def test_conv_lds_dma_kernel_every_tile(hip, monkeypatch):
     """The LDS-DMA (buffer_load ... lds) kernel, both reduction orders, on every channel tile: zero padding
     through the out-of-range sentinel, stride 2, ragged pixel and channel tiles, one and many reduction stages."""
-    monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD', '0')
     cases = [((3, 32, 13, 11), (150, 32, 3, 3), (1, 1), (1, 1), (1, 1)),
              ((2, 48, 7, 7), (24, 48, 1, 1), (1, 1), (0, 0), (0, 0)),
              ((1, 16, 37, 37), (16, 16, 7, 7), (2, 2), (3, 3), (3, 3)),
@@ -311,7 +308,7 @@ def test_conv_lds_dma_kernel_every_tile(hip, monkeypatch):
              ((2, 9, 10, 10), (70, 9, 5, 5), (1, 1), (2, 2), (2, 2)),
              ((2, 1, 12, 12), (8, 1, 3, 3), (1, 1), (0, 0), (0, 0))]
     for tile in ('32x128', '64x128', '128x128'):
-        monkeypatch.setenv('PVHIP_CONV_TILE', tile)
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_TILE', tile)
         for xs, ws, st, pb, pe in cases:
             x = rnd(sum(xs), xs)
             w = rnd(sum(ws), ws, (2.0 / (ws[1] * ws[2] * ws[3])) ** 0.5)
@@ -321,8 +318,8 @@ def test_conv_lds_dma_kernel_every_tile(hip, monkeypatch):
 def test_conv_pointwise_16byte_gather_variant(hip, monkeypatch):
     """The opt-in 16-byte gather of the (r,s)-major kernel for 1x1 / stride 1 / unpadded layers (PVHIP_CONV_PW=1;
     off by default because it measured slower) stays correct, ragged last pixel tile included."""
-    monkeypatch.setenv('PVHIP_CONV_PW', '1')
-    monkeypatch.setenv('PVHIP_CONV_KERNEL', 'lds')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_PW', '1')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_KERNEL', 'lds')
     for xs, ws in [((3, 64, 14, 14), (96, 64, 1, 1)), ((2, 32, 6, 6), (40, 32, 1, 1)), ((5, 192, 28, 28), (16, 192, 1, 1))]:
         x = rnd(sum(xs), xs)
         w = rnd(sum(ws), ws, (2.0 / ws[1]) ** 0.5)
@@ -334,8 +331,8 @@ def test_conv_fused_bias_and_activation_bit_exact(hip, monkeypatch, kernel):
     """Fused epilogues (bias, then ReLU or Clamp) of both convolution kernels and of the depthwise kernel equal
     the separate Add / ReLU / Clamp launches bit for bit."""
     if kernel != 'default':
-        monkeypatch.setenv('PVHIP_CONV_KERNEL', kernel)
-        monkeypatch.setenv('PVHIP_CONV_WINOGRAD', '0')
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_KERNEL', kernel)
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD', '0')
     cases = [('Convolution', (2, 32, 9, 9), (40, 32, 3, 3)),     # (r,s)-major kernel (LDS-DMA by default)
              ('Convolution', (2, 5, 9, 9), (70, 5, 3, 3)),       # c-major kernel
              ('GroupConvolution', (2, 24, 11, 11), (24, 1, 1, 3, 3))]
@@ -601,7 +598,7 @@ def test_maxpool_then_1x1_convolution_as_one_launch_is_bit_identical(hip, monkey
     launches (zero pad cells take part in the max, NaN wins), also with fused bias + ReLU and written in place into a wider
     tensor; within the tolerance of the oracle's MaxPool -> Convolution."""
     from pyopenvino_amd import device as dev
-    monkeypatch.setenv('PVHIP_FUSE_POOLCONV', '2')          # also the 8-byte form (rows that are not whole 16-byte groups: off by default)
+    helpers.setenv(monkeypatch, 'PVHIP_FUSE_POOLCONV', '2')          # also the 8-byte form (rows that are not whole 16-byte groups: off by default)
     conv, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
     x = rnd(sum(xs), xs, 1.0, -0.4)
     x[0, 1, 2, 3] = np.nan if k == 40 else x[0, 1, 2, 3]
