@@ -9,19 +9,31 @@ host (and, for N > 1, an RCCL all-gather of the Result tensors first).  For N > 
 GPU with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; torch.distributed
 (gloo) is used for the rendezvous / barrier / max-over-ranks only.
 
+The timed region is a block of exactly K steps between barrier + device synchronisation on both sides (max over
+ranks); the block is repeated until at least --min-seconds (1 s) have been timed and the MEDIAN block is reported
+(`steps` = K, `ms_per_step` = median block / K, `timed_blocks`, `timed_region_s`).
+
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
-  roofline      for the dominant kernel (conv_igemm_kernel, fp32 MFMA): algorithmic FLOPs of all 57
-                Convolution launches of a step / their summed device time measured with hipEvents on the
-                compute stream inside the timed steps;
+  roofline      for the dominant kernels, the fp32-MFMA Convolution launches (Winograd forms, pointwise, implicit GEMM):
+                `achieved` = ALGORITHMIC flops (2*N*K*C*kh*kw*oh*ow) of a step's launches / their device time, measured
+                with hipEvents on the compute stream inside the timed blocks; `frac_executed` = the flops the matrix
+                cores actually EXECUTE (Winograd families scaled by 16/36, 36/144, 36/100) over the same time, which is
+                what compares with the MFMA peak; `per_kernel` = the same per kernel family with its own bound
+                min(MFMA peak, arithmetic intensity x HBM peak);
   cpu_baseline  the oracle (CPU restatement of the reference's 'special' path) timed on this host, N=1 per
-                image like the reference, on a bounded sample of the same workload.
-A per-op-type breakdown (device ms, algorithmic GB/s or TFLOP/s) goes to stderr and, if the directory
-exists, to gpurun_out/bench_breakdown.json.
+                image like the reference, on a bounded sample of the same workload;
+  single_request_images_per_sec   one synchronous infer() at a time (SURVEY 8(d): B / wall time of one infer, median);
+  hbm_copy_ceiling_GBs            what a plain device-to-device copy and the 16-byte ReLU stream reach on THIS box;
+  extra_configs                   BASELINE configs 2 (mnist batch 64) and 5 (ssd_mobilenet_v1_coco batch 128).
+A per-op-type breakdown goes to stderr and, if the directory exists, the per-layer table to gpurun_out/bench_layers.json
+(committed per round as profiles/rNN_layers.json).
 """
 import argparse
+import ctypes
 import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,8 +46,11 @@ if REPO not in sys.path:
 MODEL = 'googlenet-v1'
 BATCH_PER_GPU = 256
 WEIGHT_SEED = 1234
-PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA dense peak
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA dense peak (2.4 GHz)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+SAMPLE_EVERY = 20              # every 20th step of a timed block (the first included) runs alone, with event brackets
+KERNEL_NODES = {'Convolution', 'MatMul', 'MaxPool', 'AvgPool', 'Add', 'Multiply', 'ReLU', 'SoftMax', 'LRN',
+                'Concat', 'Transpose', 'GroupConvolution', 'Clamp', 'Sigmoid', 'DetectionOutput'}
 
 
 def node_work(node, inputs_shapes, out_shape):
@@ -93,6 +108,113 @@ def cpu_baseline(blob, n_images):
             'sample': '{} googlenet-v1 images, one N=1 forward each, oracle numpy/OpenBLAS plugins, {:.1f} s'.format(n_images, dt)}
 
 
+def copy_ceiling(device):
+    """Achieved HBM rate of a plain device-to-device copy and of the 16-byte-per-lane ReLU stream on this box, on a tensor
+    far larger than the 256 MiB Infinity Cache (GoogLeNet's conv1 output, 822 MB): the ceiling the memory-bound ops of the
+    pass can be held against (the spec's 8 TB/s is not reachable by any kernel)."""
+    n = 256 * 64 * 112 * 112
+    x, y = device.DeviceTensor.empty((n,)), device.DeviceTensor.empty((n,))
+    device.call('pvhip_memset', ctypes.c_void_p(x.ptr), 0, n * 4)
+    out = {}
+    for name, fn in (('memcpy_d2d', lambda: device.call('pvhip_memcpy_d2d', ctypes.c_void_p(y.ptr), ctypes.c_void_p(x.ptr), n * 4)),
+                     ('relu_stream', lambda: device.call('pvhip_relu_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n))):
+        fn()
+        device.synchronize()
+        e0 = device.Event().record()
+        for _ in range(10):
+            fn()
+        e1 = device.Event().record()
+        e1.synchronize()
+        out[name] = round(8.0 * n / (e0.elapsed_ms(e1) / 10 * 1e-3) / 1e9, 1)
+    out['tensor_MB'] = round(4.0 * n / 1e6, 1)
+    return out
+
+
+def median_infer_rate(ex, feed, batch, reps, warm=3):
+    from pyopenvino_amd import device
+    for _ in range(warm):
+        ex.infer(feed)
+    times = []
+    for _ in range(reps):
+        device.synchronize()
+        t0 = time.perf_counter()
+        ex.infer(feed)
+        times.append(time.perf_counter() - t0)
+    return batch / statistics.median(times), statistics.median(times) * 1e3
+
+
+def extra_configs(blob=None):
+    """BASELINE configs 2 and 5 next to the headline (one synchronous infer() at a time, input resident in HBM, result on the
+    host; median of 10-20): mnist batch 64 on the shipped weights, ssd_mobilenet_v1_coco batch 128 (whole IR: prior boxes
+    folded, DetectionOutput on the device) on synthetic weights.  Reference numbers for context (CPU, batch 1, hardware
+    unstated): integrity_test_expected_result.txt:8 mnist 'special' 8.6 ms, :50 googlenet 0.554 s, :71 ssd 18.26 s per image."""
+    from pyopenvino_amd import IECore, device, synth
+    out = []
+    ie = IECore()
+    net = ie.read_network(os.path.join(REPO, 'models', 'mnist.xml'))
+    net.set_batch(64)
+    ex = ie.load_network(net)
+    x = device.DeviceTensor.from_numpy(np.concatenate([synth.uniform_pixels(50 + i, (1, 1, 28, 28)) for i in range(64)], 0))
+    rate, ms = median_infer_rate(ex, {net.inputs[0]['name']: x}, 64, 20)
+    out.append({'workload': 'models/mnist.xml fp32 batch 64 (shipped weights)', 'images_per_sec': round(rate, 1), 'ms_per_infer': round(ms, 4),
+                'reference_cpu_ms_per_image': 8.6})
+    del ex, net
+    xml = os.path.join(REPO, 'models', 'ssd_mobilenet_v1_coco.xml')
+    net = ie.read_network(xml, weights=synth.synth_weights(xml, WEIGHT_SEED))
+    net.set_batch(128)
+    ex = ie.load_network(net)
+    x = device.DeviceTensor.from_numpy(synth.uniform_pixels(9, (128, 3, 300, 300)))
+    feed = {net.inputs[0]['name']: x}
+    rate, ms = median_infer_rate(ex, feed, 128, 10)
+    ex.device_timing, ex.compute_streams = 'all', 1
+    ex.infer(feed)
+    by_type = {}
+    for nid, typ, nm, t_ms in ex.device_times_ms():
+        by_type[typ] = by_type.get(typ, 0.0) + t_ms
+    ex.device_timing = None
+    for host_side in ('Const', 'Parameter', 'Reshape'):        # no launch behind them: their brackets time nothing but themselves
+        by_type.pop(host_side, None)
+    total = sum(by_type.values())
+    top = max(by_type.items(), key=lambda kv: kv[1])
+    work = collect_work(net)
+    conv_fl = sum(fl for nid, (fl, _) in work.items() if net.G.nodes[nid]['type'] == 'Convolution' and nid not in ex._fused_away)
+    out.append({'workload': 'models/ssd_mobilenet_v1_coco.xml fp32 batch 128, whole IR (synthetic weights seed {})'.format(WEIGHT_SEED),
+                'images_per_sec': round(rate, 1), 'ms_per_infer': round(ms, 3),
+                'dominant_op': top[0], 'dominant_op_fraction_of_device_time': round(top[1] / total, 3),
+                'convolution_TFLOPs_algorithmic': round(conv_fl / (by_type.get('Convolution', 1e9) * 1e-3) / 1e12, 1),
+                'device_ms_by_op': {k: round(v, 3) for k, v in sorted(by_type.items(), key=lambda kv: -kv[1])[:6]},
+                'reference_cpu_ms_per_image': 18260.0})
+    del ex, net, x
+    if blob is not None:
+        # SURVEY 8(f)-4: the FP16 IR of the headline model (every constant stored as f16, what Model Optimizer --data_type FP16
+        # writes) read with fp16_as_fp32=False: Convolution and MatMul round their operands to fp16 and run on the f16 matrix
+        # cores with fp32 accumulation, every tensor stays fp32 in HBM.  A separate entry: never the headline dtype.
+        import tempfile
+        gxml = os.path.join(REPO, 'models', MODEL + '.xml')
+        with tempfile.TemporaryDirectory() as tmp:
+            xml16, blob16 = synth.fp16_ir(gxml, blob, tmp)
+            net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+        assert net.f16_mfma
+        net.set_batch(BATCH_PER_GPU)
+        ex = ie.load_network(net)
+        x = device.DeviceTensor.from_numpy(synth.uniform_pixels(1000, (BATCH_PER_GPU, 3, 224, 224)))
+        feed = {net.inputs[0]['name']: x}
+        rate, ms = median_infer_rate(ex, feed, BATCH_PER_GPU, 10)
+        ex.device_timing, ex.compute_streams = {'Convolution'}, 1
+        ex.infer(feed)
+        conv_ms = sum(t[3] for t in ex.device_times_ms())
+        ex.device_timing = None
+        work = collect_work(net)
+        conv_fl = sum(fl for nid, (fl, _) in work.items() if net.G.nodes[nid]['type'] == 'Convolution')
+        out.append({'workload': 'models/googlenet-v1.xml as an FP16 IR, batch 256: fp16 operands on the f16 matrix cores (v_mfma_f32_32x32x16_f16), fp32 '
+                                'accumulation, fp32 tensors in HBM; one synchronous infer() at a time',
+                    'dtype': 'f16 operands / f32 accumulate', 'images_per_sec': round(rate, 1), 'ms_per_infer': round(ms, 3),
+                    'convolution_ms': round(conv_ms, 3), 'convolution_TFLOPs_algorithmic': round(conv_fl / (conv_ms * 1e-3) / 1e12, 1),
+                    'note': 'first f16-MFMA kernel (one general implicit-GEMM form, register-staged fp32 -> fp16 gather): gather-bound, far from the '
+                            '2.5 PFLOP/s f16 MFMA peak'})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -101,11 +223,14 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU (BASELINE: 256)')
     ap.add_argument('--cpu-images', type=int, default=60, help='images timed on the CPU baseline (0 = skip)')
     ap.add_argument('--no-node-timing', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip extra_configs (mnist batch 64, SSD batch 128)')
+    ap.add_argument('--min-seconds', type=float, default=1.0, help='repeat the block of --steps steps until this much has been timed')
     ap.add_argument('--streams', type=int, default=0, help='compute streams the scheduler forks branches onto (0 = engine default)')
     ap.add_argument('--requests', type=int, default=8, help='infer requests in flight per GPU (each a whole batch; 1 = synchronous infer())')
     args = ap.parse_args()
 
     from pyopenvino_amd import IECore, device, shard, synth
+    from pyopenvino_amd.op_plugins import Convolution as conv_plugin
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
@@ -129,17 +254,11 @@ def main():
     ex.comm = comm
     # The Result gather goes over RCCL; if the communicator cannot be created on ANY rank (no librccl, no peer access) all
     # ranks agree to gather through the host group instead -- said loudly on stderr and in the JSON line, never silently.
-    gather_path, rccl_error = ('rccl' if comm.use_rccl else ('none (one rank)' if world == 1 else 'host group (PVHIP_NO_RCCL=1)')), ''
-    if comm.use_rccl:
-        try:
-            comm.init_device()
-        except Exception as exc:       # noqa: BLE001 -- whatever it is, the other ranks must hear about it
-            rccl_error = '{}: {}'.format(type(exc).__name__, exc)
-        if group.allreduce_max(1.0 if rccl_error else 0.0) > 0.0:
-            comm.use_rccl = False
-            gather_path = 'host group (RCCL communicator unavailable{})'.format(': ' + rccl_error if rccl_error else ' on another rank')
-            print('bench.py rank {}: RCCL unavailable, gathering Result tensors through the host group. {}'.format(rank, rccl_error),
-                  file=sys.stderr, flush=True)
+    gather_path, rccl_error = comm.agree_on_gather()
+    if gather_path.startswith('host group (RCCL'):
+        print('bench.py rank {}: RCCL unavailable, gathering Result tensors through the host group. {}'.format(rank, rccl_error),
+              file=sys.stderr, flush=True)
+    rccl_ranks = comm.rccl_ranks()      # ncclCommCount: what RCCL itself says the world is (0: no communicator)
 
     # synthetic input of this rank's shard, resident in HBM before the timed region
     x_host = synth.uniform_pixels(1000 + rank, (args.batch, 3, 224, 224))
@@ -147,8 +266,6 @@ def main():
     x_req = [x_dev] + [device.DeviceTensor.from_numpy(synth.uniform_pixels(1000 + rank + 100 * r, (args.batch, 3, 224, 224)))
                        for r in range(1, n_req)]
     in_name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
-
-    SAMPLE_EVERY = 20        # every 20th timed step (the first one included) is taken out of the pipeline and instrumented
     dispatch_s = [0.0]       # host seconds spent dispatching asynchronous passes
 
     def pipelined(steps, first=0, on_sample=None):
@@ -177,29 +294,34 @@ def main():
     for req in ex.requests:
         for _ in range(3):
             req.infer({in_name: x_req[req.index]})
-    KERNEL_NODES = {'Convolution', 'MatMul', 'MaxPool', 'AvgPool', 'Add', 'Multiply', 'ReLU', 'SoftMax', 'LRN',
-                    'Concat', 'Transpose', 'GroupConvolution', 'Clamp', 'Sigmoid'}
+    informational = rank == 0 and world == 1 and not args.no_node_timing
     per_node = {}
-    # informational, before the warm-up and the timed region (so that those are the last launches of the process,
-    # which is what the committed rocprofv3 summary compares with): the same step fed from a HOST array (Parameter
-    # uploads 154 MB over PCIe from pageable memory, then the forward pass) -- SURVEY 8(d) asks for the end-to-end
-    # rate beside the resident one; then the per-layer breakdown, one bracket per node
-    pcie_ms = None
-    if rank == 0 and world == 1 and not args.no_node_timing:
+    pcie_ms = single_rate = single_ms = ceiling = None
+    if informational:
+        ceiling = copy_ceiling(device)
+        # the same step fed from a HOST array (Parameter uploads 154 MB over PCIe from pageable memory, then the forward
+        # pass) -- SURVEY 8(d) asks for the end-to-end rate beside the resident one
         ex.device_timing, ex.compute_streams = None, n_streams
         ex.infer({in_name: x_host})
         t1 = time.perf_counter()
         for _ in range(3):
             ex.infer({in_name: x_host})
         pcie_ms = (time.perf_counter() - t1) / 3 * 1e3
+        # ONE request at a time, the reference's own metric shape (inference_engine.py:295-321: B / wall time of one
+        # exenet.infer()): the inception arms forked onto the engine's default 4 streams, nothing else in flight
+        saved = (ex.compute_streams, ex.stream_base)
+        ex.compute_streams, ex.stream_base = int(os.environ.get('PVHIP_STREAMS', '4')), 0
+        single_rate, single_ms = median_infer_rate(ex, {in_name: x_dev}, args.batch, 11)
+        ex.compute_streams, ex.stream_base = saved
     ex.device_timing_runs = False
     ex.compute_streams = 1
-    if not args.no_node_timing and rank == 0 and world == 1:
+    if informational:
+        # the per-layer breakdown, one hipEvent bracket per launch, on one stream, untimed
         ex.device_timing = KERNEL_NODES
-        for _ in range(2):
+        for _ in range(3):
             ex.infer({in_name: x_dev})
             for nid, typ, name, ms in ex.device_times_ms():
-                per_node.setdefault(nid, [typ, name, 0.0])[2] += ms / 2.0
+                per_node.setdefault(nid, [typ, name, 0.0])[2] += ms / 3.0
         ex.device_timing = None
     ex.compute_streams = n_streams
 
@@ -208,17 +330,12 @@ def main():
         out = ex.infer({in_name: x_dev})[out_name]
     assert out.shape == (args.batch * world, 1000) and np.isfinite(out).all()
 
-    # A hipEvent bracket costs ~10-15 us of stream time, so inside the timed region only the dominant kernel
-    # (the Convolution launches) is bracketed, one bracket per RUN of consecutive Convolution launches (~14 runs
-    # of 57 launches per step) and only on every 20th step, which runs alone and on one stream; the per-layer breakdown (one bracket per node, each
-    # inflated by its bracket) is taken in an extra, untimed pass afterwards and is informational only.
-    conv_ms, conv_launches, conv_brackets = 0.0, 0, 0
-    sampled_steps = 0
+    # A hipEvent bracket costs ~10-15 us of stream time, so inside the timed region only the dominant kernels
+    # (the Convolution launches) are bracketed, one bracket per RUN of consecutive Convolution launches and only on every
+    # 20th step, which runs alone and on one stream.
+    conv_ms, conv_launches, conv_brackets, sampled_steps = 0.0, 0, 0, 0
     host_dispatch = 0.0
-    group.barrier()
-    device.synchronize()
-    t0 = time.perf_counter()
-    ev0 = device.Event().record()
+
     def sampled_step():
         nonlocal host_dispatch, sampled_steps, conv_ms, conv_launches, conv_brackets
         ex.device_timing, ex.device_timing_runs = {'Convolution'}, True
@@ -233,23 +350,40 @@ def main():
             conv_brackets += 1
         return res
 
-    if n_req > 1:
-        dispatch_s[0] = 0.0
-        out = pipelined(args.steps, 0, None if args.no_node_timing else sampled_step)
-        host_dispatch += dispatch_s[0]
-    else:
-        for step in range(args.steps):
-            if (not args.no_node_timing) and step % SAMPLE_EVERY == 0:
-                out = sampled_step()
-            else:
-                out = ex.infer({in_name: x_dev})[out_name]
-                host_dispatch += sum(t[3] for t in ex.last_node_times if t[1] != 'Result')
-    ev1 = device.Event().record()
-    device.synchronize()
-    group.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = group.allreduce_max(elapsed)
-    dev_ms = ev0.elapsed_ms(ev1)
+    def timed_block():
+        """EXACTLY args.steps steps between barrier + device synchronisation on both sides; max over ranks."""
+        nonlocal host_dispatch
+        group.barrier()
+        device.synchronize()
+        t0 = time.perf_counter()
+        ev0 = device.Event().record()
+        if n_req > 1:
+            dispatch_s[0] = 0.0
+            pipelined(args.steps, 0, None if args.no_node_timing else sampled_step)
+            host_dispatch += dispatch_s[0]
+        else:
+            for step in range(args.steps):
+                if (not args.no_node_timing) and step % SAMPLE_EVERY == 0:
+                    sampled_step()
+                else:
+                    ex.infer({in_name: x_dev})
+                    host_dispatch += sum(t[3] for t in ex.last_node_times if t[1] != 'Result')
+        ev1 = device.Event().record()
+        device.synchronize()
+        group.barrier()
+        elapsed = group.allreduce_max(time.perf_counter() - t0)
+        return elapsed, ev0.elapsed_ms(ev1)
+
+    blocks = []
+    while True:
+        blocks.append(timed_block())
+        # every rank takes the same decision: the block times are already the max over ranks
+        if sum(b[0] for b in blocks) >= args.min_seconds or len(blocks) >= 200:
+            break
+    elapsed = statistics.median(b[0] for b in blocks)
+    dev_ms = statistics.median(b[1] for b in blocks)
+    n_blocks = len(blocks)
+
     if rank == 0:
         total_images = args.batch * world * args.steps
         result = {
@@ -260,99 +394,155 @@ def main():
                                    'input resident in HBM, Result copied to host'.format(args.batch, WEIGHT_SEED),
                        'global_batch': args.batch * world,
                        'parallelism': 'batch shard x{} (one process per GPU), all-gather of Result'.format(world),
-                       'result_gather': gather_path,
+                       'result_gather': gather_path, 'rccl_ranks': rccl_ranks,
                        'requests_in_flight': n_req, 'compute_streams_per_request': n_streams},
+            'timed_blocks': n_blocks, 'timed_region_s': round(sum(b[0] for b in blocks), 3),
+            'block_ms_min_median_max': [round(1e3 * min(b[0] for b in blocks), 3), round(1e3 * elapsed, 3), round(1e3 * max(b[0] for b in blocks), 3)],
             'device_ms_per_step': dev_ms / args.steps,
-            'host_dispatch_ms_per_step': 1000.0 * host_dispatch / args.steps,
+            'host_dispatch_ms_per_step': 1000.0 * host_dispatch / (args.steps * n_blocks),
         }
+        if single_rate is not None:
+            result['single_request_images_per_sec'] = single_rate
+            result['single_request_ms_per_infer'] = single_ms
         if pcie_ms is not None:
             result['host_input_images_per_sec'] = args.batch / (pcie_ms * 1e-3)    # input uploaded from host memory every step
+        if ceiling is not None:
+            result['hbm_copy_ceiling_GBs'] = ceiling
         roof = None
         if sampled_steps:
             work = collect_work(net)
-            by_type = {}
+            G = net.G
+            by_type, families = {}, {}
             all_nodes = per_node
             if not all_nodes:   # multi-rank run: no per-layer pass, Convolution work from the graph
-                all_nodes = {nid: [net.G.nodes[nid]['type'], net.G.nodes[nid]['name'], 0.0]
-                             for nid in work if net.G.nodes[nid]['type'] == 'Convolution' and nid not in ex._fused_away}
-            for nid, (typ, name, ms) in list(all_nodes.items()):
+                all_nodes = {nid: [G.nodes[nid]['type'], G.nodes[nid]['name'], 0.0]
+                             for nid in work if G.nodes[nid]['type'] == 'Convolution' and nid not in ex._fused_away}
+            layers = []
+            for nid, (typ, name, ms) in sorted(all_nodes.items()):
                 fl, by = work.get(nid, (0.0, 0.0))
+                family, exec_fl = typ, (fl if typ == 'MatMul' else 0.0)
+                if typ == 'Convolution':
+                    family, frac = conv_plugin.kernel_kind(G.nodes[nid])
+                    exec_fl = fl * frac
                 sibs = getattr(ex, '_siblings', {}).get(nid)
                 if sibs:                 # convolutions of the same input launched together: all their flops, the input once
-                    in_bytes = 4.0 * int(np.prod(net.G.nodes[nid]['input'][0]['dims']))
+                    in_bytes = 4.0 * int(np.prod(G.nodes[nid]['input'][0]['dims']))
                     for sid in sibs:
                         sfl, sby = work.get(sid, (0.0, 0.0))
-                        fl, by = fl + sfl, by + sby - in_bytes
-                    work[nid] = (fl, by)
-                    all_nodes[nid] = [typ, name + ' (+{} siblings)'.format(len(sibs)), ms]
+                        fl, by, exec_fl = fl + sfl, by + sby - in_bytes, exec_fl + sfl
+                    name += ' (+{} siblings)'.format(len(sibs))
+                    family += ', sibling launch'
                 pin = getattr(ex, '_pool_conv', {}).get(nid)
-                if pin is not None:      # MaxPool folded into this 1x1 convolution (still a Convolution launch: same flops, same bytes)
-                    all_nodes[nid] = [typ, net.G.nodes[pin[0]]['name'] + ' + ' + name, ms]
+                if pin is not None:      # MaxPool folded into this 1x1 convolution (still one Convolution launch: same flops, same bytes)
+                    name = G.nodes[pin[0]]['name'] + ' + ' + name
+                    family = 'MaxPool + 1x1 (conv_pool1x1_kernel)'
                 pooled = getattr(ex, '_lrn_pool', {}).get(nid)
                 if pooled is not None:   # LRN and the MaxPool behind it as one launch: reads the LRN input once, writes the pooled tensor once
-                    typ = 'LRN+MaxPool'
-                    lrn_in = net.G.nodes[nid]['input'][0]['dims']
-                    pool_out = next(iter(net.G.nodes[pooled]['output'].values()))['dims']
+                    typ = family = 'LRN+MaxPool'
+                    lrn_in = G.nodes[nid]['input'][0]['dims']
+                    pool_out = next(iter(G.nodes[pooled]['output'].values()))['dims']
                     by = 4.0 * (int(np.prod(lrn_in)) + int(np.prod(pool_out)))
-                    work[nid] = (0.0, by)
-                    all_nodes[nid] = [typ, name + ' + ' + net.G.nodes[pooled]['name'], ms]
-                agg = by_type.setdefault(typ, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
-                agg['ms'] += ms
-                agg['flops'] += fl
-                agg['bytes'] += by
-                agg['launches'] += 1
+                    fl = 0.0
+                    name += ' + ' + G.nodes[pooled]['name']
+                for table, key in ((by_type, typ), (families, family)):
+                    agg = table.setdefault(key, {'ms': 0.0, 'flops': 0.0, 'exec': 0.0, 'bytes': 0.0, 'launches': 0})
+                    agg['ms'] += ms
+                    agg['flops'] += fl
+                    agg['exec'] += exec_fl
+                    agg['bytes'] += by
+                    agg['launches'] += 1
+                row = {'id': nid, 'type': typ, 'kernel': family, 'name': name, 'ms': round(ms, 4), 'gflop': round(fl / 1e9, 3),
+                       'gflop_executed': round(exec_fl / 1e9, 3), 'mb': round(by / 1e6, 2)}
+                if ms > 0:
+                    bound_tf = min(PEAK_MFMA_F32_TFLOPS, (fl / by) * PEAK_HBM_GBS / 1e3) if (fl > 0 and by > 0) else None
+                    row.update({'TFLOPs': round(fl / (ms * 1e-3) / 1e12, 2) if fl > 0 else None,
+                                'TFLOPs_executed': round(exec_fl / (ms * 1e-3) / 1e12, 2) if fl > 0 else None,
+                                'GBs': round(by / (ms * 1e-3) / 1e9, 1),
+                                'bound': ('mfma' if bound_tf == PEAK_MFMA_F32_TFLOPS else 'hbm') if fl > 0 else 'hbm',
+                                'bound_TFLOPs': round(bound_tf, 1) if bound_tf else None,
+                                'frac_of_bound': round((exec_fl / (ms * 1e-3) / 1e12) / bound_tf, 3) if bound_tf else round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)})
+                layers.append(row)
             conv = by_type.get('Convolution')
             if conv:
                 assert conv_launches == conv['launches'] * sampled_steps, (conv_launches, conv['launches'], sampled_steps)
-                conv['ms'] = conv_ms / sampled_steps             # run brackets inside the timed region
+                layer_pass_ms = conv['ms']
+                conv['ms'] = conv_ms / sampled_steps             # run brackets inside the timed blocks
                 n_launch = conv['launches']
                 flops_per_launch = conv['flops'] / n_launch          # algorithmic: 2*N*K*C*kh*kw*oh*ow, averaged
                 avg_launch_ms = conv['ms'] / n_launch                # hipEvents on the compute stream, timed steps
                 tf = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
+                tf_exec = conv['exec'] / (conv['ms'] * 1e-3) / 1e12
                 traffic, traffic_src = None, None
                 for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_traffic.json')), reverse=True):
                     try:
-                        k = json.load(open(path))['kernels']['conv_igemm_kernel']
+                        doc = json.load(open(path))
+                        k = doc['kernels']['convolution_kernels']
                         traffic = k['read_bytes_per_launch'] + k['write_bytes_per_launch']
-                        traffic_src = os.path.relpath(path, REPO)
+                        traffic_src = 'static: {} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_bench.sh, tree {}; ' \
+                                      'not re-measured in this run)'.format(os.path.relpath(path, REPO), doc.get('tree', 'unknown'))
                         break
                     except Exception:
                         continue
+                per_kernel = {}
+                for fam, agg in sorted(families.items(), key=lambda kv: -kv[1]['ms']):
+                    if agg['flops'] <= 0 or agg['ms'] <= 0:
+                        continue
+                    bound_tf = min(PEAK_MFMA_F32_TFLOPS, agg['flops'] / agg['bytes'] * PEAK_HBM_GBS / 1e3)
+                    per_kernel[fam] = {'launches': agg['launches'], 'ms': round(agg['ms'], 4),
+                                       'TFLOPs_algorithmic': round(agg['flops'] / (agg['ms'] * 1e-3) / 1e12, 1),
+                                       'TFLOPs_executed': round(agg['exec'] / (agg['ms'] * 1e-3) / 1e12, 1),
+                                       'bound_TFLOPs': round(bound_tf, 1),
+                                       'frac_executed_of_bound': round(agg['exec'] / (agg['ms'] * 1e-3) / 1e12 / bound_tf, 3)}
                 roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': tf / PEAK_MFMA_F32_TFLOPS, 'traffic': traffic,
-                        'kernel': 'conv_wino4_kernel (conv2/3x3, inception 3a / 3b 3x3: Winograd F(4x4,3x3), 36/144 of the algorithmic multiplies) + conv_wino_kernel '
-                                  '(the other seven 3x3 layers: F(2x2,3x3), 16/36; conv_wino4_kernel<2>: seven 5x5 layers, F(2x2,5x5), 36/100) + conv_igemm_dma_kernel '
-                                  '(conv1, 1x1, the 7x7-sized 5x5; the 1x1 / 3x3_reduce / 5x5_reduce convolutions of an inception module are one launch): '
-                                  '{} launches per step for the 57 '
-                                  'Convolution nodes, bias+ReLU fused'.format(n_launch),
-                        'launches_per_step': n_launch, 'flops_per_launch': flops_per_launch, 'avg_launch_us': avg_launch_ms * 1e3,
+                        'frac': tf / PEAK_MFMA_F32_TFLOPS,
+                        'frac_executed': tf_exec / PEAK_MFMA_F32_TFLOPS, 'achieved_executed': tf_exec,
+                        'frac_note': '`achieved` / `frac` count ALGORITHMIC flops (2*N*K*C*kh*kw*oh*ow: SURVEY 8(d)); the Winograd families execute 16/36 '
+                                     '(F(2x2,3x3)), 36/144 (F(4x4,3x3)) or 36/100 (F(2x2,5x5)) of them on the matrix cores, so `frac` can exceed what the MFMA pipe '
+                                     'does: `frac_executed` is executed flops / peak, the figure that compares with matrix-core utilisation',
+                        'traffic': traffic, 'traffic_source': traffic_src,
+                        'kernel': 'all Convolution launches of a step: conv_wino4_kernel (F(4x4,3x3), F(2x2,5x5)) + conv_wino_kernel (F(2x2,3x3)) + conv_pw_kernel '
+                                  '(1x1; the 1x1 / 3x3_reduce / 5x5_reduce convolutions of an inception module are one launch) + conv_pool1x1_kernel (MaxPool + pool_proj) '
+                                  '+ conv_igemm_dma_kernel (conv1, the 7x7-sized 5x5): {} launches per step for the 57 Convolution nodes, bias+ReLU fused'.format(n_launch),
+                        'launches_per_step': n_launch, 'flops_per_launch': flops_per_launch, 'flops_executed_per_launch': conv['exec'] / n_launch,
+                        'avg_launch_us': avg_launch_ms * 1e3,
                         'algorithmic_bytes_per_launch': conv['bytes'] / n_launch,
-                        'traffic_source': traffic_src, 'event_sampled_steps': sampled_steps,
-                        'measured_on': 'every 20th timed step (the first included), run alone on one stream (the other steps keep {} requests in flight with the inception '
-                                       'arms on {} streams each: kernels overlap and a launch has no duration of its own)'.format(n_req, n_streams),
-                        'event_brackets_per_step': conv_brackets // sampled_steps}
+                        'event_sampled_steps': sampled_steps,
+                        'measured_on': 'every {}th step of a timed block (the first included), run alone on one stream (the other steps keep {} requests in flight: '
+                                       'kernels overlap and a launch has no duration of its own)'.format(SAMPLE_EVERY, n_req),
+                        'event_brackets_per_step': conv_brackets // sampled_steps,
+                        'per_kernel': per_kernel,
+                        'per_kernel_measured_on': 'the untimed per-layer pass (one hipEvent bracket per launch, one stream; Convolution total there {:.3f} ms '
+                                                  'against {:.3f} ms with run brackets in the timed blocks)'.format(layer_pass_ms, conv['ms'])}
             breakdown = {}
             for typ, agg in sorted(by_type.items(), key=lambda kv: -kv[1]['ms']):
                 row = {'launches': agg['launches'], 'ms_per_step': round(agg['ms'], 4)}
                 if agg['flops'] > 0:
                     row['TFLOP/s'] = round(agg['flops'] / (agg['ms'] * 1e-3) / 1e12, 2)
+                    row['TFLOP/s executed'] = round(agg['exec'] / (agg['ms'] * 1e-3) / 1e12, 2) if agg['exec'] else None
                     row['frac_mfma_peak'] = round(row['TFLOP/s'] / PEAK_MFMA_F32_TFLOPS, 4)
                 if agg['ms'] > 0:
                     row['GB/s'] = round(agg['bytes'] / (agg['ms'] * 1e-3) / 1e9, 1)
                     row['frac_hbm_peak'] = round(row['GB/s'] / PEAK_HBM_GBS, 4)
                 breakdown[typ] = row
-            layers = [{'id': nid, 'type': typ, 'name': name, 'ms': round(ms, 4),
-                       'gflop': round(work.get(nid, (0, 0))[0] / 1e9, 3), 'mb': round(work.get(nid, (0, 0))[1] / 1e6, 2)}
-                      for nid, (typ, name, ms) in sorted(all_nodes.items())]
+            result['per_op'] = breakdown
             print('per-op breakdown (device time per step):', file=sys.stderr)
             for typ, row in breakdown.items():
                 print('  {:12s} {}'.format(typ, row), file=sys.stderr)
             out_dir = os.path.join(REPO, 'gpurun_out')
             if os.path.isdir(out_dir):
-                with open(os.path.join(out_dir, 'bench_breakdown.json'), 'w') as f:
-                    json.dump({'by_type': breakdown, 'layers': layers, 'device': device.device_name()}, f, indent=1)
+                with open(os.path.join(out_dir, 'bench_layers.json'), 'w') as f:
+                    json.dump({'device': device.device_name(), 'workload': result['config']['workload'],
+                               'note': 'per-launch device time from the untimed per-layer pass of bench.py (one hipEvent bracket per launch on one stream; a bracket '
+                                       'adds ~10 us); bound = min(157.3 TFLOP/s fp32 MFMA, arithmetic intensity x 8 TB/s); frac_of_bound uses EXECUTED flops',
+                               'by_type': breakdown, 'by_kernel_family': roof['per_kernel'] if roof else None, 'layers': layers}, f, indent=1)
         result['roofline'] = roof
-        # the CPU restatement of the reference path, on rank 0 at N=1 only (the other ranks would wait for it at the exit barrier)
+        # BASELINE configs 2 and 5 beside the headline, and the CPU restatement of the reference path: rank 0 at N=1 only
+        # (the other ranks would wait for it at the exit barrier)
+        if world == 1:
+            x_req = x_dev = None            # (closures above still name them)
+            for req in ex.requests:
+                req.runner.release_device_state()
+            result['extra_configs'] = extra_configs(blob) if not args.no_extra else None
         result['cpu_baseline'] = cpu_baseline(blob, args.cpu_images) if (args.cpu_images > 0 and world == 1) else None
         print(json.dumps(result), flush=True)
 

@@ -66,10 +66,10 @@ int         pvhip_sync(void);                           /* host-side wait for ev
 
 /* Compute streams.  Every launch and copy goes to the CURRENT stream (stream 0 after pvhip_init).  The
  * scheduler may put independent branches of the graph (inference_engine.py:218-242 orders them serially)
- * on up to 8 streams and order them with untimed events; blocks freed while a stream other than 0 has been
+ * on up to 8 streams (index 8 is for copies and the RCCL gather of requests in flight) and order them with untimed events; blocks freed while a stream other than 0 has been
  * used are handed out again only after the next full synchronisation (pvhip_sync, or pvhip_memcpy_d2h
  * issued on stream 0). */
-#define PVHIP_MAX_STREAMS 8
+#define PVHIP_MAX_STREAMS 9                             /* 8 compute streams + 1 for copies and the gather        */
 int         pvhip_stream_select(int index);             /* make stream `index` current (created on first use) */
 int         pvhip_stream_wait_event(void* ev);          /* current stream waits for a recorded event  */
 int         pvhip_event_create_untimed(void** ev);      /* ordering-only event (no timestamps)        */
@@ -169,6 +169,17 @@ int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
                         const float* bias, int relu,
                         int out_channel_offset, int out_channels_total,
                         float act_lo, float act_hi);
+/* Which kernel family pvhip_conv2d_f32 dispatches this geometry to (no device needed; honours the PVHIP_* switches): the
+ * benchmark's roofline needs it, because the Winograd families execute a fraction of the algorithmic multiplies on the
+ * matrix cores -- F(2x2,3x3) 16/36, F(4x4,3x3) 36/144, F(2x2,5x5) 36/100 -- and the direct families all of them.         */
+#define PVHIP_CONV_KIND_IGEMM        0   /* implicit GEMM, LDS-DMA tiles (pvhip_conv.hip)                    */
+#define PVHIP_CONV_KIND_POINTWISE    1   /* 1x1 / stride 1: fragment-ordered weights (pvhip_pw.hip)          */
+#define PVHIP_CONV_KIND_WINO_F2_3X3  2
+#define PVHIP_CONV_KIND_WINO_F4_3X3  3
+#define PVHIP_CONV_KIND_WINO_F2_5X5  4
+#define PVHIP_CONV_KIND_STEM         5   /* 7x7 / stride 2 / 3 channels                                       */
+int    pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
+                                int sh, int sw, int pad_top, int pad_left);
 /* Add.py:9-14 of a per-channel constant (1,c,1,1) followed by the convolution, as one launch: y = conv(x + pre_add[c]) with zero
  * padding applied AFTER the add, exactly as the two nodes do (the same fp32 add; bit-identical).  pre_add: c device floats.
  * Only where the convolution's own kernel fetches its input through registers -- the 7x7 / stride 2 / 3-channel stem
@@ -211,6 +222,22 @@ int    pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, 
                               const float* bias, int act, float act_lo, float act_hi,
                               int n_dest, const pvhip_conv_dest* dests);
 
+/* ---- FP16 IRs.  The reference runs an FP16 IR in numpy float16 (common_def.py:13-17; Convolution.py:57-87 and
+ * MatMul.py:9-17 then multiply AND accumulate in float16).  These entries take the same fp32 device tensors as their _f32
+ * twins, round both operands to fp16 (round to nearest even; the constants of an FP16 IR are fp16 values already) and
+ * accumulate in fp32 on the f16 matrix-core instructions (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate).  The engine
+ * selects them only for an FP16 IR read with fp16_as_fp32=False.  pvhip_conv2d_f16_pack_elems counts FLOATS of wpack.    */
+size_t pvhip_conv2d_f16_pack_elems(int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_f16_pack(const float* w_oihw, float* wpack, int k_out, int c, int kh, int kw, int h, int w);
+int    pvhip_conv2d_f16(const float* x, const float* wpack, float* y,
+                        int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
+                        int sh, int sw, int pad_top, int pad_left,
+                        const float* bias, int act,
+                        int out_channel_offset, int out_channels_total,
+                        float act_lo, float act_hi);
+int    pvhip_matmul_f16(const float* a, const float* b, float* c, int m, int n, int k,
+                        int trans_a, int trans_b);
+
 /* GroupConvolution.py:53-79 kernel_GroupConvolution_numpy, depthwise case only (weights
  * [G,1,1,kh,kw], one input and one output channel per group), applied to every image.  bias / act /
  * act_lo / act_hi: optional fused Add(per-channel Const) and ReLU (1) or Clamp (2), as for pvhip_conv2d_f32. */
@@ -236,7 +263,8 @@ int pvhip_detection_output_f32(const float* loc, const float* conf, const float*
 #define PVHIP_UNIQUE_ID_BYTES 128
 int pvhip_comm_unique_id(void* unique_id_out);
 int pvhip_comm_init(const void* unique_id, int rank, int world);
-int pvhip_comm_allgather_f32(const float* send, float* recv, size_t count_per_rank);
+int pvhip_comm_allgather_f32(const float* send, float* recv, size_t count_per_rank);   /* every rank the SAME count (ncclAllGather) */
+int pvhip_comm_ranks(int* count);                 /* ncclCommCount of the communicator: how many ranks RCCL itself sees */
 int pvhip_comm_destroy(void);
 
 #ifdef __cplusplus

@@ -1,6 +1,8 @@
 // The only inter-GPU exchange of the path: an all-gather of the Result tensor over RCCL (xGMI).
 // librccl.so is opened lazily so that single-GPU use never pays for (or depends on) it.
+// Types, enumerators and prototypes come from <rccl/rccl.h> (compile time); only the symbols are resolved with dlsym.
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cstring>
 
@@ -10,16 +12,16 @@ using namespace pvhip;
 
 namespace {
 
-struct UniqueId {
-    char internal[PVHIP_UNIQUE_ID_BYTES];
-};
-typedef void* Comm;
+static_assert(sizeof(ncclUniqueId) == PVHIP_UNIQUE_ID_BYTES, "pvhip.h promises a unique id of NCCL_UNIQUE_ID_BYTES bytes");
+typedef ncclUniqueId UniqueId;
+typedef ncclComm_t   Comm;
 
-typedef int (*GetUniqueIdFn)(UniqueId*);
-typedef int (*CommInitRankFn)(Comm*, int, UniqueId, int);
-typedef int (*AllGatherFn)(const void*, void*, size_t, int, Comm, hipStream_t);
-typedef int (*CommDestroyFn)(Comm);
-typedef const char* (*GetErrorStringFn)(int);
+typedef decltype(&ncclGetUniqueId)    GetUniqueIdFn;
+typedef decltype(&ncclCommInitRank)   CommInitRankFn;
+typedef decltype(&ncclAllGather)      AllGatherFn;
+typedef decltype(&ncclCommDestroy)    CommDestroyFn;
+typedef decltype(&ncclCommCount)      CommCountFn;
+typedef decltype(&ncclGetErrorString) GetErrorStringFn;
 
 struct Rccl {
     void*            handle = nullptr;
@@ -27,6 +29,7 @@ struct Rccl {
     CommInitRankFn   comm_init_rank = nullptr;
     AllGatherFn      all_gather = nullptr;
     CommDestroyFn    comm_destroy = nullptr;
+    CommCountFn      comm_count = nullptr;
     GetErrorStringFn get_error_string = nullptr;
     Comm             comm = nullptr;
     int              rank = 0, world = 1;
@@ -35,8 +38,6 @@ Rccl& rccl() {
     static Rccl r;
     return r;
 }
-
-constexpr int kNcclFloat = 7;  // ncclFloat32 in rccl.h
 
 int load_rccl() {
     Rccl& r = rccl();
@@ -51,8 +52,9 @@ int load_rccl() {
     r.comm_init_rank   = (CommInitRankFn)dlsym(r.handle, "ncclCommInitRank");
     r.all_gather       = (AllGatherFn)dlsym(r.handle, "ncclAllGather");
     r.comm_destroy     = (CommDestroyFn)dlsym(r.handle, "ncclCommDestroy");
+    r.comm_count       = (CommCountFn)dlsym(r.handle, "ncclCommCount");
     r.get_error_string = (GetErrorStringFn)dlsym(r.handle, "ncclGetErrorString");
-    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy)
+    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy || !r.comm_count)
         return fail(PVHIP_ECOMM, "librccl.so lacks a required symbol");
     return PVHIP_OK;
 }
@@ -60,7 +62,7 @@ int load_rccl() {
 int rccl_fail(const char* what, int code) {
     Rccl& r = rccl();
     return fail(PVHIP_ECOMM, "%s -> RCCL error %d (%s)", what, code,
-                r.get_error_string ? r.get_error_string(code) : "?");
+                r.get_error_string ? r.get_error_string((ncclResult_t)code) : "?");
 }
 
 }  // namespace
@@ -103,8 +105,18 @@ int pvhip_comm_allgather_f32(const float* send, float* recv, size_t count_per_ra
     if (r.comm == nullptr) return fail(PVHIP_ECOMM, "pvhip_comm_allgather_f32: communicator not initialised");
     if (count_per_rank == 0) return PVHIP_OK;
     PVHIP_CHECK_ARG(send != nullptr && recv != nullptr);
-    int e = r.all_gather(send, recv, count_per_rank, kNcclFloat, r.comm, state().stream);
+    int e = r.all_gather(send, recv, count_per_rank, ncclFloat32, r.comm, state().stream);
     if (e != 0) return rccl_fail("ncclAllGather", e);
+    return PVHIP_OK;
+}
+
+int pvhip_comm_ranks(int* count) {
+    PVHIP_CHECK_ARG(count != nullptr);
+    Rccl& r = rccl();
+    *count = 0;
+    if (r.comm == nullptr) return fail(PVHIP_ECOMM, "pvhip_comm_ranks: communicator not initialised");
+    int e = r.comm_count(r.comm, count);
+    if (e != 0) return rccl_fail("ncclCommCount", e);
     return PVHIP_OK;
 }
 

@@ -9,7 +9,7 @@
 
 namespace pvhip {
 
-constexpr int kMaxStreams = 8;
+constexpr int kMaxStreams = PVHIP_MAX_STREAMS;
 
 struct State {
     bool        ready  = false;

@@ -1169,6 +1169,16 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
                        out_channels_total, act_lo, act_hi);
 }
 
+int pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left) {
+    const unsigned long long out_e = (unsigned long long)n * k_out * oh * ow;
+    if (stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, out_e)) return PVHIP_CONV_KIND_STEM;
+    if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return PVHIP_CONV_KIND_POINTWISE;
+    if (wino25_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) return PVHIP_CONV_KIND_WINO_F2_5X5;
+    if (wino4_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) return PVHIP_CONV_KIND_WINO_F4_3X3;
+    if (wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return PVHIP_CONV_KIND_WINO_F2_3X3;
+    return PVHIP_CONV_KIND_IGEMM;
+}
+
 int pvhip_conv2d_preadd_supported(int n, int c, int kh, int kw, int sh, int sw, int k_out, int oh, int ow, int pad_top, int pad_left) {
     return stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, (unsigned long long)n * k_out * oh * ow) ? 1 : 0;
 }

@@ -70,6 +70,11 @@ SIGNATURES = {
     'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
     'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
     'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
+    'pvhip_conv2d_f16_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
+    'pvhip_conv2d_f16_pack': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
+    'pvhip_conv2d_f16': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
+    'pvhip_matmul_f16': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
     'pvhip_conv2d_preadd_supported': (_c.c_int, [_c.c_int] * 11),
     'pvhip_conv2d_preadd_f32': (_c.c_int, [_fp, _fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),
@@ -82,11 +87,12 @@ SIGNATURES = {
     'pvhip_comm_unique_id': (_c.c_int, [_c.c_void_p]),
     'pvhip_comm_init': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     'pvhip_comm_allgather_f32': (_c.c_int, [_fp, _fp, _c.c_size_t]),
+    'pvhip_comm_ranks': (_c.c_int, [_c.POINTER(_c.c_int)]),
     'pvhip_comm_destroy': (_c.c_int, []),
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported',
+_NOT_STATUS = {'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_preadd_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -206,6 +212,16 @@ class _Block:
         except Exception:
             pass
         self.ptr = 0
+
+    # One owner per device allocation: a copied _Block would free the same pointer twice (the second time possibly after
+    # the pool has handed the block to another tensor).
+    def __deepcopy__(self, memo=None):
+        raise PvhipError('a device block cannot be copied: strip device tensors from the graph first')
+
+    __copy__ = __deepcopy__
+
+    def __reduce__(self):
+        raise PvhipError('a device block cannot be pickled')
 
 
 def _contig_strides(shape):
@@ -368,11 +384,12 @@ def pool_epoch_end(epoch: int):
     call('pvhip_pool_epoch_end', int(epoch))
 
 
-MAX_STREAMS = 8     # PVHIP_MAX_STREAMS of include/pvhip.h
+MAX_STREAMS = 9      # PVHIP_MAX_STREAMS of include/pvhip.h: 8 compute streams + one for copies / the RCCL gather
+COPY_STREAM = 8      # what InferRequest.wait() gathers and copies on when the batch is sharded: no request computes there
 
 
 def select_stream(index: int):
-    """Make compute stream `index` (0..7) the current one: every later launch and copy goes to it."""
+    """Make stream `index` (0..8) the current one: every later launch and copy goes to it."""
     ensure_init()
     call('pvhip_stream_select', int(index))
 

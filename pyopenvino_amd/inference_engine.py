@@ -73,8 +73,11 @@ class IECore:
     def read_network(self, model: str, weights=None, fp16_as_fp32=None):
         """``model``: path of the IR ``.xml``.  ``weights``: path of the ``.bin`` (default: next to the
         xml, as the reference does) or the blob itself (bytes / uint8 ndarray) when the weights were
-        synthesised in memory.  ``fp16_as_fp32``: run an FP16 IR with fp32 tensors (constants upcast once at load,
-        every FP16 port declared FP32); default: what the plugin package asks for (``COMPUTE_FP32``)."""
+        synthesised in memory.  ``fp16_as_fp32``: run an FP16 IR with fp32 tensors AND fp32 arithmetic (constants upcast once
+        at load, every FP16 port declared FP32); default: what the plugin package asks for (``COMPUTE_FP32``).  False with a
+        package that declares ``F16_MFMA`` (this one): the tensors are still fp32 in HBM, but Convolution and MatMul round
+        their operands to fp16 and run on the f16 matrix cores with fp32 accumulation (``net.f16_mfma``); with any other
+        package the IR is left as it is (FP16 ports, float16 constants: the reference's own mode)."""
         net = IENetwork(self)
         net.read_IR_Model(model, weights)
         net.parse_IR_XML()
@@ -82,8 +85,11 @@ class IECore:
         net.set_constants_to_graph()
         if fp16_as_fp32 is None:
             fp16_as_fp32 = all(getattr(sys.modules.get(m.__package__), 'COMPUTE_FP32', False) for m in self.plugins.plugins.values())
-        if fp16_as_fp32:
+        packages = [sys.modules.get(m.__package__) for m in self.plugins.plugins.values()]
+        f16_mfma = fp16_as_fp32 is False and all(getattr(pkg, 'F16_MFMA', False) for pkg in packages)
+        if fp16_as_fp32 or f16_mfma:
             net.promote_fp16()
+            net.f16_mfma = f16_mfma and net.ir_precision == 'FP16'      # an FP32 IR keeps its fp32 kernels
         net.inputs = self.construct_node_info(net, 'Parameter')
         net.outputs = self.construct_node_info(net, 'Result')
         return net
@@ -110,6 +116,7 @@ class IENetwork:
         self.inputs = None
         self.outputs = None
         self.batch_size = 1
+        self.f16_mfma = False      # FP16 IR read with fp16_as_fp32=False: Convolution / MatMul on the f16 matrix cores
 
     # ------------------------------------------------------------------ IR reading
     def read_IR_Model(self, model, weights=None):
@@ -305,11 +312,11 @@ class InferRequest:
                 from . import device
                 # The copy to the host synchronises the stream it is issued on: use one that has nothing else queued
                 # (this request's own have drained; another request's have not).
-                # With sharded batches the gather and the copy go to the LAST stream, which no request computes on:
+                # With sharded batches the gather and the copy go to the copy stream (index 8), which no request computes on:
                 # every rank waits for its requests in the same order, so the collectives of the one communicator
                 # are issued in the same order everywhere and never overlap each other.
                 gathers = comm is not None and comm.world > 1
-                device.select_stream(device.MAX_STREAMS - 1 if gathers else ex.stream_base)
+                device.select_stream(device.COPY_STREAM if gathers else ex.stream_base)
                 if gathers:
                     value = comm.allgather_rows(value)
                 value = value.numpy() if hasattr(value, 'numpy') and not isinstance(value, np.ndarray) else np.asarray(value)
@@ -362,6 +369,10 @@ class Executable_Network:
         import copy
         if count > 8:
             raise ValueError('at most 8 requests (one compute stream each)')
+        # A graph that has already been loaded or inferred holds device tensors (cached constants, packed weights, node
+        # outputs): a deep copy would alias their blocks, and both owners would free them.  Strip that state first: every
+        # request uploads and packs its own.
+        self.release_device_state()
         per = max(1, int(self.compute_streams) // count)
         self.requests = [InferRequest(self, self, 0)]
         for i in range(1, count):
@@ -381,6 +392,19 @@ class Executable_Network:
             for i, req in enumerate(self.requests):
                 req.runner.stream_base = i * per
                 req.runner.compute_streams = per
+
+    def release_device_state(self):
+        """Drop every device tensor the graph holds (cached constants, packed weights, node outputs, results); the next
+        infer uploads and packs again."""
+        G = self.ienet.G
+        for nid in G.nodes:
+            node = G.nodes[nid]
+            for key in [k for k in node if isinstance(k, str) and k.startswith('_hip_')]:
+                del node[key]
+            for port in node.get('output', {}).values():
+                port.pop('data', None)
+            for key in ('result', 'param', '_sibling_out', '_fuse_bias', '_out_into', '_siblings', '_fuse_pool', '_fuse_pool_in', '_fuse_pre_add'):
+                node.pop(key, None)
 
     def start_async(self, request_id: int, inputs: dict):
         self.requests[request_id].start_async(inputs)
@@ -503,7 +527,8 @@ class Executable_Network:
 
         # An Add of a per-channel Const whose only consumer is a convolution that adds in its own input fetch (the 7x7 stem
         # behind data/mean): the Add is not dispatched, the convolution reads the Add's input and receives the constant.
-        if getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False) and os.environ.get('PVHIP_FUSE_PREADD', '1') != '0':
+        f16 = bool(getattr(self.ienet, 'f16_mfma', False))     # the f16-MFMA kernel fuses the epilogue and the Concat store only
+        if not f16 and getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False) and os.environ.get('PVHIP_FUSE_PREADD', '1') != '0':
             for cid in G.nodes:
                 if G.nodes[cid]['type'] != 'Convolution' or cid in self._fused_away:
                     continue
@@ -524,7 +549,7 @@ class Executable_Network:
                     self._fused_away.add(src)
         # A 3x3 / stride 1 / pad 1 MaxPool whose only consumer is a fused 1x1 convolution (pool -> pool_proj): the MaxPool is not
         # dispatched, the convolution reads the MaxPool's input and pools while it builds its input tile.
-        if getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and os.environ.get('PVHIP_FUSE_POOLCONV', '1') != '0':
+        if not f16 and getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and os.environ.get('PVHIP_FUSE_POOLCONV', '1') != '0':
             for cid in list(self._fusion):
                 if G.nodes[cid]['type'] != 'Convolution':
                     continue
@@ -539,7 +564,7 @@ class Executable_Network:
         # 1x1, 3x3_reduce and 5x5_reduce arms of an inception module) are one launch of the first of them in schedule
         # order: the input is read once and every output-channel tile stores into the tensor of its own convolution
         # (Convolution.launch_siblings; each output has the bits of its own launch).
-        if self.fuse_siblings and getattr(conv_plugin, 'SUPPORTS_SIBLINGS', False):
+        if not f16 and self.fuse_siblings and getattr(conv_plugin, 'SUPPORTS_SIBLINGS', False):
             position = {t: i for i, t in enumerate(self.task_list)}
             groups = {}
             for cid, f in self._fusion.items():
@@ -729,8 +754,34 @@ class Executable_Network:
             base = self.stream_base
             # blocks allocated during this pass and freed before it has finished on the device (workspaces) are
             # parked until it has; the previous pass's outputs, replaced as we go, are reusable at once
-            epoch = device.pool_epoch_begin()
+            epoch = self._open_epoch = device.pool_epoch_begin()
             device.select_stream(base)
+        try:
+            self._dispatch_tasks(G, registry, plan, times, verbose)
+        except BaseException:
+            # a plugin raised in the middle of a pass: leave the device in a defined state -- every stream drained, stream 0
+            # current, the allocation epoch closed (its parked blocks back in the pool) -- and let the error travel on
+            if plan is not None:
+                from . import device
+                try:
+                    device.select_stream(0)
+                    device.synchronize()
+                    device.pool_epoch_dispatched()
+                    device.pool_epoch_end(self._open_epoch)
+                except Exception:
+                    pass
+            raise
+        self.last_node_times = times
+
+    def _dispatch_tasks(self, G, registry, plan, times, verbose):
+        open_run = None
+        if plan is not None:
+            from . import device
+            stream_of, waits, records = plan
+            done_events, spare, current = {}, self.__dict__.setdefault('_order_events', []), 0
+            held = self.__dict__.setdefault('_events_in_flight', [])
+            base = self.stream_base
+            epoch = self._open_epoch
         for task in self.task_list:
             if task in self._fused_away:
                 continue
@@ -761,6 +812,8 @@ class Executable_Network:
             else:
                 node.pop('_fuse_pool_in', None)
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
+            if node_type in ('Convolution', 'MatMul'):
+                node['_f16_mfma'] = bool(getattr(self.ienet, 'f16_mfma', False))
             fusion = self._fusion.get(task)
             node.pop('_out_into', None)
             if fusion is not None:
@@ -852,7 +905,6 @@ class Executable_Network:
                 device.select_stream(0)
                 device.synchronize()
                 device.pool_epoch_end(epoch)
-        self.last_node_times = times
 
     def wait_done(self):
         """Host-side wait for a pass dispatched with defer_sync (its streams have been joined on the base stream)."""

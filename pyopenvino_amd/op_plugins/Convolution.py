@@ -55,7 +55,20 @@ def packed_weights(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
     return wpack
 
 
-def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, pre_add=None):
+def packed_weights_f16(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
+    """fp16 weight panel + gather table of the f16-MFMA kernel (FP16 IRs), cached on the node like packed_weights."""
+    cached = node.get('_hip_wpack16')
+    key = (w.shape, h, wd)
+    if cached is not None and cached[0] is w._block and cached[1] == key:
+        return cached[2]
+    k, c, kh, kw = w.shape
+    wpack = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_f16_pack_elems', k, c, kh, kw)),))
+    dev.call('pvhip_conv2d_f16_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wpack.ptr), k, c, kh, kw, h, wd)
+    node['_hip_wpack16'] = (w._block, key, wpack)
+    return wpack
+
+
+def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, pre_add=None, f16=False):
     n, c, h, wd = x.shape
     kn, kc, kh, kw = w.shape
     if kc != c:
@@ -66,7 +79,7 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         # the strided slice of the padded image is shorter than (oh, ow): numpy refuses the assignment (:68)
         raise ValueError('could not broadcast input array: window exceeds the padded input '
                          '({}x{} padded, kernel {}x{}, stride {}, output {}x{})'.format(hp, wp, kh, kw, strides, oh, ow))
-    wpack = packed_weights(node, w, h, wd)
+    wpack = packed_weights_f16(node, w, h, wd) if f16 else packed_weights(node, w, h, wd)
     act_code, act_lo, act_hi = 0, 0.0, 0.0
     if act is not None:
         act_code = 1 if act[0] == 'relu' else 2
@@ -82,13 +95,30 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         y = dev.ChannelSlice(target, coff, kn)
     tail = (n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
-    if pre_add is not None:
+    if f16:         # FP16 IR: fp16 operands on the f16 matrix cores, fp32 accumulation
+        dev.call('pvhip_conv2d_f16', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
+    elif pre_add is not None:
         assert pre_add.size == c
         dev.call('pvhip_conv2d_preadd_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(pre_add.ptr), ctypes.c_void_p(wpack.ptr),
                  ctypes.c_void_p(target.ptr), *tail)
     else:
         dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
     return y
+
+
+# pvhip_conv2d_kernel_kind codes -> (family name, fraction of the algorithmic multiply-adds the matrix cores execute)
+KERNEL_KINDS = {0: ('implicit GEMM (LDS-DMA)', 1.0), 1: ('pointwise', 1.0), 2: ('Winograd F(2x2,3x3)', 16.0 / 36.0),
+                3: ('Winograd F(4x4,3x3)', 36.0 / 144.0), 4: ('Winograd F(2x2,5x5)', 36.0 / 100.0), 5: ('7x7 stem', 1.0)}
+
+
+def kernel_kind(node: dict):
+    """(family name, executed fraction) of the kernel libpvhip runs for this Convolution node (IR port dims; no device needed)."""
+    attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+    strides, pb, pe = (common_def.string_to_tuple(attrs[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+    oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
+    code = dev.call('pvhip_conv2d_kernel_kind', int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3]), oh, ow,
+                    strides[0], strides[1], pb[0], pb[1])
+    return KERNEL_KINDS[int(code)]
 
 
 def pre_add_fusable(node: dict) -> bool:
@@ -250,7 +280,9 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
     siblings = node.get('_siblings')
-    if node.get('_fuse_pool_in') is not None:
+    if node.get('_f16_mfma'):
+        y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'), f16=True)
+    elif node.get('_fuse_pool_in') is not None:
         y = launch_pooled(node, x, w, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'))
     elif siblings:
         members = [(w, bias, node.get('_out_into'))]

@@ -27,6 +27,7 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         raise ValueError('matmul: Input operand 1 has a mismatch in its core dimension 0 (size {} is different '
                          'from {})'.format(kb, ka))
     c = dev.DeviceTensor.empty((m, n))
-    dev.call('pvhip_matmul_f32', ctypes.c_void_p(a.ptr), ctypes.c_void_p(b.ptr), ctypes.c_void_p(c.ptr), m, n, ka,
+    # an FP16 IR read with fp16_as_fp32=False: fp16 operands on the f16 matrix cores, fp32 accumulation (the engine's hint)
+    dev.call('pvhip_matmul_f16' if node.get('_f16_mfma') else 'pvhip_matmul_f32', ctypes.c_void_p(a.ptr), ctypes.c_void_p(b.ptr), ctypes.c_void_p(c.ptr), m, n, ka,
              int(ta), int(tb))
     return {common_def.first_output_port(node): c}

@@ -114,15 +114,74 @@ class BatchShardComm:
         dev.call('pvhip_comm_init', ctypes.c_char_p(uid), self.rank, self.world)
         self._rccl_ready = True
 
+    def agree_on_gather(self):
+        """Create the RCCL communicator on every rank, or agree -- all ranks together, through the host group -- to gather
+        through the host group instead when ANY rank cannot (no librccl, no GPU, the unique id could not be made).  Never
+        silently: returns (gather path for the record, error text of this rank or '')."""
+        if self.world == 1:
+            return 'none (one rank)', ''
+        if not self.use_rccl:
+            return 'host group (PVHIP_NO_RCCL=1)', ''
+        error = ''
+        try:
+            self.init_device()
+        except Exception as exc:       # noqa: BLE001 -- whatever it is, the other ranks must hear about it
+            error = '{}: {}'.format(type(exc).__name__, exc)
+        if self.group.allreduce_max(1.0 if error else 0.0) > 0.0:
+            if self._rccl_ready:       # this rank has a communicator the others do not: drop it
+                try:
+                    self.close()
+                except Exception:      # noqa: BLE001
+                    pass
+            self.use_rccl = False
+            return 'host group (RCCL communicator unavailable{})'.format(': ' + error if error else ' on another rank'), error
+        return 'rccl', ''
+
+    def rccl_ranks(self) -> int:
+        """ncclCommCount of the communicator (0 when there is none): what RCCL itself believes the world is."""
+        if not self._rccl_ready:
+            return 0
+        n = ctypes.c_int(0)
+        dev.call('pvhip_comm_ranks', ctypes.byref(n))
+        return n.value
+
+    def row_counts(self, rows: int):
+        """Rows of every rank's shard, in rank order (host exchange; cached per own row count: the shards of a run do
+        not change from one gather to the next)."""
+        cache = self.__dict__.setdefault('_row_counts', {})
+        if rows not in cache:
+            cache[rows] = [int(np.asarray(p).reshape(-1)[0]) for p in self.group.allgather_array(np.array([rows], dtype=np.int64))]
+        return cache[rows]
+
     def allgather_rows(self, value):
-        """Concatenate every rank's tensor along axis 0, in rank order."""
+        """Concatenate every rank's tensor along axis 0, in rank order.  ncclAllGather moves the SAME count from every
+        rank, while shard() hands the first total % world ranks one more row: uneven shards are gathered padded to the
+        longest one and the padding rows are cut out of the result."""
         if self.world == 1:
             return value
         if isinstance(value, dev.DeviceTensor) and self.use_rccl:
             self.init_device()
-            out = dev.DeviceTensor.empty((value.shape[0] * self.world,) + tuple(value.shape[1:]))
-            dev.call('pvhip_comm_allgather_f32', ctypes.c_void_p(value.ptr), ctypes.c_void_p(out.ptr), value.size)
-            return out
+            counts = self.row_counts(value.shape[0])
+            most, inner = max(counts), tuple(value.shape[1:])
+            row = int(np.prod(inner, dtype=np.int64)) if inner else 1
+            send = value
+            if value.shape[0] != most:                                 # pad this rank's shard (zeros, cut out below)
+                send = dev.DeviceTensor.empty((most,) + inner)
+                dev.call('pvhip_memset', ctypes.c_void_p(send.ptr), 0, send.nbytes)
+                if value.nbytes:
+                    dev.call('pvhip_memcpy_d2d', ctypes.c_void_p(send.ptr), ctypes.c_void_p(value.ptr), value.nbytes)
+            out = dev.DeviceTensor.empty((most * self.world,) + inner)
+            dev.call('pvhip_comm_allgather_f32', ctypes.c_void_p(send.ptr), ctypes.c_void_p(out.ptr), most * row)
+            if min(counts) == most:
+                return out
+            dense = dev.DeviceTensor.empty((sum(counts),) + inner)
+            at = 0
+            for r, n_rows in enumerate(counts):                        # rank r's real rows, packed
+                if n_rows:
+                    dev.call('pvhip_memcpy_d2d', ctypes.c_void_p(dense.ptr + at * row * 4), ctypes.c_void_p(out.ptr + r * most * row * 4),
+                             n_rows * row * 4)
+                at += n_rows
+            return dense
         parts = self.group.allgather_array(np.asarray(value))
         return np.concatenate(parts, axis=0)
 

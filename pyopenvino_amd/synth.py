@@ -21,6 +21,8 @@ reference's un-shifted SoftMax stays finite):
 """
 import xml.etree.ElementTree as et
 
+import os
+
 import numpy as np
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -176,3 +178,41 @@ def synth_weights(xml_path: str, seed: int = 1234) -> bytes:
             vals = z * 0.05
         blob[offset:offset + size] = np.asarray(vals, dtype='<f4').tobytes()[:size]
     return bytes(blob)
+
+
+def fp16_ir(xml_path, blob, out_dir):
+    """Write the FP16 twin of an FP32 IR (what Model Optimizer's --data_type FP16 produces): every port FP16, every f32
+    constant stored as f16 in a new blob, the Parameter f16.  Returns (path of the new .xml, the new blob)."""
+    import xml.etree.ElementTree as et
+    tree = et.parse(xml_path)
+    root = tree.getroot()
+    src = memoryview(blob)
+    out = bytearray()
+    moved = {}                                   # constants that share a blob region keep sharing it
+    for layer in root.iterfind('./layers/layer'):
+        for port in layer.iter('port'):
+            if port.attrib.get('precision') == 'FP32':
+                port.attrib['precision'] = 'FP16'
+        data = layer.find('data')
+        if data is None:
+            continue
+        if layer.attrib['type'] == 'Parameter' and data.attrib.get('element_type') == 'f32':
+            data.attrib['element_type'] = 'f16'
+        if layer.attrib['type'] != 'Const':
+            continue
+        offset, size = int(data.attrib['offset']), int(data.attrib['size'])
+        key = (offset, size, data.attrib['element_type'])
+        if key not in moved:
+            raw = bytes(src[offset:offset + size])
+            if data.attrib['element_type'] == 'f32':
+                raw = np.frombuffer(raw, dtype='<f4').astype('<f2').tobytes()
+            while len(out) % 8:
+                out.append(0)
+            moved[key] = (len(out), len(raw))
+            out += raw
+        data.attrib['offset'], data.attrib['size'] = str(moved[key][0]), str(moved[key][1])
+        if data.attrib['element_type'] == 'f32':
+            data.attrib['element_type'] = 'f16'
+    path = os.path.join(out_dir, os.path.basename(xml_path)[:-4] + '_fp16.xml')
+    tree.write(path)
+    return path, bytes(out)

@@ -1,6 +1,7 @@
 #!/bin/bash
-# GPU-box routine: parity tests -> smoke -> bench -> rocprof stats.  Stops at the first step that is
-# killed by its timeout (never start another GPU step after a hang).
+# GPU-box routine: parity tests -> smoke -> bench.  Stops at the first step that fails -- killed by its timeout, by a
+# signal (a GPU fault / abort: rc >= 128) or with any other non-zero status: never start another GPU step after a hang or
+# a fault -- and exits with that step's status.
 set -u
 mkdir -p gpurun_out
 step() {  # step <seconds> <logfile> <cmd...>
@@ -10,8 +11,7 @@ step() {  # step <seconds> <logfile> <cmd...>
     local rc=$?
     echo "=== rc=$rc" | tee -a gpurun_out/ci.log
     tail -n 25 "gpurun_out/$log"
-    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT - stopping" | tee -a gpurun_out/ci.log; exit 99; fi
-    return $rc
+    if [ $rc -ne 0 ]; then echo "FAILED (rc=$rc): $* -- stopping; last lines of gpurun_out/$log above" | tee -a gpurun_out/ci.log; exit $rc; fi
 }
 : > gpurun_out/ci.log
 step 900 test_gpu.log python -m pytest tests -m gpu -q -x --timeout=600 ${PYTEST_EXTRA:-}

@@ -4,7 +4,7 @@
 # the judged summaries under profiles/ via scripts/summarize_profile.py.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r01}
+TAG=${TAG:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -13,17 +13,17 @@ cd /tmp && export TMPDIR=/tmp
 # ONE stream, where a launch's duration is its own -- that one is what bench.py's roofline (sampled steps that run
 # alone on one stream) must agree with.
 echo "== kernel trace + stats, default (requests in flight)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_forked -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-images 0 > $OUT/stats_forked.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_forked -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-images 0 --no-extra --min-seconds 0 > $OUT/stats_forked.log 2>&1
 echo "rc=$?"; grep '^{' $OUT/stats_forked.log | tail -1 > $OUT/bench_line_forked.json
 echo "== kernel trace + stats, one stream"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-images 0 --requests 1 --streams 1 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-images 0 --no-extra --min-seconds 0 --requests 1 --streams 1 > $OUT/stats.log 2>&1
 echo "rc=$?"; grep '^{' $OUT/stats.log | tail -1 > $OUT/bench_line_under_profiler.json
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c"
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-images 0 --no-node-timing --requests 1 --streams 1 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-images 0 --no-extra --min-seconds 0 --no-node-timing --requests 1 --streams 1 > $OUT/pmc_$c.log 2>&1
   echo "rc=$?"
 done
 echo "== pmc SQ pass"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-images 0 --no-node-timing --requests 1 --streams 1 > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-images 0 --no-extra --min-seconds 0 --no-node-timing --requests 1 --streams 1 > $OUT/pmc_SQ.log 2>&1
 echo "rc=$?"
 cd $R && python3 scripts/summarize_profile.py $OUT $TAG

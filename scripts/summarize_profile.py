@@ -15,7 +15,7 @@ import sys
 
 def is_conv(name):
     """The kernels behind the Convolution nodes: implicit GEMM (also with the MaxPool in front folded in), the Winograd forms, the 7x7 stem."""
-    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_stem' in name or 'conv_pool1x1' in name
+    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_stem' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name
 
 
 def find(root, pattern):
@@ -29,7 +29,7 @@ def main():
     prof = os.path.join(repo, 'profiles')
     os.makedirs(prof, exist_ok=True)
     md = ['# rocprofv3 summary `{}`'.format(tag), '',
-          'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0 --requests 1 --streams 1` '
+          'Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0 --no-extra --min-seconds 0 --requests 1 --streams 1` '
           '(googlenet-v1, batch 256, 1 GPU; one request at a time on ONE compute stream, so that a launch\'s start-to-end time is its own: '
           'this is what bench.py\'s roofline measures on its sampled steps).  The default command (several whole-batch requests in flight, '
           'kernels of different passes overlapping) is summarised at the end.', '']
@@ -53,7 +53,7 @@ def main():
                 conv_total_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         if conv_calls:
-            md += ['', '**conv_wino4_kernel + conv_wino_kernel + conv_igemm_dma_kernel + conv_pool1x1_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+            md += ['', '**conv_wino4_kernel + conv_wino_kernel + conv_pw_kernel + conv_igemm_dma_kernel + conv_pool1x1_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of {} launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * per_pass / 1e6, per_pass)]
     trace = find(os.path.join(raw, 'stats'), '*kernel_trace.csv')
@@ -82,7 +82,7 @@ def main():
         with open(os.path.join(prof, tag + '_kernel_stats_forked.csv'), 'w') as f:
             f.write(open(forked).read())
         forked_md = ['', '## Default command (requests in flight)', '',
-                     '`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0`: per-kernel table in `{}_kernel_stats_forked.csv`.  '
+                     '`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-images 0 --no-extra --min-seconds 0`: per-kernel table in `{}_kernel_stats_forked.csv`.  '
                      'Convolution launches: {:.0f}, average start-to-end {:.2f} us -- longer than alone on one stream because launches of different '
                      'passes share the chip; the step is shorter.'.format(tag, calls, tot / max(1.0, calls) / 1e3)]
         fl = os.path.join(raw, 'bench_line_forked.json')
@@ -98,13 +98,13 @@ def main():
         for r in csv.DictReader(open(cc)):
             if r['Counter_Name'] != counter:
                 continue
-            fam = 'conv_igemm_kernel' if (is_conv(r['Kernel_Name'])) else r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('<')[0].replace('void ', '')
+            fam = 'convolution_kernels' if (is_conv(r['Kernel_Name'])) else r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].split('<')[0].replace('void ', '')
             agg = per_kernel.setdefault(fam, [0.0, 0])
             agg[0] += float(r['Counter_Value'])
             agg[1] += 1
         traffic[counter] = {k: {'sum_kb': v[0], 'launches': v[1]} for k, v in per_kernel.items()}
     if traffic.get('FETCH_SIZE') and traffic.get('WRITE_SIZE'):
-        out = {'tag': tag, 'note': 'KB counters from separate --pmc passes; read side doubled (gfx950 FETCH_SIZE reports half of a wide '
+        out = {'tag': tag, 'tree': os.environ.get('PVHIP_TREE', 'unknown'), 'note': 'KB counters from separate --pmc passes; read side doubled (gfx950 FETCH_SIZE reports half of a wide '
                                    'coalesced stream, MI355X_MICROARCH.md section HBM); bytes per launch', 'kernels': {}}
         md += ['', '## HBM traffic per launch (PMC, corrected)', '', '| kernel family | launches | read MB | write MB | total MB |', '|---|---|---|---|---|']
         for fam, f in traffic['FETCH_SIZE'].items():
@@ -125,7 +125,7 @@ def main():
                 agg[r['Counter_Name']] = agg.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
         if agg.get('GRBM_GUI_ACTIVE'):
             cyc = agg['GRBM_GUI_ACTIVE'] / 8.0
-            md += ['', '## convolution kernels (conv_wino4 + conv_wino + conv_igemm_dma + conv_pool1x1), SQ counters summed over their launches', '']
+            md += ['', '## convolution kernels (conv_wino4 + conv_wino + conv_pw + conv_igemm_dma + conv_pool1x1), SQ counters summed over their launches', '']
             md += ['- MFMA pipe busy: {:.1f} % of SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))'.format(
                 100.0 * agg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / cyc)]
             if agg.get('SQ_BUSY_CU_CYCLES'):

@@ -22,7 +22,9 @@ Fixtures
                            synthetic weights, 1 image: 'concat' in full, the two class tensors subsampled + float64 sums
   ssd_full_e2e.npz         the whole SSD IR (prior boxes + DetectionOutput included) through the reference's infer(),
                            synthetic weights, 1 image: the (1,1,100,7) detections and the (1,2,7668) prior tensor
-  mnist_fp16_e2e.npz       models/mnist rewritten as an FP16 IR (tests/helpers.fp16_ir) through the reference (numpy float16), 3 images
+  mnist_fp16_e2e.npz       models/mnist rewritten as an FP16 IR (pyopenvino_amd.synth.fp16_ir) through the reference (numpy float16), 3 images
+  conv_node6_fp16.npz      the same node fixture in float16 as the reference computes it (x, w, float16 output), cropped to 64x64
+  googlenet_rows8.npz      the reference's N=1 answers for 8 seeded images on the synthetic GoogLeNet weights
   conv_node6_crop.npz      the reference's own single-node fixture resources/node_args_6.pickle (SSD Conv2d_0,
                            3x3 stride 2 same_upper pads (0,0)/(1,1)), input cropped to 64x64 and cast to fp32
 """
@@ -247,10 +249,9 @@ def ssd_full_case(IECore):
 
 
 def fp16_case(IECore):
-    """models/mnist as an FP16 IR (tests/helpers.fp16_ir: every port FP16, constants stored as f16)
+    """models/mnist as an FP16 IR (pyopenvino_amd.synth.fp16_ir: every port FP16, constants stored as f16)
     through the reference, which computes it in numpy float16; three of the mnist_e2e images."""
-    sys.path.insert(0, os.path.join(REPO, 'tests'))
-    import helpers
+    helpers = synth
     print('mnist as an FP16 IR through the reference (float16 numpy)')
     tmp = '/tmp/pv_golden_models'
     os.makedirs(tmp, exist_ok=True)
@@ -260,14 +261,21 @@ def fp16_case(IECore):
     with open(stem + '.bin', 'wb') as f:
         f.write(blob16)
     images = np.load(os.path.join(HERE, 'mnist_e2e.npz'))['images'][:3]
-    outs = []
+    outs, logits = [], []
     for i in range(len(images)):
-        o, _ = run_model(IECore, stem, images[i:i + 1])
+        ie = IECore()
+        net = ie.read_network(stem + '.xml', stem + '.bin')
+        ex = ie.load_network(net, 'CPU')
+        ex.kernel_type = 'special'
+        o = np.ascontiguousarray(ex.infer({net.inputs[0]['name']: images[i:i + 1]})[net.outputs[0]['name']])
         assert o.dtype == np.float16, o.dtype
         outs.append(o.astype(np.float32))
+        soft = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'SoftMax')
+        pre = next(iter(net.G.pred[soft]))                       # the Add in front of the SoftMax: the float16 logits
+        logits.append(np.asarray(next(iter(net.G.nodes[pre]['output'].values()))['data']).astype(np.float32))
     out = np.concatenate(outs, 0)
-    np.savez_compressed(os.path.join(HERE, 'mnist_fp16_e2e.npz'), out=out, n_images=np.array(len(images)))
-    print('  out', out.shape, 'argmax', out.argmax(axis=1))
+    np.savez_compressed(os.path.join(HERE, 'mnist_fp16_e2e.npz'), out=out, n_images=np.array(len(images)), logits=np.concatenate(logits, 0))
+    print('  out', out.shape, 'argmax', out.argmax(axis=1), 'logits', logits[0])
 
 
 def run_model(IECore, model, x, input_name=None, capture_layers=False):
@@ -332,6 +340,24 @@ def model_cases(IECore):
         print('  out', out.shape, 'row sums', out.sum(axis=1), 'argmax', out.argmax(axis=1))
 
 
+def googlenet_rows_case(IECore, nimg=8):
+    """googlenet_rows8.npz: the reference's N=1 answers for 8 seeded images on the synthetic weights (the first two are the rows
+    of googlenet_e2e.npz): what rows 0-7 of the batch-256 run on the GPU are held against."""
+    tmp = '/tmp/pv_golden_models'
+    os.makedirs(tmp, exist_ok=True)
+    xml = os.path.join(REF, 'models', 'googlenet-v1.xml')
+    stem = os.path.join(tmp, 'googlenet-v1')
+    with open(stem + '.bin', 'wb') as f:
+        f.write(synth.synth_weights(xml, 1234))
+    if not os.path.exists(stem + '.xml'):
+        os.symlink(xml, stem + '.xml')
+    outs = [run_model(IECore, stem, synth.uniform_pixels(500 + i, (1, 3, 224, 224)))[0] for i in range(nimg)]
+    out = np.concatenate(outs, 0)
+    np.savez_compressed(os.path.join(HERE, 'googlenet_rows8.npz'), out=out, image_seeds=np.array([500 + i for i in range(nimg)]),
+                        weight_seed=np.array(1234))
+    print('googlenet rows', out.shape, 'argmax', out.argmax(axis=1))
+
+
 def ssd_backbone_case(IECore):
     """SSD-MobileNet backbone + box/class heads on synthetic weights, ONE image, through the reference's own
     scheduler loop restricted to the ancestors of 'concat' / 'concat_1' / the Sigmoid (its PriorBox /
@@ -387,6 +413,27 @@ def node6_case(plugins):
     os.replace(os.path.join(HERE, 'ops', 'conv_node6_crop.npz'), os.path.join(HERE, 'conv_node6_crop.npz'))
 
 
+def node6_fp16_case(plugins):
+    """conv_node6_fp16.npz: the reference's own FP16 node fixture (resources/node_args_6.pickle: SSD Conv2d_0, 3x3 stride 2
+    same_upper, replayed as test_node_sample.py:1-16 does) in float16 as it stands, input cropped to 64x64: x, w and the
+    'special' kernel's float16 output."""
+    print('reference single-node fixture resources/node_args_6.pickle (cropped, float16 as the reference computes it)')
+    with open(os.path.join(REF, 'resources', 'node_args_6.pickle'), 'rb') as f:
+        node, inputs = pickle.load(f)
+    x = np.ascontiguousarray(inputs[0][:, :, :64, :64])
+    w = np.ascontiguousarray(inputs[1])
+    assert x.dtype == np.float16 and w.dtype == np.float16
+    node = dict(node)
+    node['input'] = {0: port('FP16', x.shape), 1: port('FP16', w.shape)}
+    oh = (64 + 0 + 1 - 3) // 2 + 1
+    node['output'] = {2: port('FP16', (1, w.shape[0], oh, oh))}
+    res = plugins['Convolution'].compute(node, {0: x, 1: w}, kernel_type='special', debug=False)
+    out = np.ascontiguousarray(next(iter(res.values())))
+    assert out.dtype == np.float16, out.dtype
+    np.savez_compressed(os.path.join(HERE, 'conv_node6_fp16.npz'), x=x, w=w, out=out, data=json.dumps(dict(node['data'])))
+    print('  out', out.shape, out.dtype, 'min', out.min(), 'max', out.max())
+
+
 def main():
     IECore = import_reference()
     plugins = IECore().plugins.plugins
@@ -394,8 +441,12 @@ def main():
         ssd_backbone_case(IECore)
         ssd_full_case(IECore)
         return
-    if 'fp16' in sys.argv[1:]:           # only the FP16-IR fixture
+    if 'rows' in sys.argv[1:]:           # only the 8-row GoogLeNet fixture
+        googlenet_rows_case(IECore)
+        return
+    if 'fp16' in sys.argv[1:]:           # only the FP16 fixtures
         fp16_case(IECore)
+        node6_fp16_case(plugins)
         return
     if 'head' in sys.argv[1:]:           # only the SSD head per-op fixtures and the end-to-end SSD fixture
         head_cases(plugins)
@@ -404,7 +455,9 @@ def main():
     op_cases(plugins)
     head_cases(plugins)
     node6_case(plugins)
+    node6_fp16_case(plugins)
     model_cases(IECore)
+    googlenet_rows_case(IECore)
     fp16_case(IECore)
     ssd_backbone_case(IECore)
     ssd_full_case(IECore)

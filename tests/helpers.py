@@ -56,9 +56,32 @@ def rel_err(got, want):
     return float(np.abs(got[fin] - want[fin]).max() / scale)
 
 
-def assert_close(got, want, tol=REL_TOL, what=''):
+def elementwise_excess(got, want, tol=REL_TOL):
+    """max over elements of |got - want| / (tol * |want| + tol * rms(want)): <= 1 means every element is within `tol` RELATIVE to
+    its own magnitude, with a floor of `tol` x the tensor's rms for elements near zero (cancellation in a sum leaves an absolute
+    error of that order).  Much tighter than rel_err's max-norm for tensors with a large dynamic range (SoftMax rows, conv
+    outputs near zero)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, 'shape {} != {}'.format(got.shape, want.shape)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), 'NaN pattern differs'
+    assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), 'inf pattern differs'
+    if not fin.any():
+        return 0.0
+    w, g = want[fin], got[fin]
+    rms = float(np.sqrt(np.mean(w * w)))
+    return float((np.abs(g - w) / (tol * np.abs(w) + tol * max(rms, 1e-30))).max())
+
+
+def assert_close(got, want, tol=REL_TOL, what='', elementwise=True):
+    """The stated tolerance of the path, `tol` relative, in BOTH norms: max-norm (rel_err) and element by element
+    (elementwise_excess, against REL_TOL unless `tol` is looser).  Returns the max-norm error."""
     err = rel_err(got, want)
     assert err <= tol, '{}: relative error {:.3e} > {:.1e}'.format(what, err, tol)
+    if elementwise:
+        ex = elementwise_excess(got, want, max(tol, REL_TOL))
+        assert ex <= 1.0, '{}: an element is {:.2f} x outside |d| <= {:.0e} |want| + {:.0e} rms(want)'.format(what, ex, max(tol, REL_TOL), max(tol, REL_TOL))
     return err
 
 
@@ -109,38 +132,6 @@ def layer_sums(net):
 
 
 def fp16_ir(xml_path, blob, out_dir):
-    """Write the FP16 twin of an FP32 IR (what Model Optimizer's --data_type FP16 produces): every port FP16, every f32
-    constant stored as f16 in a new blob, the Parameter f16.  Returns (path of the new .xml, the new blob)."""
-    import xml.etree.ElementTree as et
-    tree = et.parse(xml_path)
-    root = tree.getroot()
-    src = memoryview(blob)
-    out = bytearray()
-    moved = {}                                   # constants that share a blob region keep sharing it
-    for layer in root.iterfind('./layers/layer'):
-        for port in layer.iter('port'):
-            if port.attrib.get('precision') == 'FP32':
-                port.attrib['precision'] = 'FP16'
-        data = layer.find('data')
-        if data is None:
-            continue
-        if layer.attrib['type'] == 'Parameter' and data.attrib.get('element_type') == 'f32':
-            data.attrib['element_type'] = 'f16'
-        if layer.attrib['type'] != 'Const':
-            continue
-        offset, size = int(data.attrib['offset']), int(data.attrib['size'])
-        key = (offset, size, data.attrib['element_type'])
-        if key not in moved:
-            raw = bytes(src[offset:offset + size])
-            if data.attrib['element_type'] == 'f32':
-                raw = np.frombuffer(raw, dtype='<f4').astype('<f2').tobytes()
-            while len(out) % 8:
-                out.append(0)
-            moved[key] = (len(out), len(raw))
-            out += raw
-        data.attrib['offset'], data.attrib['size'] = str(moved[key][0]), str(moved[key][1])
-        if data.attrib['element_type'] == 'f32':
-            data.attrib['element_type'] = 'f16'
-    path = os.path.join(out_dir, os.path.basename(xml_path)[:-4] + '_fp16.xml')
-    tree.write(path)
-    return path, bytes(out)
+    """The FP16 twin of an FP32 IR (pyopenvino_amd.synth.fp16_ir)."""
+    from pyopenvino_amd import synth
+    return synth.fp16_ir(xml_path, blob, out_dir)

@@ -178,6 +178,39 @@ def test_conv_winograd_f2x2_5x5(hip, monkeypatch):
     assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
 
 
+@pytest.mark.parametrize('form', ['F(4x4,3x3)', 'F(2x2,3x3)', 'F(2x2,5x5)'])
+def test_conv_winograd_stress_elementwise(hip, monkeypatch, form):
+    """The Winograd forms on hostile data, element by element against the oracle (|d| <= 1e-4 |want| + 1e-4 rms(want), on top
+    of the max-norm): un-centred activations 0 .. 255 (what conv2/3x3 would see without data/mean), weights with 1 % outliers
+    x 50, reduction lengths 192 x 9 = 1728 and 64 x 9 = 576 (5x5: 48 x 25, 32 x 25).  The transforms' coefficients (up to 8 and
+    1/24 for F(4x4,3x3)) amplify rounding; a numpy fp32 model of the three forms puts F(4x4,3x3) at ~0.25 of this bound,
+    F(2x2) at ~0.02."""
+    from pyopenvino_amd import synth
+    if form == 'F(4x4,3x3)':
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD4', 'force')
+        k, pad, shapes = 3, 1, [((2, 192, 28, 28), 96), ((1, 64, 56, 56), 40)]
+    elif form == 'F(2x2,3x3)':
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD4', '0')
+        k, pad, shapes = 3, 1, [((2, 192, 14, 14), 96), ((3, 64, 7, 7), 40)]
+    else:
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD5', 'force')
+        k, pad, shapes = 5, 2, [((2, 48, 28, 28), 64), ((2, 32, 14, 14), 40)]
+    from pyopenvino_amd.op_plugins import Convolution as conv
+    for xs, kout in shapes:
+        x = synth.uniform_pixels(sum(xs), xs)                                    # integers 0 .. 255, not centred
+        w = rnd(kout, (kout, xs[1], k, k), (2.0 / (xs[1] * k * k)) ** 0.5)
+        outl = synth.uniform_pixels(kout + 1, w.shape) < 2.56                    # ~1 % of the weights
+        w = np.where(outl, w * 50.0, w).astype(np.float32)
+        node = make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad)))
+        assert form.replace(' ', '') in conv.kernel_kind(node)[0].replace(' ', ''), conv.kernel_kind(node)
+        got = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+        want = first_out(oracle_plugin('Convolution').compute(dict(node), {0: x, 1: w}, kernel_type='special'))
+        excess = helpers.elementwise_excess(got, want)
+        err = assert_close(got, want, helpers.REL_TOL, '{} stress {}'.format(form, xs))
+        print('{} {} k{}: max-norm {:.2e}, element-wise excess {:.3f}'.format(form, xs, kout, err, excess))
+        assert excess <= 0.5, '{} {}: only {:.2f} x inside the element-wise bound'.format(form, xs, 1.0 / max(excess, 1e-9))
+
+
 def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     """F(4x4, 3x3) (the layers with extents divisible by 4 and enough patches; forced here): one, odd and many channel
     stages, ragged channel blocks, fewer patches than a workgroup holds, several images, fused bias + ReLU written in place
@@ -757,3 +790,79 @@ def test_device_tensor_roundtrip_and_pool_reuse(hip):
     del t
     t2 = hip.DeviceTensor.empty((5, 7, 3))
     assert t2.ptr == ptr, 'a freed block of the same size is reused'
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f16-MFMA kernels for FP16 IRs: fp16 operands, fp32 accumulation
+FP16_TOL = 2e-2      # against the reference's OWN float16 arithmetic (it accumulates in float16: 11 significant bits per partial sum)
+
+
+def f16r(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def test_conv_f16_mfma_vs_oracle_on_rounded_operands(hip):
+    """pvhip_conv2d_f16 (node['_f16_mfma']) against the oracle convolution of the SAME operands rounded to fp16: products of two
+    fp16 values are exact in fp32, so only the fp32 summation order differs -- 1e-5, element by element too.  Windows 1x1 ..
+    7x7, strides, asymmetric padding, channel counts that are not multiples of the 32-row stage or the 64-channel tile, several
+    images, a pixel count that is not a multiple of 128; then bias + ReLU fused and written in place into a wider tensor."""
+    from pyopenvino_amd import device as dev
+    cases = [((2, 3, 20, 20), 32, 3, (2, 2), (0, 0), (1, 1)), ((1, 64, 14, 14), 96, 1, (1, 1), (0, 0), (0, 0)),
+             ((3, 20, 13, 11), 70, 3, (1, 1), (1, 1), (1, 1)), ((2, 16, 12, 12), 40, 5, (1, 1), (2, 2), (2, 2)),
+             ((1, 3, 37, 37), 64, 7, (2, 2), (3, 3), (3, 3)), ((2, 33, 9, 9), 5, 3, (1, 1), (0, 0), (0, 0))]
+    for xs, k, kk, st, pb, pe in cases:
+        x, w = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5)
+        node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+        node['_f16_mfma'] = True
+        got = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+        want = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x, w], conv_data(st, pb, pe)), {0: f16r(x), 1: f16r(w)},
+                                                              kernel_type='special'))
+        assert_close(got, want, 1e-5, 'f16 conv {} k{} {}x{}'.format(xs, k, kk, kk))
+        plain = first_out(hip_plugin('Convolution').compute(make_node('Convolution', [x, w], conv_data(st, pb, pe)), {0: x, 1: w}))
+        assert not np.array_equal(got, plain), 'the fp32 kernel ran'
+        assert_close(got, plain, 5e-3, 'f16 vs fp32 operands', elementwise=False)
+    x, w, b = np.abs(rnd(1, (2, 24, 10, 6))), rnd(2, (40, 24, 3, 3), 0.1), rnd(3, (1, 40, 1, 1), 0.3)
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
+    node['_f16_mfma'] = True
+    wide = dev.DeviceTensor.from_numpy(np.full((2, 50, 10, 6), -1.0, dtype=np.float32))
+    fused = dict(node)
+    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
+    hip_plugin('Convolution').compute(fused, {0: x, 1: w})
+    got = np.asarray(wide)
+    unfused = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+    assert_bit_exact(got[:, 7:47], np.maximum(unfused + b, 0).astype(np.float32), 'f16 conv: fused epilogue')
+    assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
+
+
+def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
+    """The reference's own FP16 node fixture (resources/node_args_6.pickle, replayed as test_node_sample.py:1-16 does; cropped)
+    in float16 as the reference computes it: the f16-MFMA result is within fp16 tolerance of the reference's float16 output
+    (which accumulates its 27 products in float16), and 1e-5 from the exact sum of the same fp16 operands."""
+    z = np.load(os.path.join(helpers.GOLDEN, 'conv_node6_fp16.npz'))
+    x, w, ref = z['x'].astype(np.float32), z['w'].astype(np.float32), z['out'].astype(np.float32)
+    import json
+    data = json.loads(str(z['data']))
+    node = make_node('Convolution', [x, w], data)
+    node['_f16_mfma'] = True
+    got = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+    assert got.shape == ref.shape
+    err_ref = helpers.rel_err(got, ref)
+    exact = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x, w], data), {0: x, 1: w}, kernel_type='special'))
+    err_exact = assert_close(got, exact, 1e-5, 'f16 conv vs the fp32 sum of the same fp16 operands')
+    print('node_args_6 in float16: {:.2e} from the reference float16 output, {:.2e} from the fp32 sum'.format(err_ref, err_exact))
+    assert err_ref <= FP16_TOL, err_ref
+    assert helpers.rel_err(exact, ref) <= FP16_TOL          # (what separates them is the reference's float16 accumulation)
+
+
+def test_matmul_f16_mfma(hip):
+    """pvhip_matmul_f16 for the four transpose combinations and ragged shapes against float64 on the fp16-rounded operands."""
+    for m, n, k in ((64, 10, 64), (3, 70, 130), (256, 1000, 1024), (65, 33, 31)):
+        for ta, tb in ((False, True), (False, False), (True, False), (True, True)):
+            a = rnd(m + k, (k, m) if ta else (m, k))
+            b = rnd(n + k, (n, k) if tb else (k, n), 0.1)
+            node = make_node('MatMul', [a, b], {'transpose_a': 'true' if ta else 'false', 'transpose_b': 'true' if tb else 'false'})
+            node['_f16_mfma'] = True
+            got = first_out(hip_plugin('MatMul').compute(node, {0: a, 1: b}))
+            A = f16r(a).astype(np.float64).T if ta else f16r(a).astype(np.float64)
+            B = f16r(b).astype(np.float64).T if tb else f16r(b).astype(np.float64)
+            assert_close(got, (A @ B).astype(np.float32), 1e-5, 'matmul f16 {}x{}x{} ta={} tb={}'.format(m, n, k, ta, tb))

@@ -259,3 +259,17 @@ def test_infer_requests_api_on_host_plugins():
     for i in (2, 0, 1):
         assert np.array_equal(ex.wait(i)[out_name], want[i])
     assert np.array_equal(ex.requests[1].infer({name: xs[0]})[out_name], want[0])
+
+
+def test_device_blocks_cannot_be_copied():
+    """copy.deepcopy of a graph that holds device tensors would alias their blocks (two owners, two frees)."""
+    import copy
+    from pyopenvino_amd import device
+    blk = device._Block.__new__(device._Block)
+    blk.ptr, blk.nbytes = 0, 16
+    for fn in (copy.deepcopy, copy.copy):
+        with pytest.raises(device.PvhipError):
+            fn(blk)
+    t = device.DeviceTensor(blk, (4,))
+    with pytest.raises(device.PvhipError):
+        copy.deepcopy({'w': t})

@@ -147,3 +147,17 @@ def check_fp16_ir(plugin_package, tmp_path):
 
 def test_oracle_fp16_ir_as_fp32(tmp_path):
     check_fp16_ir('oracle.op_plugins', tmp_path)
+
+
+def test_oracle_on_the_reference_fp16_node_fixture():
+    """conv_node6_fp16.npz (the reference's float16 run of its own node fixture): the oracle's fp32 sum of the same fp16 operands
+    is within fp16 tolerance of it -- what pins the fixture the f16-MFMA kernel is tested against on the GPU."""
+    import importlib
+    import json
+    z = np.load(os.path.join(GOLDEN, 'conv_node6_fp16.npz'))
+    x, w, ref = z['x'].astype(np.float32), z['w'].astype(np.float32), z['out'].astype(np.float32)
+    node = {'name': 'n6', 'type': 'Convolution', 'data': json.loads(str(z['data'])),
+            'input': {0: {'precision': 'FP32', 'dims': x.shape}, 1: {'precision': 'FP32', 'dims': w.shape}},
+            'output': {2: {'precision': 'FP32', 'dims': ref.shape}}}
+    got = next(iter(importlib.import_module('oracle.op_plugins.Convolution').compute(node, {0: x, 1: w}, kernel_type='special').values()))
+    assert got.shape == ref.shape and helpers.rel_err(got, ref) <= 2e-2

@@ -62,3 +62,99 @@ def test_two_rank_batch_shard_and_gather(tmp_path, total):
         got = np.load(os.path.join(str(tmp_path), 'rank{}.npy'.format(r)))
         assert got.shape == (total, 10)
         helpers.assert_close(got, want, 1e-6, 'rank {} gathered batch'.format(r))
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
+                       'LOCAL_RANK': str(rank)})
+    os.environ.pop('PVHIP_NO_RCCL', None)
+    sys.path.insert(0, helpers.REPO)
+    from pyopenvino_amd import shard
+    group = shard.TorchGroup('gloo')
+    comm = shard.BatchShardComm(group)              # use_rccl: the communicator cannot be made here (no GPU)
+    assert comm.use_rccl
+    path, err = comm.agree_on_gather()
+    part = np.full((2 + rank, 3), float(rank), dtype=np.float32)            # uneven shards through the path agreed on
+    got = comm.allgather_rows(part)
+    with open(os.path.join(out_dir, 'rank{}.txt'.format(rank)), 'w') as f:
+        f.write('{}\n{}\n{}\n{}\n'.format(path, int(comm.use_rccl), got.shape[0], comm.rccl_ranks()))
+    group.barrier()
+    group.close()
+
+
+def test_every_rank_agrees_on_the_host_gather_when_rccl_is_unavailable(tmp_path):
+    """bench.py's N > 1 branch without GPUs: no rank can create the communicator, all of them learn it through the host
+    group, switch to the host gather together and say so; the gather then still returns every rank's rows."""
+    from pyopenvino_amd import device
+    if device.device_count() > 0:
+        pytest.skip('a GPU is visible here: the communicator can be created')
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_fallback_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        path, use_rccl, rows, ranks = open(os.path.join(str(tmp_path), 'rank{}.txt'.format(r))).read().split('\n')[:4]
+        assert path.startswith('host group (RCCL communicator unavailable') and use_rccl == '0' and rows == '5' and ranks == '0'
+
+
+def test_uneven_shards_are_padded_for_ncclallgather(monkeypatch):
+    """The RCCL branch of allgather_rows with device calls faked on the host: ncclAllGather is given the SAME count by every
+    rank (the longest shard), and the padding rows are cut out of the result, in rank order."""
+    from pyopenvino_amd import device as dev, shard
+
+    class Group:
+        rank, world = 1, 3
+        def allgather_array(self, arr):
+            return [np.array([3]), np.array([2]), np.array([2])]      # rows of ranks 0, 1, 2 (7 images on 3 ranks)
+
+    heap, calls = {}, []
+
+    class FakeTensor:
+        _next = [0x1000]
+        def __init__(self, shape):
+            self.shape = tuple(shape)
+            self.ptr = FakeTensor._next[0]
+            FakeTensor._next[0] += 0x100000
+            heap[self.ptr] = np.zeros(int(np.prod(self.shape)), dtype=np.float32)
+        size = property(lambda self: int(np.prod(self.shape)))
+        nbytes = property(lambda self: self.size * 4)
+
+    def find(ptr):
+        base = max(b for b in heap if b <= ptr)
+        return heap[base], (ptr - base) // 4
+
+    def fake_call(name, *args):
+        val = [a.value if hasattr(a, 'value') else a for a in args]
+        calls.append((name, val))
+        if name == 'pvhip_memset':
+            buf, off = find(val[0]); buf[off:off + val[2] // 4] = 0
+        elif name == 'pvhip_memcpy_d2d':
+            dst, do = find(val[0]); src, so = find(val[1]); n = val[2] // 4
+            dst[do:do + n] = src[so:so + n]
+        elif name == 'pvhip_comm_allgather_f32':
+            src, so = find(val[0]); dst, do = find(val[1]); n = val[2]
+            assert n == 3 * 4                                          # the longest shard: 3 rows of 4
+            for r in range(3):                                         # what the three ranks would send
+                rows = [3, 2, 2][r]
+                block = np.zeros(n, dtype=np.float32)
+                block[:rows * 4] = 100 * r + np.arange(rows * 4)
+                if r == 1:
+                    assert np.array_equal(src[so:so + n], block)        # this rank's padded shard
+                dst[do + r * n:do + (r + 1) * n] = block
+        return 0
+
+    monkeypatch.setattr(dev, 'call', fake_call)
+    monkeypatch.setattr(dev, 'ensure_init', lambda: None)
+    monkeypatch.setattr(dev.DeviceTensor, 'empty', classmethod(lambda cls, shape, dtype=np.float32: FakeTensor(shape)))
+    comm = shard.BatchShardComm(Group())
+    comm._rccl_ready = True
+    mine = FakeTensor((2, 4))
+    heap[mine.ptr][:] = 100 + np.arange(8)
+    monkeypatch.setattr(shard.dev, 'DeviceTensor', type('DT', (), {'empty': staticmethod(lambda shape, dtype=np.float32: FakeTensor(shape))}))
+    # isinstance(value, dev.DeviceTensor) must hold for the fake
+    shard.dev.DeviceTensor = FakeTensor
+    FakeTensor.empty = staticmethod(lambda shape, dtype=np.float32: FakeTensor(shape))
+    out = comm.allgather_rows(mine)
+    assert out.shape == (7, 4)
+    want = np.concatenate([100 * r + np.arange([3, 2, 2][r] * 4) for r in range(3)]).astype(np.float32)
+    assert np.array_equal(heap[out.ptr][:28], want)
+    assert [c[0] for c in calls].count('pvhip_comm_allgather_f32') == 1
