@@ -177,20 +177,8 @@ int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
 #define PVHIP_CONV_KIND_WINO_F2_3X3  2
 #define PVHIP_CONV_KIND_WINO_F4_3X3  3
 #define PVHIP_CONV_KIND_WINO_F2_5X5  4
-#define PVHIP_CONV_KIND_STEM         5   /* 7x7 / stride 2 / 3 channels                                       */
 int    pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
                                 int sh, int sw, int pad_top, int pad_left);
-/* Add.py:9-14 of a per-channel constant (1,c,1,1) followed by the convolution, as one launch: y = conv(x + pre_add[c]) with zero
- * padding applied AFTER the add, exactly as the two nodes do (the same fp32 add; bit-identical).  pre_add: c device floats.
- * Only where the convolution's own kernel fetches its input through registers -- the 7x7 / stride 2 / 3-channel stem
- * (pvhip_conv2d_preadd_supported; no device needed); PVHIP_EUNSUPPORTED otherwise.  Other arguments as pvhip_conv2d_f32. */
-int    pvhip_conv2d_preadd_supported(int n, int c, int kh, int kw, int sh, int sw, int k_out, int oh, int ow, int pad_top, int pad_left);
-int    pvhip_conv2d_preadd_f32(const float* x, const float* pre_add, const float* wpack, float* y,
-                               int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
-                               int sh, int sw, int pad_top, int pad_left,
-                               const float* bias, int relu,
-                               int out_channel_offset, int out_channels_total,
-                               float act_lo, float act_hi);
 /* MaxPool.py:41-72 (3x3 window, stride 1, pad 1 all round: output extent = input extent) followed by a 1x1 / stride 1 / unpadded
  * Convolution.py:57-87, as one launch: y = conv1x1(maxpool(x)); the pooled tensor is never written.  Bit-identical to
  * pvhip_maxpool2d_f32 followed by pvhip_conv2d_f32.  x is (n, c, h, w); wpack the pvhip_conv2d_pack_f32 panel of the (k_out, c, 1, 1)

@@ -31,7 +31,6 @@ struct Settings {
     int  conv_winograd4 = 1;     // PVHIP_CONV_WINOGRAD4: 0 off, 1 by size rule, 2 ("force") any size
     int  conv_winograd5 = 1;     // PVHIP_CONV_WINOGRAD5: likewise for F(2x2,5x5)
     bool conv_pointwise = true;  // PVHIP_CONV_POINTWISE=0: 1x1 layers on the general LDS-DMA kernel
-    bool conv_stem      = false; // PVHIP_CONV_STEM=1: the persistent 7x7 / stride 2 / 3-channel kernel for the first layer (opt-in)
     int  fuse_poolconv  = 1;     // PVHIP_FUSE_POOLCONV: 0 off, 1 rows of whole 16-byte groups, 2 also 8-byte groups
     bool pool3          = true;  // PVHIP_POOL3=0: the one-shot MaxPool kernel for 3x3 windows too
     // ---- tuning runs (scripts/): defaults are what the product uses
@@ -46,12 +45,11 @@ struct Settings {
     int  pool3_kb = 16, pool3_stage = 1, pool3_wg = 0, pool3_g = 0, pool3_s = 0, pool3_band = 0;   // PVHIP_POOL3_KB/_STAGE/_WG/_CFG
     bool pool3_verbose = false;
     int  pool_lds_kb = 16;                 // PVHIP_POOL_LDS_KB
-    int  stem_wg = 0;                      // PVHIP_STEM_WG
     int  wino_kb = 0;                      // PVHIP_WINO_KB=32|64
     bool wino_small = true;                // PVHIP_WINO_SMALL=0
     int  wino_waves = 8;                   // PVHIP_WINO_WAVES=4
     // ---- wrong-on-purpose ablations: honoured only by the diagnostic build (make diag -> libpvhip_diag.so, -DPVHIP_DIAG)
-    int  conv_ablate = 0, stem_ablate = 0, wino4_ablate = 0, pw_ablate = 0;
+    int  conv_ablate = 0, wino4_ablate = 0, pw_ablate = 0;
     bool pool3_tuning() const { return pool3_kb != 16 || pool3_stage != 1 || pool3_wg != 0 || pool3_g != 0; }
 };
 const Settings& settings();

@@ -980,7 +980,6 @@ size_t pvhip_conv2d_pack_elems(int k_out, int c, int kh, int kw) {
     const size_t kred_pad = (size_t)round_up_int(c * kh * kw, kBK);
     const size_t kout_pad = (size_t)round_up_int(k_out, kKoutAlign);
     size_t elems = 2 * (kred_pad + kTabSpare) + (kred_pad + kPanelSpare) * kout_pad;   // two tables, then the weight panel (both with spare stages)
-    elems += stem_pack_elems(k_out, c, kh, kw);      // the 7x7 / 3-channel stem keeps its own panel behind the general one
     if (kh == 3 && kw == 3) elems += wino_pack_elems(k_out, c) + wino4_pack_elems(k_out, c);
     if (kh == 1 && kw == 1) elems += pw_pack_elems(k_out, c);         // 1x1: the fragment-ordered panel of the pointwise kernel
     if (kh == 5 && kw == 5) elems += wino4_pack_elems(k_out, c);       // 5x5: the F(2x2,5x5) panel   // 3x3: the Winograd-transformed panels ride along (stride / pad are not known yet)
@@ -998,10 +997,6 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
     float* wp   = wpack + 2 * (kred_pad + kTabSpare);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid_for((size_t)(kred_pad + kPanelSpare) * kout_pad)), dim3(kBlock), 0, state().stream,
                        w_oihw, ktab, wp, k_out, c, kh, kw, h, w, kred, kred_pad, kout_pad, rs_major(c, kh, kw) ? 1 : 0);
-    if (stem_pack_elems(k_out, c, kh, kw) > 0) {
-        const int rc = stem_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out);
-        if (rc) return rc;
-    }
     if (kh == 1 && kw == 1 && pw_pack_elems(k_out, c) > 0) {
         const int rc = pw_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out, c);
         if (rc) return rc;
@@ -1023,7 +1018,7 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
     return PVHIP_OK;
 }
 
-static int conv2d_impl(const float* x, const float* pre_add, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh,
+static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh,
                        int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
                        int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
     PVHIP_REQUIRE_INIT();
@@ -1061,16 +1056,6 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
 
     // ---- 3x3 / stride 1 / same padding: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (pvhip_wino.hip)
-    // ---- 7x7 / stride 2 / 3 input channels: the persistent stem kernel (pvhip_stem.hip)
-    if (stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, out_e)) {
-        const int rc = stem_conv(x, pre_add, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, y, n, h, w, k_out, oh, ow, pad_top,
-                                 pad_left, bias, relu, act_lo, act_hi, a.y_coff, a.y_ctotal);
-        if (rc) return rc;
-        PVHIP_LAUNCH_CHECK();
-        return PVHIP_OK;
-    }
-    if (pre_add != nullptr)
-        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_preadd_f32: only the 7x7 / stride 2 / 3-channel stem kernel adds in its fetch (ask pvhip_conv2d_preadd_supported)");
     if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
         const PwDest d{y, 0, k_out, a.y_ctotal, a.y_coff};
         const int rc = pw_conv(x, a.wp + (size_t)(a.kred_pad + kPanelSpare) * a.kout_pad, n, c, h * w, k_out, bias, relu, act_lo, act_hi, 1, &d);
@@ -1165,30 +1150,16 @@ static int conv2d_impl(const float* x, const float* pre_add, const float* wpack,
 int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh, int kw,
                      int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
                      int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
-    return conv2d_impl(x, nullptr, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
+    return conv2d_impl(x, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
                        out_channels_total, act_lo, act_hi);
 }
 
 int pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left) {
-    const unsigned long long out_e = (unsigned long long)n * k_out * oh * ow;
-    if (stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, out_e)) return PVHIP_CONV_KIND_STEM;
     if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return PVHIP_CONV_KIND_POINTWISE;
     if (wino25_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) return PVHIP_CONV_KIND_WINO_F2_5X5;
     if (wino4_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) return PVHIP_CONV_KIND_WINO_F4_3X3;
     if (wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return PVHIP_CONV_KIND_WINO_F2_3X3;
     return PVHIP_CONV_KIND_IGEMM;
-}
-
-int pvhip_conv2d_preadd_supported(int n, int c, int kh, int kw, int sh, int sw, int k_out, int oh, int ow, int pad_top, int pad_left) {
-    return stem_eligible(c, kh, kw, sh, sw, k_out, pad_top, pad_left, (unsigned long long)n * k_out * oh * ow) ? 1 : 0;
-}
-
-int pvhip_conv2d_preadd_f32(const float* x, const float* pre_add, const float* wpack, float* y, int n, int c, int h, int w, int k_out,
-                            int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
-                            int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
-    PVHIP_CHECK_ARG(pre_add != nullptr);
-    return conv2d_impl(x, pre_add, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
-                       out_channels_total, act_lo, act_hi);
 }
 
 int pvhip_conv2d_multi_supported(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int n_dest) {

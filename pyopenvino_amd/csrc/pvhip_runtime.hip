@@ -30,7 +30,6 @@ void load_settings() {
     s.generation = g_settings.generation + 1;
     auto env   = [](const char* name) -> const char* { const char* e = getenv(name); return (e != nullptr && e[0] != 0) ? e : nullptr; };
     auto is0   = [&](const char* name) { const char* e = env(name); return e != nullptr && e[0] == '0'; };
-    auto is1   = [&](const char* name) { const char* e = env(name); return e != nullptr && e[0] == '1'; };
     auto num   = [&](const char* name, int dflt) { const char* e = env(name); return e != nullptr ? atoi(e) : dflt; };
     auto tri   = [&](const char* name) { const char* e = env(name); return e == nullptr ? 1 : (e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1)); };
     if (const char* e = env("PVHIP_CONV_KERNEL")) s.conv_kernel = strcmp(e, "lds") == 0 ? 1 : (strcmp(e, "wave") == 0 ? 2 : 0);
@@ -38,7 +37,6 @@ void load_settings() {
     s.conv_winograd4 = tri("PVHIP_CONV_WINOGRAD4");
     s.conv_winograd5 = tri("PVHIP_CONV_WINOGRAD5");
     s.conv_pointwise = !is0("PVHIP_CONV_POINTWISE");
-    s.conv_stem      = is1("PVHIP_CONV_STEM");
     if (const char* e = env("PVHIP_FUSE_POOLCONV")) s.fuse_poolconv = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
     s.pool3 = !(env("PVHIP_POOL3") != nullptr && num("PVHIP_POOL3", 1) == 0);
     if (const char* e = env("PVHIP_CONV_TILE")) {
@@ -61,13 +59,11 @@ void load_settings() {
     }
     s.pool3_verbose = env("PVHIP_POOL3_VERBOSE") != nullptr;
     s.pool_lds_kb   = num("PVHIP_POOL_LDS_KB", 16);
-    s.stem_wg       = num("PVHIP_STEM_WG", 0);
     { const int v = num("PVHIP_WINO_KB", 0); s.wino_kb = (v == 32 || v == 64) ? v : 0; }
     s.wino_small = !is0("PVHIP_WINO_SMALL");
     s.wino_waves = num("PVHIP_WINO_WAVES", 8) == 4 ? 4 : 8;
 #ifdef PVHIP_DIAG
     s.conv_ablate  = num("PVHIP_CONV_ABLATE", 0);
-    s.stem_ablate  = num("PVHIP_STEM_ABLATE", 0);
     s.wino4_ablate = num("PVHIP_WINO4_ABLATE", 0);
     s.pw_ablate    = num("PVHIP_PW_ABLATE", 0);
 #endif

@@ -23,13 +23,6 @@ int    wino4_conv(int m, const float* x, const float* u, float* y, int n, int c,
 bool   wino25_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n);
 int    wino25_pack(const float* w_oihw, float* u, int k, int c);
 
-// The 7x7 / stride 2 / 3-channel first convolution (pvhip_stem.hip): its own weight panel and persistent kernel
-bool   stem_eligible(int c, int kh, int kw, int sh, int sw, int k_out, int pad_top, int pad_left, unsigned long long out_elems);
-size_t stem_pack_elems(int k, int c, int kh, int kw);
-int    stem_pack(const float* w_oihw, float* wl, int k);
-int    stem_conv(const float* x, const float* pre_add, const float* wl, float* y, int n, int h, int w, int k_out, int oh, int ow, int pad_top,
-                 int pad_left, const float* bias, int act, float act_lo, float act_hi, int out_channel_offset, int out_channels_total);
-
 // Pointwise (1x1 / stride 1 / unpadded, C a multiple of 16) convolutions (pvhip_pw.hip): weights in MFMA-fragment order, one
 // workgroup per pixel tile and group of <= 8 32-channel tiles; PVHIP_CONV_POINTWISE=0 selects the general kernel
 struct PwDest {

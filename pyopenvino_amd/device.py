@@ -75,8 +75,6 @@ SIGNATURES = {
     'pvhip_conv2d_f16': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_matmul_f16': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
-    'pvhip_conv2d_preadd_supported': (_c.c_int, [_c.c_int] * 11),
-    'pvhip_conv2d_preadd_f32': (_c.c_int, [_fp, _fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),
     'pvhip_conv2d_pooled_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 5 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_multi_supported': (_c.c_int, [_c.c_int] * 8),
@@ -93,7 +91,7 @@ SIGNATURES = {
 
 # entry points whose return value is not a status code
 _NOT_STATUS = {'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported',
-               'pvhip_conv2d_multi_supported', 'pvhip_conv2d_preadd_supported', 'pvhip_conv2d_pooled_supported'}
+               'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
 MAX_CONV_DESTS = 6

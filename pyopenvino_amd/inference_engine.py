@@ -349,7 +349,6 @@ class Executable_Network:
         self._concat_direct = {}        # Concat node id -> total channels, when every input is written in place
         self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it
         self._siblings = {}             # Convolution node id -> ids of the convolutions of the same input launched with it
-        self._pre_add = {}              # Convolution node id -> (Add node folded into its input fetch, Const id, id of the Add's data input)
         self._pool_conv = {}            # Convolution node id -> (MaxPool node folded into its input tile, id of the MaxPool's data input)
         self.fuse_siblings = os.environ.get('PVHIP_FUSE_SIBLINGS', '1') != '0'
         self._infer_serial = 0
@@ -403,7 +402,7 @@ class Executable_Network:
                 del node[key]
             for port in node.get('output', {}).values():
                 port.pop('data', None)
-            for key in ('result', 'param', '_sibling_out', '_fuse_bias', '_out_into', '_siblings', '_fuse_pool', '_fuse_pool_in', '_fuse_pre_add'):
+            for key in ('result', 'param', '_sibling_out', '_fuse_bias', '_out_into', '_siblings', '_fuse_pool', '_fuse_pool_in'):
                 node.pop(key, None)
 
     def start_async(self, request_id: int, inputs: dict):
@@ -446,7 +445,7 @@ class Executable_Network:
         bit-identical to the three launches); the Add and ReLU nodes are not dispatched and their output
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
-        self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pre_add, self._pool_conv = {}, set(), {}, {}, {}, {}
+        self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pool_conv = {}, set(), {}, {}, {}
         if not self.fuse_epilogues:
             return
         G = self.ienet.G
@@ -525,28 +524,7 @@ class Executable_Network:
             self._concat_direct[nid] = coff
             self._fused_away.add(nid)
 
-        # An Add of a per-channel Const whose only consumer is a convolution that adds in its own input fetch (the 7x7 stem
-        # behind data/mean): the Add is not dispatched, the convolution reads the Add's input and receives the constant.
         f16 = bool(getattr(self.ienet, 'f16_mfma', False))     # the f16-MFMA kernel fuses the epilogue and the Concat store only
-        if not f16 and getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False) and os.environ.get('PVHIP_FUSE_PREADD', '1') != '0':
-            for cid in G.nodes:
-                if G.nodes[cid]['type'] != 'Convolution' or cid in self._fused_away:
-                    continue
-                src = next((p_ for p_ in G.pred[cid] if G.edges[(p_, cid)]['connection'][3] == 0), None)
-                if src is None or G.nodes[src]['type'] != 'Add' or src in self._fused_away or len(list(G.successors(src))) != 1:
-                    continue
-                preds = sorted(G.pred[src], key=lambda p_: G.edges[(p_, src)]['connection'][3])
-                if len(preds) != 2 or G.nodes[preds[1]]['type'] != 'Const' or G.nodes[preds[0]]['type'] == 'Const':
-                    continue
-                chans = G.nodes[cid]['input'][0]['dims'][1]
-                cdata = G.nodes[preds[1]]['data']
-                if tuple(cdata['shape']) != (1, chans, 1, 1) or cdata['element_type'] != 'f32':
-                    continue
-                if tuple(G.nodes[src]['input'][0]['dims']) != tuple(G.nodes[cid]['input'][0]['dims']):
-                    continue
-                if conv_plugin.pre_add_fusable(G.nodes[cid]):
-                    self._pre_add[cid] = (src, preds[1], preds[0])
-                    self._fused_away.add(src)
         # A 3x3 / stride 1 / pad 1 MaxPool whose only consumer is a fused 1x1 convolution (pool -> pool_proj): the MaxPool is not
         # dispatched, the convolution reads the MaxPool's input and pools while it builds its input tile.
         if not f16 and getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and os.environ.get('PVHIP_FUSE_POOLCONV', '1') != '0':
@@ -623,8 +601,7 @@ class Executable_Network:
                     if nid is not None:
                         owner[nid] = lead
 
-        folded_adds = {add_id: src_id for add_id, _, src_id in self._pre_add.values()}
-        folded_adds.update({pool_id: src_id for pool_id, src_id in self._pool_conv.values()})      # ... and MaxPools folded likewise
+        folded_adds = {pool_id: src_id for pool_id, src_id in self._pool_conv.values()}      # MaxPools folded into their consumer's fetch
 
         def producers(nid):
             if nid in folded_adds:           # an Add folded into its consumer's fetch: whoever wrote the Add's input
@@ -793,15 +770,6 @@ class Executable_Network:
                     device.select_stream(base + current)
                 for dep in waits[task]:
                     done_events[dep].wait()
-            pre = self._pre_add.get(task)
-            if pre is not None:              # the folded Add hands its own input on: the kernel adds the constant while it fetches
-                add_id, const_id, _ = pre
-                edge = next(G.edges[(p_, add_id)]['connection'] for p_ in G.pred[add_id] if G.edges[(p_, add_id)]['connection'][3] == 0)
-                out = G.nodes[add_id]['output']
-                out[next(iter(out))]['data'] = G.nodes[edge[0]]['output'][edge[1]]['data']
-                node['_fuse_pre_add'] = G.nodes[const_id]['output'][0]['data']
-            else:
-                node.pop('_fuse_pre_add', None)
             pooled_in = self._pool_conv.get(task)
             if pooled_in is not None:        # the folded MaxPool hands its own input on: the kernel pools while it builds its tile
                 pool_id, _ = pooled_in
@@ -978,8 +946,8 @@ class Executable_Network:
                 chain = [cid, f['add']] + ([f['relu']] if f['relu'] is not None else [])
                 if all(c in needed for c in chain):
                     keep[cid] = dict(f, into=None)      # Concat elimination is not applied to sub-graphs
-            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add, self._pool_conv)
-            self._siblings, self._pre_add, self._pool_conv = {}, {}, {}      # sub-graph runs launch every convolution (Add, MaxPool) on its own
+            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pool_conv)
+            self._siblings, self._pool_conv = {}, {}      # sub-graph runs launch every convolution (MaxPool) on its own
             self._fusion = {c: f for c, f in keep.items()}
             self._fused_away = {n for f in self._fusion.values() for n in (f['add'], f['relu']) if n is not None}
             self._concat_direct = {}
@@ -988,7 +956,7 @@ class Executable_Network:
             try:
                 self.run_tasks(False)
             finally:
-                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pre_add, self._pool_conv = saved
+                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pool_conv = saved
         finally:
             self.task_list = full
         out = {}

@@ -20,11 +20,6 @@ SUPPORTS_FUSED_EPILOGUE = True
 # same activation); the input is then read once, by one launch whose output-channel tiles store into the tensor of the
 # convolution they belong to.  The siblings' outputs are left in node['_sibling_out'], in the same order.
 SUPPORTS_SIBLINGS = True
-# An Add of a per-channel constant whose only consumer is a convolution that fetches its input through registers (the 7x7 /
-# stride 2 / 3-channel stem: GoogLeNet's data/mean in front of conv1) may be handed over with the convolution:
-# node['_fuse_pre_add'] = the (1, C, 1, 1) constant, inputs[0] = the Add's own input.  The kernel adds while it fetches (the same
-# fp32 add; zero padding stays zero), the Add launch and its tensor disappear.
-SUPPORTS_PRE_ADD = True
 # A 3x3 / stride 1 / pad 1 MaxPool whose only consumer is a 1x1 convolution (the pool -> pool_proj arm of an inception module) may
 # be handed over with the convolution: node['_fuse_pool_in'] = the MaxPool's node dict, inputs[0] = the MaxPool's own input.  The
 # kernel pools while it builds its input tile; the pooled tensor is never written.
@@ -68,7 +63,7 @@ def packed_weights_f16(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
     return wpack
 
 
-def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, pre_add=None, f16=False):
+def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, f16=False):
     n, c, h, wd = x.shape
     kn, kc, kh, kw = w.shape
     if kc != c:
@@ -97,10 +92,6 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
     if f16:         # FP16 IR: fp16 operands on the f16 matrix cores, fp32 accumulation
         dev.call('pvhip_conv2d_f16', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
-    elif pre_add is not None:
-        assert pre_add.size == c
-        dev.call('pvhip_conv2d_preadd_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(pre_add.ptr), ctypes.c_void_p(wpack.ptr),
-                 ctypes.c_void_p(target.ptr), *tail)
     else:
         dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
     return y
@@ -108,7 +99,7 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
 
 # pvhip_conv2d_kernel_kind codes -> (family name, fraction of the algorithmic multiply-adds the matrix cores execute)
 KERNEL_KINDS = {0: ('implicit GEMM (LDS-DMA)', 1.0), 1: ('pointwise', 1.0), 2: ('Winograd F(2x2,3x3)', 16.0 / 36.0),
-                3: ('Winograd F(4x4,3x3)', 36.0 / 144.0), 4: ('Winograd F(2x2,5x5)', 36.0 / 100.0), 5: ('7x7 stem', 1.0)}
+                3: ('Winograd F(4x4,3x3)', 36.0 / 144.0), 4: ('Winograd F(2x2,5x5)', 36.0 / 100.0)}
 
 
 def kernel_kind(node: dict):
@@ -119,18 +110,6 @@ def kernel_kind(node: dict):
     code = dev.call('pvhip_conv2d_kernel_kind', int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3]), oh, ow,
                     strides[0], strides[1], pb[0], pb[1])
     return KERNEL_KINDS[int(code)]
-
-
-def pre_add_fusable(node: dict) -> bool:
-    """True when libpvhip adds a per-channel constant in this convolution's input fetch (IR port dims; no device needed)."""
-    try:
-        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
-        strides, pb, pe = (common_def.string_to_tuple(attrs[k]) for k in ('strides', 'pads_begin', 'pads_end'))
-        oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
-        return bool(dev.call('pvhip_conv2d_preadd_supported', int(xd[0]), int(xd[1]), int(wd[2]), int(wd[3]), strides[0], strides[1],
-                             int(wd[0]), oh, ow, pb[0], pb[1]))
-    except (KeyError, ValueError, AssertionError, IndexError):
-        return False
 
 
 def pooled_fusable(node: dict, pool_node: dict) -> bool:
@@ -293,9 +272,7 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         outs = launch_siblings(node, x, members, strides, pads_begin, node.get('_fuse_act'))
         y, node['_sibling_out'] = outs[0], outs[1:]
     else:
-        pre_add = node.get('_fuse_pre_add')
-        y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'),
-                   into=node.get('_out_into'), pre_add=dev.as_device(pre_add) if pre_add is not None else None)
+        y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'))
     port = common_def.first_output_port(node)
     assert common_def.type_convert_tbl[node['output'][port]['precision']] == np.float32
     return {port: y}

@@ -153,7 +153,6 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
     _, net_u, ex_u = build_network(HIP, 'googlenet-v1', weights=blob, batch=2, fuse=False)
     assert len(ex_f._fusion) == 57 and len(ex_f._fused_away) == 114 + 9 + 1 + 18 + 2 and len(ex_f._concat_direct) == 9 and not ex_u._fusion
     assert len(ex_f._pool_conv) == 2 and not ex_u._pool_conv           # pool + pool_proj of the 28x28 modules (3a, 3b) as one launch
-    assert not ex_f._pre_add and not ex_u._pre_add                    # (data/mean rides in conv1's patch fetch only with PVHIP_CONV_STEM=1)
     assert len(ex_f._siblings) == 9 and not ex_u._siblings            # 1x1 + 3x3_reduce + 5x5_reduce of a module as one launch
     assert len(ex_f._lrn_pool) == 1 and not ex_u._lrn_pool          # conv2/norm2 -> pool2/3x3_s2 as one launch
     out_f, out_u = infer_one(ex_f, net_f, x), infer_one(ex_u, net_u, x)

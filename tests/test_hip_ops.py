@@ -101,56 +101,17 @@ def test_conv_model_shapes_vs_oracle(hip, xs, ws, st, pb, pe):
     vs_oracle('Convolution', [x, w], conv_data(st, pb, pe), 'conv {} * {}'.format(xs, ws))
 
 
-def test_conv_stem_7x7_stride2(hip, monkeypatch):
-    """The persistent 7x7 / stride 2 / 3-channel kernel (GoogLeNet conv1): ragged extents (half-empty tiles), fewer tiles
-    than workgroups and more, K below 64, asymmetric / no padding, fused bias + ReLU written in place into a wider tensor;
-    against the oracle and against the general kernel."""
-    from pyopenvino_amd import device as dev
-    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', '1')
+def test_conv_7x7_stride2_first_layer(hip):
+    """The 7x7 / stride 2 / 3-channel first layer (GoogLeNet conv1) on the general c-major LDS-DMA kernel: ragged extents, K below
+    64, asymmetric / no padding, many images.  (Two LDS-patch kernels written for this layer -- a persistent one and one tile per
+    workgroup -- measured 0.77 / 0.80 ms against 0.68 ms + 0.07 ms for the Add in front, and lost in the pass: removed.)"""
     cases = [((2, 3, 224, 224), 64, (3, 3), (3, 3)), ((1, 3, 23, 31), 40, (3, 3), (3, 3)), ((3, 3, 40, 17), 7, (0, 0), (0, 0)),
              ((5, 3, 64, 64), 64, (2, 3), (1, 0)), ((1, 3, 7, 7), 3, (0, 0), (0, 0)), ((70, 3, 30, 30), 16, (3, 3), (3, 3))]
     for xs, k, pb, pe in cases:
         x = rnd(sum(xs), xs, 50.0)
         w = rnd(k, (k, 3, 7, 7), (2.0 / 147) ** 0.5)
-        err = vs_oracle('Convolution', [x, w], conv_data((2, 2), pb, pe), 'stem {} k{} pads {} {}'.format(xs, k, pb, pe))
-        assert err <= 2e-5, 'stem {}: {:.2e}'.format(xs, err)
-    x, w, b = rnd(1, (2, 3, 37, 45), 20.0), rnd(2, (24, 3, 7, 7), 0.1), rnd(3, (1, 24, 1, 1), 0.3)
-    node = make_node('Convolution', [x, w], conv_data((2, 2), (3, 3), (3, 3)))
-    oh, ow = hip_plugin('Convolution').calc_output_shape((37, 45), (7, 7), (2, 2), (3, 3), (3, 3), 'floor', 'explicit')
-    wide = dev.DeviceTensor.from_numpy(np.full((2, 30, oh, ow), -1.0, dtype=np.float32))
-    fused = dict(node)
-    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 5)
-    hip_plugin('Convolution').compute(fused, {0: x, 1: w})
-    got = np.asarray(wide)
-    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', '0')
-    general = np.maximum(first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w})) + b, 0)
-    assert_close(got[:, 5:29], general, 5e-6, 'stem fused vs the general kernel')
-    assert np.all(got[:, :5] == -1.0) and np.all(got[:, 29:] == -1.0)
-
-
-def test_conv_stem_with_the_add_in_front_folded_in_is_bit_identical(hip, monkeypatch):
-    """Add(per-channel Const) -> 7x7 / stride 2 convolution handed over as one call (node['_fuse_pre_add']): the kernel adds
-    while it fetches its input patch, padding stays zero -- the bits of the two launches; other convolutions decline."""
-    from pyopenvino_amd import device as dev
-    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', '1')
-    conv, add = hip_plugin('Convolution'), hip_plugin('Add')
-    x = rnd(7, (3, 3, 45, 38), 60.0, 100.0)
-    m = np.array([-104.0, -117.0, -123.0], dtype=np.float32).reshape(1, 3, 1, 1)
-    w, b = rnd(8, (48, 3, 7, 7), 0.05), rnd(9, (1, 48, 1, 1), 0.2)
-    node = make_node('Convolution', [x, w], conv_data((2, 2), (3, 3), (3, 3)))
-    assert conv.pre_add_fusable(node)
-    summed = first_out(add.compute(make_node('Add', [x, m]), {0: x, 1: m}))
-    two = dict(node)
-    two['_fuse_bias'], two['_fuse_act'] = dev.DeviceTensor.from_numpy(b), ('relu',)
-    want = first_out(conv.compute(two, {0: summed, 1: w}))
-    one = dict(node)
-    one['_fuse_bias'], one['_fuse_act'], one['_fuse_pre_add'] = dev.DeviceTensor.from_numpy(b), ('relu',), dev.DeviceTensor.from_numpy(m)
-    got = first_out(conv.compute(one, {0: x, 1: w}))
-    assert_bit_exact(got, want, 'stem with the Add folded in')
-    oracle = np.maximum(first_out(oracle_plugin('Convolution').compute(node, {0: x + m, 1: w}, kernel_type='special')) + b, 0)
-    assert_close(got, oracle, helpers.REL_TOL, 'stem with the Add folded in vs oracle')
-    other = make_node('Convolution', [rnd(1, (1, 16, 8, 8)), rnd(2, (8, 16, 3, 3))], conv_data((1, 1), (1, 1), (1, 1)))
-    assert not conv.pre_add_fusable(other)
+        err = vs_oracle('Convolution', [x, w], conv_data((2, 2), pb, pe), 'conv1-like {} k{} pads {} {}'.format(xs, k, pb, pe))
+        assert err <= 2e-5, 'conv1-like {}: {:.2e}'.format(xs, err)
 
 
 def test_conv_winograd_f2x2_5x5(hip, monkeypatch):

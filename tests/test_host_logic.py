@@ -180,33 +180,23 @@ def test_bench_work_model_matches_survey_totals():
 
 
 def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
-    """plan_streams on GoogLeNet (fused, Concat-eliminated; with and without the opt-in stem kernel, which folds data/mean
-    into conv1) and on the unfused graph: every producer a node reads from is either on the node's own stream or in its
+    """plan_streams on GoogLeNet (fused, Concat-eliminated) and on the unfused graph: every producer a node reads from is either on the node's own stream or in its
     wait list (and records an event); the four arms of an inception module land on four different streams; a host plugin
     set gets no plan."""
-    for fuse, stem in ((True, False), (True, True), (False, False)):
-        if stem:
-            helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', '1')
-        else:
-            helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', None)
+    for fuse in (True, False):
         _, net, ex = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=fuse)
         ex.compute_streams = 4
         stream_of, waits, records = ex.plan_streams()
         G = net.G
         assert set(stream_of.values()) >= ({0, 1, 2} if fuse else {0, 1, 2, 3})      # fused siblings leave three arms per module
 
-        if fuse and stem:                    # data/mean is folded into conv1's input fetch
-            assert {G.nodes[c]['name']: G.nodes[a]['name'] for c, (a, _, _) in ex._pre_add.items()} == {'conv1/7x7_s2/WithoutBiases': 'data/mean'}
-        else:
-            assert not ex._pre_add
-        folded = {a: s for a, _, s in ex._pre_add.values()}
-        folded.update({p_: s for p_, s in ex._pool_conv.values()})       # MaxPools folded into the pool_proj convolutions
+        folded = {p_: s for p_, s in ex._pool_conv.values()}             # MaxPools folded into the pool_proj convolutions
         assert len(ex._pool_conv) == (2 if fuse else 0)                  # the 28x28 modules (rows of whole 16-byte groups)
         lead_of = {n: lead for lead, sibs in ex._siblings.items() for s in sibs
                    for n in (s, ex._fusion[s]['add'], ex._fusion[s]['relu']) if n is not None}
 
         def writers(nid):                    # dispatched nodes whose kernels write the tensor `nid` hands on
-            if nid in folded:                # an Add folded into its consumer: the tensor is the Add's own input
+            if nid in folded:                # a MaxPool folded into its consumer: the tensor is the MaxPool's own input
                 return writers(folded[nid])
             if nid in lead_of:               # a convolution launched with its sibling
                 return [lead_of[nid]]
