@@ -81,8 +81,13 @@ int         pvhip_event_record(void* ev);
 int         pvhip_event_sync(void* ev);
 int         pvhip_event_elapsed_ms(void* start, void* stop, float* ms);
 
-/* hipGraph capture of one whole forward pass (run_tasks loop, inference_engine.py:259-292) */
+/* hipGraph capture of one whole forward pass (the run_tasks loop, inference_engine.py:259-292): between _begin_capture and
+ * _end_capture every launch on the current stream -- and on the streams that join it through events -- is recorded instead of
+ * executed; pvhip_graph_launch replays the whole pass with one call.  While a capture is open pvhip_malloc must be served
+ * by the pool (run the pass eagerly first) and freed blocks stay pinned until pvhip_graph_destroy: the captured kernels hold
+ * their addresses.  No host-synchronising call (pvhip_sync, _memcpy_h2d / _d2h) may be made inside a capture.            */
 int         pvhip_graph_begin_capture(void);
+int         pvhip_graph_capture_status(int* status);    /* current stream: 0 not capturing, 1 capturing, 2 capture invalidated by an illegal call */
 int         pvhip_graph_end_capture(void** graph_exec);
 int         pvhip_graph_launch(void* graph_exec);
 int         pvhip_graph_destroy(void* graph_exec);

@@ -18,6 +18,7 @@ struct State {
     hipStream_t streams[kMaxStreams] = {};        // streams[0] is created by pvhip_init, the others on first select
     int         current = 0;
     bool        forked  = false;                  // a stream other than 0 has been used since the last full sync
+    bool        capturing = false;                // between pvhip_graph_begin_capture and _end_capture: nothing executes yet
 };
 State& state();
 

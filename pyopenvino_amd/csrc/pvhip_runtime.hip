@@ -83,7 +83,7 @@ int fail(int code, const char* fmt, ...) {
 namespace {
 struct Pool {
     std::mutex                                  mu;
-    struct Live { size_t bytes; int epoch; };
+    struct Live { size_t bytes; int epoch; bool captured; };   // captured: allocated while a pass was being captured into a graph
     std::unordered_map<void*, Live>             live;    // ptr -> rounded bytes, allocation epoch
     std::map<size_t, std::vector<void*>>        cached;  // rounded bytes -> free blocks
     std::vector<std::pair<void*, size_t>>       deferred; // epoch-0 blocks freed while streams were forked: reusable after a full sync
@@ -93,6 +93,9 @@ struct Pool {
     int                                                     next_epoch = 1, current_epoch = 0;
     std::unordered_map<int, std::vector<std::pair<void*, size_t>>> parked;   // open epoch -> freed blocks
     size_t                                      bytes_live = 0, bytes_cached = 0;
+    // Blocks freed while a forward pass is being CAPTURED into a hipGraph (workspaces, temporaries): the graph's kernels hold
+    // their addresses for every replay, so they are not handed out again until the graph is destroyed.
+    std::vector<std::pair<void*, size_t>>       capture_keep;
 };
 Pool& pool() {
     static Pool p;
@@ -234,6 +237,9 @@ int pvhip_malloc(void** ptr, size_t bytes) {
         it->second.pop_back();
         p.bytes_cached -= rb;
     } else {
+        if (state().capturing)
+            return fail(PVHIP_EHIP, "pvhip_malloc(%zu bytes): the pool has no such block while a pass is being captured into a graph "
+                                    "(run the pass eagerly first: steady-state inference allocates nothing new)", rb);
         void*      d = nullptr;
         hipError_t e = hipMalloc(&d, rb);
         if (e != hipSuccess) {
@@ -256,7 +262,7 @@ int pvhip_malloc(void** ptr, size_t bytes) {
         }
         *ptr = d;
     }
-    p.live[*ptr] = Pool::Live{rb, p.current_epoch};
+    p.live[*ptr] = Pool::Live{rb, p.current_epoch, state().capturing};
     p.bytes_live += rb;
     return PVHIP_OK;
 }
@@ -270,8 +276,16 @@ int pvhip_free(void* ptr) {
     if (it == p.live.end()) return fail(PVHIP_EINVAL, "pvhip_free: %p is not a live pvhip block", ptr);
     const size_t rb    = it->second.bytes;
     const int    epoch = it->second.epoch;
+    const bool   captured = it->second.captured;
     p.live.erase(it);
     p.bytes_live -= rb;
+    if (state().capturing && captured) {
+        // allocated AND freed inside the capture (a workspace, a temporary): the captured kernels use it on every replay, so
+        // it stays out of circulation until the graph is destroyed.  (A block of an EARLIER pass freed now -- an output this
+        // pass replaces -- is in no captured kernel: it goes back to the pool as always and may serve this very pass.)
+        p.capture_keep.emplace_back(ptr, rb);
+        return PVHIP_OK;
+    }
     if (epoch != 0) {
         auto open = p.parked.find(epoch);
         if (open != p.parked.end()) {       // its pass may still be running on some stream
@@ -370,6 +384,7 @@ int pvhip_memset(void* dst, int byte, size_t bytes) {
 
 int pvhip_sync(void) {
     PVHIP_REQUIRE_INIT();
+    if (state().capturing) return fail(PVHIP_EINVAL, "pvhip_sync: a pass is being captured into a graph (nothing executes until it is replayed)");
     return sync_all_streams();
 }
 
@@ -437,21 +452,54 @@ int pvhip_event_elapsed_ms(void* start, void* stop, float* ms) {
     return PVHIP_OK;
 }
 
+// hipGraph capture of a whole forward pass (the run_tasks loop, inference_engine.py:259-292): every launch of the pass -- on the
+// current stream and on the streams that join it through events -- becomes a node of one graph that is replayed with ONE call.
+struct GraphExec {
+    hipGraphExec_t                        exec = nullptr;
+    std::vector<std::pair<void*, size_t>> keep;      // blocks freed during the capture: pinned until the graph is destroyed
+};
+
 int pvhip_graph_begin_capture(void) {
     PVHIP_REQUIRE_INIT();
-    PVHIP_HIP(hipStreamBeginCapture(state().stream, hipStreamCaptureModeThreadLocal));
+    if (state().capturing) return fail(PVHIP_EINVAL, "pvhip_graph_begin_capture: a capture is already open");
+    // relaxed: event creation / destruction (Python's garbage collector) and pool bookkeeping go on beside the capture
+    PVHIP_HIP(hipStreamBeginCapture(state().stream, hipStreamCaptureModeRelaxed));
+    state().capturing = true;
+    return PVHIP_OK;
+}
+
+int pvhip_graph_capture_status(int* status) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(status != nullptr);
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    PVHIP_HIP(hipStreamIsCapturing(state().stream, &st));
+    *status = st == hipStreamCaptureStatusActive ? 1 : (st == hipStreamCaptureStatusInvalidated ? 2 : 0);
     return PVHIP_OK;
 }
 
 int pvhip_graph_end_capture(void** graph_exec) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(graph_exec != nullptr);
+    if (!state().capturing) return fail(PVHIP_EINVAL, "pvhip_graph_end_capture: no capture is open");
+    state().capturing = false;
+    GraphExec* ge = new GraphExec;
+    {
+        Pool& p = pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        ge->keep.swap(p.capture_keep);
+    }
+    auto release = [&]() {
+        Pool& p = pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        for (auto& blk : ge->keep) { p.cached[blk.second].push_back(blk.first); p.bytes_cached += blk.second; }
+        delete ge;
+    };
     hipGraph_t g = nullptr;
-    PVHIP_HIP(hipStreamEndCapture(state().stream, &g));
-    hipGraphExec_t ge = nullptr;
-    hipError_t     e  = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipError_t e = hipStreamEndCapture(state().stream, &g);
+    if (e != hipSuccess) { release(); (void)hipGetLastError(); return fail(PVHIP_EHIP, "hipStreamEndCapture -> %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (e != hipSuccess) return fail(PVHIP_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(e));
+    if (e != hipSuccess) { release(); return fail(PVHIP_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(e)); }
     *graph_exec = (void*)ge;
     return PVHIP_OK;
 }
@@ -459,13 +507,21 @@ int pvhip_graph_end_capture(void** graph_exec) {
 int pvhip_graph_launch(void* graph_exec) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(graph_exec != nullptr);
-    PVHIP_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, state().stream));
+    PVHIP_HIP(hipGraphLaunch(static_cast<GraphExec*>(graph_exec)->exec, state().stream));
     return PVHIP_OK;
 }
 
 int pvhip_graph_destroy(void* graph_exec) {
-    if (graph_exec == nullptr || !state().ready) return PVHIP_OK;
-    PVHIP_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    if (graph_exec == nullptr) return PVHIP_OK;
+    GraphExec* ge = static_cast<GraphExec*>(graph_exec);
+    if (state().ready) {
+        (void)sync_all_streams();
+        if (ge->exec != nullptr) (void)hipGraphExecDestroy(ge->exec);
+        Pool& p = pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        for (auto& blk : ge->keep) { p.cached[blk.second].push_back(blk.first); p.bytes_cached += blk.second; }
+    }
+    delete ge;
     return PVHIP_OK;
 }
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     'pvhip_event_sync': (_c.c_int, [_c.c_void_p]),
     'pvhip_event_elapsed_ms': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_float)]),
     'pvhip_graph_begin_capture': (_c.c_int, []),
+    'pvhip_graph_capture_status': (_c.c_int, [_c.POINTER(_c.c_int)]),
     'pvhip_graph_end_capture': (_c.c_int, [_c.POINTER(_c.c_void_p)]),
     'pvhip_graph_launch': (_c.c_int, [_c.c_void_p]),
     'pvhip_graph_destroy': (_c.c_int, [_c.c_void_p]),

@@ -18,6 +18,7 @@ Differences from the reference, all outside the numeric path:
 """
 import importlib
 import os
+from ctypes import byref, c_void_p as ctypes_void_p
 import pkgutil
 import sys
 import time
@@ -873,6 +874,80 @@ class Executable_Network:
                 device.select_stream(0)
                 device.synchronize()
                 device.pool_epoch_end(epoch)
+
+    # ---- hipGraph replay of a whole pass (what the reference's run_tasks loop, :259-292, becomes: one launch call)
+    def capture_graph(self, inputs: dict, warm: int = 2):
+        """Record one forward pass -- all its launches, on the base stream and on the streams the inception arms fork onto -- into a
+        hipGraph, for inputs that are resident on the device.  `infer_graph()` then replays it with ONE call instead of ~100
+        dispatches.  The graph holds the addresses of every tensor of the pass: they are kept alive with it (`release_graph`)."""
+        from . import device
+        G = self.ienet.G
+        if not all(isinstance(v, device.DeviceTensor) for v in inputs.values()):
+            raise ValueError('capture_graph needs device-resident inputs (DeviceTensor): their addresses go into the graph')
+        self.release_graph()
+        for _ in range(max(1, warm)):           # the pool learns every block size of the pass: a capture must not hipMalloc
+            self.infer(inputs)
+        by_name = {G.nodes[n]['name']: n for n in G.nodes}
+        for node_name, val in inputs.items():
+            G.nodes[by_name[node_name]]['param'] = val
+        results = self.ienet.find_node_by_type('Result')
+        for nid, _ in results:
+            G.nodes[nid]['comm'] = None
+            G.nodes[nid]['_async'] = True       # the Result stays on the device: infer_graph() reads it back
+        saved_timing, self.device_timing = self.device_timing, None
+        device.select_stream(self.stream_base)
+        device.call('pvhip_graph_begin_capture')
+        handle = ctypes_void_p()
+        try:
+            self.defer_sync = True
+            try:
+                self.run_tasks(False)
+            finally:
+                self.defer_sync = False
+                self.device_timing = saved_timing
+                for nid, _ in results:
+                    G.nodes[nid].pop('_async', None)
+        finally:
+            device.select_stream(self.stream_base)
+            device.call('pvhip_graph_end_capture', byref(handle))       # (also after an error: the capture must be closed)
+        pending = self.__dict__.pop('_pending', None)   # its event belongs to the graph: nothing to wait for, just close the epoch
+        if pending is not None:
+            device.pool_epoch_end(pending[0])
+        keep = [p['data'] for n in G.nodes for p in G.nodes[n].get('output', {}).values() if 'data' in p]
+        keep += [G.nodes[nid]['result'] for nid, _ in results]
+        self._graph = {'handle': handle.value, 'inputs': dict(inputs), 'keep': keep,
+                       'results': {name: G.nodes[nid]['result'] for nid, name in results}}
+        device.select_stream(0)
+
+    def infer_graph(self, inputs: dict = None) -> dict:
+        """Replay the captured pass (for new inputs: copied device-to-device into the captured input tensors first) and return
+        {Result name: ndarray} like infer()."""
+        from . import device
+        import ctypes
+        g = self.__dict__.get('_graph')
+        if g is None:
+            raise RuntimeError('no captured graph: call capture_graph(inputs) first')
+        device.select_stream(self.stream_base)
+        for name, val in (inputs or {}).items():
+            dst = g['inputs'][name]
+            if val is dst:
+                continue
+            src = device.as_device(val)
+            if src.shape != dst.shape:
+                raise ValueError('input {} has shape {}, the graph was captured for {}'.format(name, src.shape, dst.shape))
+            device.call('pvhip_memcpy_d2d', ctypes.c_void_p(dst.ptr), ctypes.c_void_p(src.ptr), dst.nbytes)
+        device.call('pvhip_graph_launch', ctypes.c_void_p(g['handle']))
+        out = {name: (t.numpy() if hasattr(t, 'numpy') and not isinstance(t, np.ndarray) else np.asarray(t)) for name, t in g['results'].items()}
+        device.select_stream(0)
+        device.synchronize()
+        return out
+
+    def release_graph(self):
+        g = self.__dict__.pop('_graph', None)
+        if g is not None:
+            from . import device
+            import ctypes
+            device.call('pvhip_graph_destroy', ctypes.c_void_p(g['handle']))
 
     def wait_done(self):
         """Host-side wait for a pass dispatched with defer_sync (its streams have been joined on the base stream)."""

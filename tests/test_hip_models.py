@@ -381,3 +381,30 @@ def test_fp16_ir_on_the_f16_matrix_cores(hip, tmp_path):
     # an FP32 IR is never switched to f16 arithmetic
     net32 = ie.read_network(os.path.join(helpers.MODELS, 'mnist.xml'), fp16_as_fp32=False)
     assert net32.ir_precision == 'FP32' and not net32.f16_mfma
+
+
+@pytest.mark.parametrize('model,shape,streams', [('mnist', (1, 28, 28), 1), ('googlenet-v1', (3, 224, 224), 4), ('googlenet-v1', (3, 224, 224), 1)])
+def test_hipgraph_replay_of_a_forward_pass_is_bit_identical(hip, model, shape, streams):
+    """Executable_Network.capture_graph records one pass (all streams of the stream plan) into a hipGraph; infer_graph replays it
+    with one call: the bits of the eager infer(), also for NEW inputs (copied into the captured input tensor) and after eager
+    passes in between (the graph keeps its tensors alive; blocks freed during the capture stay pinned)."""
+    from pyopenvino_amd import synth
+    B = 8
+    blob = None if model == 'mnist' else synth.synth_weights(os.path.join(helpers.MODELS, model + '.xml'), 1234)
+    _, net, ex = build_network(HIP, model, weights=blob, batch=B)
+    ex.compute_streams = streams
+    name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
+    x1, x2 = (synth.uniform_pixels(s, (B,) + shape) for s in (31, 32))
+    d1, d2 = hip.DeviceTensor.from_numpy(x1), hip.DeviceTensor.from_numpy(x2)
+    want1 = infer_one(ex, net, d1)
+    want2 = infer_one(ex, net, d2)
+    assert not np.array_equal(want1, want2)
+    ex.capture_graph({name: hip.DeviceTensor.from_numpy(x1)})      # the graph's own input tensor: new inputs are copied into it
+    helpers.assert_bit_exact(ex.infer_graph()[out_name], want1, 'replay')
+    helpers.assert_bit_exact(ex.infer_graph({name: d2})[out_name], want2, 'replay with new input')
+    helpers.assert_bit_exact(infer_one(ex, net, d1), want1, 'eager pass after a capture')
+    helpers.assert_bit_exact(ex.infer_graph({name: x1})[out_name], want1, 'replay after an eager pass, host input')
+    ex.release_graph()
+    with pytest.raises(RuntimeError):
+        ex.infer_graph()
+    helpers.assert_bit_exact(infer_one(ex, net, d2), want2, 'eager pass after the graph is gone')
