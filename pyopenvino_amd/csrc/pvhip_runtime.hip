@@ -221,7 +221,9 @@ int pvhip_device_name(char* buf, size_t buflen) {
     PVHIP_CHECK_ARG(buf != nullptr && buflen > 0);
     hipDeviceProp_t prop;
     PVHIP_HIP(hipGetDeviceProperties(&prop, state().device));
-    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    // some driver stacks report an empty marketing name: say what the architecture is then
+    const char* name = prop.name[0] != 0 ? prop.name : (strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? "AMD Instinct MI355X-class (gfx950)" : "AMD GPU");
+    snprintf(buf, buflen, "%s (%s, %d CUs)", name, prop.gcnArchName, prop.multiProcessorCount);
     return PVHIP_OK;
 }
 

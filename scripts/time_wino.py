@@ -13,6 +13,8 @@ LAYERS = [('conv2/3x3', (256, 64, 56, 56), 192, 3), ('3a/3x3', (256, 96, 28, 28)
           ('4e/3x3', (256, 160, 14, 14), 320, 3),
           ('3a/5x5', (256, 16, 28, 28), 32, 5), ('3b/5x5', (256, 32, 28, 28), 96, 5), ('4a/5x5', (256, 16, 14, 14), 48, 5),
           ('4b/5x5', (256, 24, 14, 14), 64, 5), ('4d/5x5', (256, 32, 14, 14), 64, 5), ('4e/5x5', (256, 32, 14, 14), 128, 5)]
+if os.environ.get('ABLATE'):          # the ablation paths exist only in the diagnostic build (make -C pyopenvino_amd/csrc diag)
+    dev.LIB_PATH = os.path.join(os.path.dirname(dev.LIB_PATH), 'libpvhip_diag.so')
 dev.init(0)
 only = sys.argv[1] if len(sys.argv) > 1 else ''
 for name, xs, k, ks in LAYERS:
@@ -33,6 +35,7 @@ for name, xs, k, ks in LAYERS:
     for tag, env in variants:
         for k_, v_ in env.items():
             os.environ[k_] = v_
+        dev.reload_settings()
         node = {}
         pd = (ks // 2, ks // 2)
         run = lambda: Convolution.launch(node, x, wt, (1, 1), pd, pd, 'explicit', bias=b, act=('relu',))
@@ -48,6 +51,7 @@ for name, xs, k, ks in LAYERS:
         line += ' {}: {:.3f} ms {:5.1f} TF |'.format(tag, ms, gf / ms)
         for k_ in env:
             del os.environ[k_]
+        dev.reload_settings()
     ref = outs['direct']
     sc = np.abs(ref).max()
     line += ' max |x - direct| / max: ' + ', '.join('{} {:.1e}'.format(k_, np.abs(v_ - ref).max() / sc) for k_, v_ in outs.items() if k_ != 'direct')

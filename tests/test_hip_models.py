@@ -254,6 +254,9 @@ def test_rccl_binding_single_rank(hip):
         recv = hip.DeviceTensor.empty(x.shape)
         hip.call('pvhip_comm_allgather_f32', ctypes.c_void_p(send.ptr), ctypes.c_void_p(recv.ptr), x.size)
         helpers.assert_bit_exact(np.asarray(recv), x, 'single-rank all-gather')
+        ranks = ctypes.c_int(0)
+        hip.call('pvhip_comm_ranks', ctypes.byref(ranks))          # ncclCommCount: what bench.py reports as rccl_ranks
+        assert ranks.value == 1
     finally:
         hip.call('pvhip_comm_destroy')
 

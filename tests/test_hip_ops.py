@@ -827,3 +827,16 @@ def test_matmul_f16_mfma(hip):
             A = f16r(a).astype(np.float64).T if ta else f16r(a).astype(np.float64)
             B = f16r(b).astype(np.float64).T if tb else f16r(b).astype(np.float64)
             assert_close(got, (A @ B).astype(np.float32), 1e-5, 'matmul f16 {}x{}x{} ta={} tb={}'.format(m, n, k, ta, tb))
+
+
+def test_convolution_input_beyond_32bit_offsets_is_refused_loudly(hip):
+    """The convolution kernels address their input with 32-bit byte offsets (out-of-range sentinel 2^31): an input of 2^29 or more
+    elements is refused with PVHIP_EUNSUPPORTED before anything is launched -- an error, never a wrapped offset."""
+    import ctypes
+    one = ctypes.c_void_p(256)                       # never dereferenced: the size check comes first
+    for entry in ('pvhip_conv2d_f32', 'pvhip_conv2d_f16'):
+        with pytest.raises(hip.PvhipError, match=r'2\^29'):
+            hip.call(entry, one, one, one, 2048, 64, 128, 32, 64, 3, 3, 128, 32, 1, 1, 1, 1, ctypes.c_void_p(0), 0, 0, 0, 0.0, 0.0)
+    n = ctypes.create_string_buffer(256)
+    hip.call('pvhip_device_name', n, 256)
+    assert n.value.decode().strip()[0] not in '(', n.value      # a marketing name, or the architecture's, in front of the parenthesis
