@@ -17,6 +17,8 @@
 //     i = w & 3 for the 32x32 tile w >> 2.
 //   * Epilogue: the output transform is separable; each wave applies the column half to its own row (registers), the
 //     four rows meet in LDS, then bias / activation / store of 2x2 patches.
+#include <type_traits>
+
 #include "pvhip_common.h"
 #include "pvhip_wino.h"
 
@@ -41,6 +43,7 @@ struct WinoArgs {
     int   act;
     float act_lo, act_hi;
     int   y_ctotal, y_coff;
+    int   balance;          // conv_wino4_kernel: producers placed by SIMD (see the kernel)
 };
 
 // U = G g G^T for one (k, c):  G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]
@@ -431,6 +434,22 @@ __global__ __launch_bounds__(kBlock) void wino25_pack_kernel(const float* __rest
     }
 }
 
+typedef float w4_float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float w4_edge(float e, int) { return e; }
+__device__ __forceinline__ float w4_edge(w4_float2v e, int i) { return e[i]; }
+
+#ifdef PVHIP_DIAG
+// ABL = 5 (diagnostic build): per-wave cycle accounts of every 61st workgroup, [wave][segment]; segment 7 counts the workgroups.
+// consumers: 0 MFMA segment (LDS reads + MFMA issue), 1 wait for the U DMA, 2 barrier;  producers: 0 gather issue, 1 wait for the older
+// gather, 2 transform + LDS writes, 3 barrier.
+__device__ unsigned long long g_w4_stamps[8][8];
+__device__ unsigned g_w4_hw[64][8][2];          // ABL = 5: HW_REG_LDS_ALLOC / HW_REG_HW_ID of the waves of the first 64 workgroups
+__device__ unsigned g_w4_hw_ticket;
+#define PVW4_NOW() ((ABL == 5) ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#else
+#define PVW4_NOW() 0ull
+#endif
+
 // M = 4: F(4x4, 3x3), pad 1.  M = 2: F(2x2, 5x5), pad 2 -- the same six interpolation points, hence the same B^T, the same 36 products
 // per channel and patch (for 4 outputs of a 5x5 window: 9 per output instead of 25) and the same kernel; only the gather geometry (an
 // aligned 8-byte load per row, TWO columns from each neighbour), the weight transform G (6x5) and the output transform A^T (2x6) differ.
@@ -446,10 +465,12 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         float Vs[2][kXi4][kCB][NT];
     };
     __shared__ __attribute__((aligned(1024))) Stage sm;
-    static_assert(sizeof(Stage) == 72 * 1024, "72 KB of LDS: two workgroups per CU");
+    static_assert(sizeof(Stage) == 72 * 1024, "72 KB of LDS (+ 32 bytes of role table): two workgroups per CU");
+    const bool settings_balance = a.balance != 0;
     static_assert(U_PIECES % CONSUMERS == 0, "whole pieces per consumer wave");
     auto& Us = sm.Us;
     auto& Vs = sm.Vs;
+    const unsigned long long t_entry = PVW4_NOW();
 
     const int nwg = gridDim.x;
     int       lid;
@@ -481,13 +502,40 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         const unsigned soff = u_base + (unsigned)(s_) * u_stage_bytes;                                           \
         _Pragma("unroll") for (int q = 0; q < U_PIECES / CONSUMERS; ++q)                                         \
             if (ABL != 4)                                                                                        \
-                wino_dma_b128(ur, &Us[buf_][0][0][0] + (wid + CONSUMERS * q) * 256, u_lane + (unsigned)(wid + CONSUMERS * q) * 1024u, soff); \
+                wino_dma_b128(ur, &Us[buf_][0][0][0] + (row + CONSUMERS * q) * 256, u_lane + (unsigned)(row + CONSUMERS * q) * 1024u, soff); \
+    }
+
+    // ---- roles.  Two workgroups share a CU, and waves w and w + 4 of a workgroup share a SIMD: with fixed roles (producers = waves
+    // 6, 7) two SIMDs carry four consumers (48 MFMAs per stage of both workgroups) and two carry two consumers and two producers (24):
+    // the main loop runs at the pace of the loaded pair (measured with s_memtime stamps: consumers 4, 5 took 2400 cycles for the
+    // MFMAs of a stage, consumers 0-3 1500).  So the producers of a workgroup go on the SIMD pair {0, 1} or {2, 3} by WHICH of the
+    // CU's two LDS slots the workgroup got (HW_REG_LDS_ALLOC.LDS_BASE: co-resident workgroups differ in it by construction): every
+    // SIMD then carries three consumers and one producer.  SIMD ids from HW_REG_HW_ID; if waves 4-7 are not on four different
+    // SIMDs (never seen) the fixed roles are used.
+    __shared__ unsigned simd_of[WAVES];
+    int  row, pidx;                 // consumer: row of the 6x6 transform domain;  producer: which pair of the stage's channels
+    bool producer;
+    {
+        const unsigned sid  = (__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11))) & 3u;           // HW_ID.SIMD_ID = bits [5:4]
+        const unsigned slot = (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11)) != 0u) ? 1u : 0u;   // LDS_ALLOC.LDS_BASE != 0
+        if (lane == 0) simd_of[wid] = sid;
+        __syncthreads();
+        const unsigned s4 = simd_of[4], s5 = simd_of[5], s6 = simd_of[6], s7 = simd_of[7];
+        const bool spread = settings_balance && ((1u << s4) | (1u << s5) | (1u << s6) | (1u << s7)) == 0xFu;
+        if (wid < 4) { producer = false; row = wid; pidx = 0; }
+        else if (spread) { producer = (sid >> 1) == slot; row = 4 + (int)(sid & 1u); pidx = (int)(sid & 1u); }
+        else { producer = wid >= CONSUMERS; row = wid; pidx = wid - CONSUMERS; }
+        producer = __builtin_amdgcn_readfirstlane(producer);
+        row      = __builtin_amdgcn_readfirstlane(row);
+        pidx     = __builtin_amdgcn_readfirstlane(pidx);
     }
 
     floatx16 acc[6];
-    if (wid >= CONSUMERS) {
+    unsigned long long st[4] = {0ull, 0ull, 0ull, 0ull};      // ABL = 5 only
+    unsigned long long t_mid0 = 0ull, t_mid1 = 0ull;
+    if (producer) {
         // ------------------------------------------------------------------ producers
-        const int g_chan = (wid - CONSUMERS) * 2 + lh;                // channel inside the stage
+        const int g_chan = pidx * 2 + lh;                             // channel inside the stage
         // Lane <-> (patch, channel of the stage).  Columns 1..4 of a patch row are ONE aligned 16-byte load (extents are
         // multiples of 4; consecutive lanes = consecutive patches = consecutive 16-byte pieces: fully coalesced).  Column 0 is
         // the left neighbour's column 4 and column 5 the right neighbour's column 1: they come from the adjacent lane by DPP
@@ -520,30 +568,46 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             if (M == 4) eoff = first ? (zlo ? 0u : 0xFFFFFFFCu) : (zhi ? 12u : 16u);
             else        eoff = first ? (zlo ? 0u : 0xFFFFFFF8u) : (zhi ? 0u : 8u);
         }
-        float vA[6][4], vB[6][4];         // M = 2 uses [0..1]
-        float eA[6][2], eB[6][2];         // M = 4 uses [0]
+        // The gathers are asm loads with hand-counted waits: hipcc's own counter tracking merged the loop's states into a
+        // wait for the WHOLE previous gather before the last loads of the next one were issued (vmcnt(10) with 22 in flight),
+        // i.e. one stage in flight instead of two and the memory latency exposed in every stage (DESIGN.md lesson 23).
+        // A gather = 12 loads, always (stages past the end re-read the last one), so "the older gather has landed" is vmcnt(12).
+        using VecT = typename std::conditional<M == 4, float4v, float2v>::type;      // own (inner) columns of a row
+        using EdgT = typename std::conditional<M == 4, float, float2v>::type;        // edge lanes: their outer column(s)
+        VecT vA[6], vB[6];
+        EdgT eA[6], eB[6];
+        unsigned eo[6];                   // edge lanes: offset of the outer column(s) of row r; every other lane: out of range
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            eo[r] = (first || last) ? rowo[r] + eoff : kOob;
+            asm volatile("" : "+v"(eo[r]));
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
 #define PVW4_GATHER(v_, e_, s_)                                                                                  \
     {                                                                                                            \
         const int se_ = (s_) < a.n_stages ? (s_) : a.n_stages - 1;     /* past the end: the last stage again (unused) */ \
         const unsigned soff = (unsigned)(se_ * kCB) * chan_bytes;                                                \
         _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
-            const unsigned eo_ = (first || last) ? rowo[r] + eoff : kOob;                                        \
             if (ABL == 1) {                                                                                      \
-                v_[r][0] = v_[r][1] = v_[r][2] = v_[r][3] = __builtin_bit_cast(float, rowo[r] + soff);           \
-                e_[r][0] = e_[r][1] = 0.0f;                                                                      \
+                v_[r] = __builtin_bit_cast(float, rowo[r] + soff);                                               \
+                e_[r] = 0.0f;                                                                                    \
             } else if (M == 4) {                                                                                 \
-                /* the WHOLE vector is cast: hipcc (ROCm 7.2) lowers a b128 load whose lanes are cast one by one to a dword load */ \
-                const float4v q4 = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(xr, rowo[r], soff, 0)); \
-                v_[r][0] = q4.x; v_[r][1] = q4.y; v_[r][2] = q4.z; v_[r][3] = q4.w;                              \
-                e_[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, eo_, soff, 0));    \
+                asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dword %1, %3, %4, %5 offen" \
+                             : "=&v"(v_[r]), "=&v"(e_[r]) : "v"(rowo[r]), "v"(eo[r]), "s"(xr), "s"(soff));       \
             } else {                                                                                             \
-                const float2v q2 = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(xr, rowo[r], soff, 0)); \
-                const float2v e2 = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(xr, eo_, soff, 0)); \
-                v_[r][0] = q2.x; v_[r][1] = q2.y;                                                                \
-                e_[r][0] = e2.x; e_[r][1] = e2.y;                                                                \
+                asm volatile("buffer_load_dwordx2 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx2 %1, %3, %4, %5 offen" \
+                             : "=&v"(v_[r]), "=&v"(e_[r]) : "v"(rowo[r]), "v"(eo[r]), "s"(xr), "s"(soff));       \
             }                                                                                                    \
         }                                                                                                        \
     }
+        // every register of the set passes through the wait: no use of a loaded value can be scheduled above it
+#define PVW4_LANDED(v_, e_, cnt_)                                                                                \
+    asm volatile("s_waitcnt vmcnt(%12)" : "+v"(v_[0]), "+v"(v_[1]), "+v"(v_[2]), "+v"(v_[3]), "+v"(v_[4]), "+v"(v_[5]), \
+                 "+v"(e_[0]), "+v"(e_[1]), "+v"(e_[2]), "+v"(e_[3]), "+v"(e_[4]), "+v"(e_[5]) : "i"(cnt_))
+#else
+#define PVW4_GATHER(v_, e_, s_) {}
+#define PVW4_LANDED(v_, e_, cnt_) {}
+#endif
 #define PVW4_TRANSFORM_STORE(v_, e_, buf_)                                                                       \
     {                                                                                                            \
         float m[36];                                                                                             \
@@ -555,12 +619,12 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                     float src_ = v_[r][NIN - IN0 + q];   /* opaque FLOAT copy: an integer cast of a loaded element folds back into */ \
                     asm volatile("" : "+v"(src_));        /* "element i of the loaded vector", which hipcc lowers to element 0      */ \
                     const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x138, 0xf, 0xf, false)); \
-                    c[r] = zlo ? 0.0f : (first ? e_[r][q] : nb);                                                 \
+                    c[r] = zlo ? 0.0f : (first ? w4_edge(e_[r], q) : nb);                                                 \
                 } else if (q >= IN0 + NIN) {   /* from the right neighbour's first inner columns (wave_shl:1), own load in the last lane */ \
                     float src_ = v_[r][q - IN0 - NIN];                                                           \
                     asm volatile("" : "+v"(src_));                                                               \
                     const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x130, 0xf, 0xf, false)); \
-                    c[r] = zhi ? 0.0f : (last ? e_[r][q - IN0 - NIN] : nb);                                      \
+                    c[r] = zhi ? 0.0f : (last ? w4_edge(e_[r], q - IN0 - NIN) : nb);                                      \
                 } else {                                                                                         \
                     c[r] = v_[r][q - IN0];                                                                       \
                 }                                                                                                \
@@ -580,27 +644,48 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             Vs[buf_][i * 6 + 5][g_chan][l31] = v5;                                                               \
         }                                                                                                        \
     }
+        t_mid0 = PVW4_NOW();
         PVW4_GATHER(vA, eA, 0);
         PVW4_GATHER(vB, eB, 1);
+        PVW4_LANDED(vA, eA, 12);
+        t_mid1 = PVW4_NOW();
         PVW4_TRANSFORM_STORE(vA, eA, 0);
         __syncthreads();
         // stage s: V(s+1) from the gather issued one stage ago, gather of stage s+2 issued now (two stages in flight)
-        for (int s = 0; s < a.n_stages; s += 2) {
+        int s = 0;
+        for (; s + 1 < a.n_stages; s += 2) {
+            const unsigned long long t0 = PVW4_NOW();
             PVW4_GATHER(vA, eA, s + 2);
-            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t1 = PVW4_NOW();
+            PVW4_LANDED(vB, eB, 12);
+            const unsigned long long t2 = PVW4_NOW();
+            PVW4_TRANSFORM_STORE(vB, eB, 1);
+            const unsigned long long t3 = PVW4_NOW();
+            __syncthreads();
+            const unsigned long long t4 = PVW4_NOW();
+            PVW4_GATHER(vB, eB, s + 3);
+            const unsigned long long u1 = PVW4_NOW();
+            PVW4_LANDED(vA, eA, 12);
+            const unsigned long long u2 = PVW4_NOW();
+            PVW4_TRANSFORM_STORE(vA, eA, 0);
+            const unsigned long long u3 = PVW4_NOW();
+            __syncthreads();
+            const unsigned long long u4 = PVW4_NOW();
+            st[0] += (t1 - t0) + (u1 - t4); st[1] += (t2 - t1) + (u2 - u1); st[2] += (t3 - t2) + (u3 - u2); st[3] += (t4 - t3) + (u4 - u3);
+        }
+        if (s < a.n_stages) {             // odd stage count: the last stage's V (buffer 1) is still to come
+            PVW4_LANDED(vB, eB, 0);
             PVW4_TRANSFORM_STORE(vB, eB, 1);
             __syncthreads();
-            if (s + 1 < a.n_stages) {
-                PVW4_GATHER(vB, eB, s + 3);
-                __builtin_amdgcn_sched_barrier(0);
-                PVW4_TRANSFORM_STORE(vA, eA, 0);
-                __syncthreads();
-            }
         }
+        // nothing may still be on its way into these registers when the epilogue reuses them
+        PVW4_LANDED(vA, eA, 0);
+        PVW4_LANDED(vB, eB, 0);
 #undef PVW4_GATHER
+#undef PVW4_LANDED
 #undef PVW4_TRANSFORM_STORE
     } else {
-        // ------------------------------------------------------------------ consumers: row i = wid of the 6x6 transform domain
+        // ------------------------------------------------------------------ consumers: one row of the 6x6 transform domain each
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -610,24 +695,41 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         __syncthreads();
         for (int s = 0; s < a.n_stages; ++s) {
             const int buf = s & 1;
+            const unsigned long long t0 = PVW4_NOW();
             PVW4_LOAD_U(s + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < kCB / 2; ++kk) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float af = Us[buf][wid * 6 + j][2 * kk + lh][l31];
-                    const float bf = Vs[buf][wid * 6 + j][2 * kk + lh][l31];
+                    const float af = Us[buf][row * 6 + j][2 * kk + lh][l31];
+                    const float bf = Vs[buf][row * 6 + j][2 * kk + lh][l31];
                     if (ABL == 3) acc[j][0] += af * bf;
                     else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t1 = PVW4_NOW();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t2 = PVW4_NOW();
             __syncthreads();
+            const unsigned long long t3 = PVW4_NOW();
+            st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2;
         }
     }
 #undef PVW4_LOAD_U
+#ifdef PVHIP_DIAG
+    if (ABL == 5) {
+        __shared__ unsigned ticket;
+        if (tid == 0) ticket = atomicAdd(&g_w4_hw_ticket, 1u);
+        __syncthreads();
+        if (ticket >= 300u && ticket < 364u && lane == 0) {
+            g_w4_hw[ticket - 300u][wid][0] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11));      // HW_REG_LDS_ALLOC, all 32 bits
+            g_w4_hw[ticket - 300u][wid][1] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        }
+    }
+#endif
+    const unsigned long long t_loops = PVW4_NOW();
 
     // ---- output transform Y = A^T D A (A^T: M x 6): the column half in registers (consumer i holds row i), the rows meet in
     // LDS, CH channels at a time: Ex[i][c'][CH][patch] = 6 * M * CH * 32 floats = 48 KB of the 72 (M = 4: 16 channels, M = 2: 32).
@@ -639,7 +741,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
         if (pass == 1) __syncthreads();
-        if (wid < CONSUMERS) {
+        if (!producer) {
 #pragma unroll
             for (int rr = 0; rr < CH / 2; ++rr) {
                 const int r  = pass * (CH / 2) + rr;                          // accumulator register
@@ -648,7 +750,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                 if (M == 4) wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1], so[2], so[3]);
                 else        wino2_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1]);
 #pragma unroll
-                for (int c2 = 0; c2 < M; ++c2) Ex[((wid * M + c2) * CH + kl) * 32 + l31] = so[c2];
+                for (int c2 = 0; c2 < M; ++c2) Ex[((row * M + c2) * CH + kl) * 32 + l31] = so[c2];
             }
         }
         __syncthreads();
@@ -691,6 +793,18 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             }
         }
     }
+#ifdef PVHIP_DIAG
+    if (ABL == 5 && blockIdx.x % 61 == 7 && lane == 0) {
+        const unsigned long long t_end = PVW4_NOW();
+        const int who = producer ? CONSUMERS + pidx : row;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_w4_stamps[who][i], st[i]);
+        atomicAdd(&g_w4_stamps[who][4], t_loops - t_entry);
+        atomicAdd(&g_w4_stamps[who][5], t_end - t_loops);
+        atomicAdd(&g_w4_stamps[who][6], ((t_mid0 - t_entry) << 32) | ((t_mid1 - t_mid0) & 0xffffffffull));
+        atomicAdd(&g_w4_stamps[who][7], 1ull);
+    }
+#endif
 }
 
 }  // namespace
@@ -810,6 +924,7 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     a.TY = h / m; a.TX = w / m;
     a.T  = n * a.TY * a.TX;
     a.n_kb = (k_out + 31) / 32;
+    a.balance = settings().wino_balance ? 1 : 0;
     a.n_stages = c / kCB;
     a.x_bytes = (unsigned)((size_t)n * c * h * w * 4);
     a.u_bytes = (unsigned)(wino4_pack_elems(k_out, c) * 4);
@@ -828,6 +943,7 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
         case 2: hipLaunchKernelGGL((conv_wino4_kernel<4, 2>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         case 3: hipLaunchKernelGGL((conv_wino4_kernel<4, 3>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         case 4: hipLaunchKernelGGL((conv_wino4_kernel<4, 4>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        case 5: hipLaunchKernelGGL((conv_wino4_kernel<4, 5>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         default: break;
     }
 #endif
@@ -836,3 +952,21 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
 }
 
 }  // namespace pvhip
+
+#ifdef PVHIP_DIAG
+// diagnostic build only: read and clear the cycle accounts of conv_wino4_kernel<4, 5> (PVHIP_WINO4_ABLATE=5); out = 64 counters
+extern "C" int pvhip_diag_wino4_hw(unsigned* out) {          // 64 x 8 x 2 words, and the ticket counter is reset
+    unsigned zero = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_hw), 64 * 8 * 2 * sizeof(unsigned)) != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_hw_ticket), &zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+extern "C" int pvhip_diag_wino4_stamps(unsigned long long* out) {
+    unsigned long long zero[64] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_stamps), sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_stamps), zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+#endif
