@@ -44,6 +44,7 @@ struct WinoArgs {
     float act_lo, act_hi;
     int   y_ctotal, y_coff;
     int   balance;          // conv_wino4_kernel: producers placed by SIMD (see the kernel)
+    int   n_tiles;          // conv_wino4_kernel: channel blocks x patch blocks, walked by a persistent grid
 };
 
 // U = G g G^T for one (k, c):  G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]
@@ -437,6 +438,18 @@ __global__ __launch_bounds__(kBlock) void wino25_pack_kernel(const float* __rest
 typedef float w4_float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float w4_edge(float e, int) { return e; }
 __device__ __forceinline__ float w4_edge(w4_float2v e, int i) { return e[i]; }
+typedef float w4_float4v __attribute__((ext_vector_type(4)));
+// a buffer load as wide as its destination (the WHOLE vector is cast: hipcc (ROCm 7.2) lowers a b128 load whose lanes are cast one
+// by one to a dword load)
+__device__ __forceinline__ void w4_load(w4_float4v& d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    d = __builtin_bit_cast(w4_float4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void w4_load(w4_float2v& d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    d = __builtin_bit_cast(w4_float2v, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void w4_load(float& d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 
 #ifdef PVHIP_DIAG
 // ABL = 5 (diagnostic build): per-wave cycle accounts of every 61st workgroup, [wave][segment]; segment 7 counts the workgroups.
@@ -453,6 +466,12 @@ __device__ unsigned g_w4_hw_ticket;
 // M = 4: F(4x4, 3x3), pad 1.  M = 2: F(2x2, 5x5), pad 2 -- the same six interpolation points, hence the same B^T, the same 36 products
 // per channel and patch (for 4 outputs of a 5x5 window: 9 per output instead of 25) and the same kernel; only the gather geometry (an
 // aligned 8-byte load per row, TWO columns from each neighbour), the weight transform G (6x5) and the output transform A^T (2x6) differ.
+//
+// PERSISTENT: the grid is two workgroups per CU and a workgroup walks tiles (32 output channels x 32 patches) L, L + G, L + 2G, ...
+// The producers' pipeline (gather two stages ahead, transform one stage ahead) runs ACROSS the tile boundary: in the last two stages
+// of a tile they gather stages 0 / 1 of the next tile and transform its stage 0, so that the next tile's main loop starts as soon as
+// the epilogue is over (one workgroup per tile spent 15 k cycles of a 50-110 k cycle life between its first instruction and its first
+// MFMA, and two workgroups per CU cannot cover that for each other: s_memtime stamps, scripts/stamps_wino4.py).
 template <int M, int ABL>   // ABL: diagnostic ablations (wrong results on purpose): 1 no gather, 2 no transform, 3 no MFMA, 4 no U DMA
 __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     static_assert(M == 4 || M == 2, "F(4x4,3x3) or F(2x2,5x5)");
@@ -460,27 +479,28 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     constexpr int KB = 32, NT = 32, WAVES = 8, CONSUMERS = 6;
     constexpr unsigned kOob = 0x80000000u;
     constexpr int U_PIECES = kXi4 * kCB * KB * 4 / 1024;      // 18 one-KiB pieces per U stage image
+    // V0 first: the epilogue's exchange area is Us + the head of V1, and V0 holds stage 0 of the NEXT tile by then
     struct Stage {
+        float V0[kXi4][kCB][NT];
         float Us[2][kXi4][kCB][KB];
-        float Vs[2][kXi4][kCB][NT];
+        float V1[kXi4][kCB][NT];
     };
     __shared__ __attribute__((aligned(1024))) Stage sm;
     static_assert(sizeof(Stage) == 72 * 1024, "72 KB of LDS (+ 32 bytes of role table): two workgroups per CU");
-    const bool settings_balance = a.balance != 0;
     static_assert(U_PIECES % CONSUMERS == 0, "whole pieces per consumer wave");
     auto& Us = sm.Us;
-    auto& Vs = sm.Vs;
     const unsigned long long t_entry = PVW4_NOW();
+    const unsigned long long r_entry = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
 
-    const int nwg = gridDim.x;
-    int       lid;
+    const int G = gridDim.x;
+    int       L;                 // first tile: workgroups of one XCD (blockIdx & 7) take neighbouring tiles (same patches, other channel blocks)
     {
         const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int xcd = bid & 7, q = G >> 3, r = G & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int kb = lid % a.n_kb;
-    const int tb = lid / a.n_kb;
+    const int n_tiles = a.n_tiles;
+    const int n_eff   = a.n_stages + (a.n_stages & 1);       // an odd stage count runs one more stage on the panel's spare zero image
 
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -492,11 +512,12 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
+                                                                        a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
     constexpr unsigned u_stage_bytes = (unsigned)kXi4 * kCB * KB * 4u;
-    const unsigned u_base = (unsigned)(kb * (a.n_stages + 1)) * u_stage_bytes;
     const unsigned u_lane = (unsigned)lane * 16u;
 
-    // the U image of a stage: 18 one-KiB pieces, three per consumer wave (the producers' loop stays free of hand-counted waits)
+    // the U image of a stage: 18 one-KiB pieces, three per consumer wave
 #define PVW4_LOAD_U(s_, buf_)                                                                                   \
     {                                                                                                           \
         const unsigned soff = u_base + (unsigned)(s_) * u_stage_bytes;                                           \
@@ -506,12 +527,10 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     }
 
     // ---- roles.  Two workgroups share a CU, and waves w and w + 4 of a workgroup share a SIMD: with fixed roles (producers = waves
-    // 6, 7) two SIMDs carry four consumers (48 MFMAs per stage of both workgroups) and two carry two consumers and two producers (24):
-    // the main loop runs at the pace of the loaded pair (measured with s_memtime stamps: consumers 4, 5 took 2400 cycles for the
-    // MFMAs of a stage, consumers 0-3 1500).  So the producers of a workgroup go on the SIMD pair {0, 1} or {2, 3} by WHICH of the
-    // CU's two LDS slots the workgroup got (HW_REG_LDS_ALLOC.LDS_BASE: co-resident workgroups differ in it by construction): every
-    // SIMD then carries three consumers and one producer.  SIMD ids from HW_REG_HW_ID; if waves 4-7 are not on four different
-    // SIMDs (never seen) the fixed roles are used.
+    // 6, 7) two SIMDs carry four consumers (48 MFMAs per stage of both workgroups) and two carry two consumers and two producers (24).
+    // So the producers of a workgroup go on the SIMD pair {0, 1} or {2, 3} by WHICH of the CU's two LDS slots the workgroup got
+    // (HW_REG_LDS_ALLOC.LDS_BASE: co-resident workgroups differ in it by construction): every SIMD then carries three consumers and
+    // one producer.  SIMD ids from HW_REG_HW_ID; if waves 4-7 are not on four different SIMDs (never seen) the fixed roles are used.
     __shared__ unsigned simd_of[WAVES];
     int  row, pidx;                 // consumer: row of the 6x6 transform domain;  producer: which pair of the stage's channels
     bool producer;
@@ -521,7 +540,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         if (lane == 0) simd_of[wid] = sid;
         __syncthreads();
         const unsigned s4 = simd_of[4], s5 = simd_of[5], s6 = simd_of[6], s7 = simd_of[7];
-        const bool spread = settings_balance && ((1u << s4) | (1u << s5) | (1u << s6) | (1u << s7)) == 0xFu;
+        const bool spread = a.balance != 0 && ((1u << s4) | (1u << s5) | (1u << s6) | (1u << s7)) == 0xFu;
         if (wid < 4) { producer = false; row = wid; pidx = 0; }
         else if (spread) { producer = (sid >> 1) == slot; row = 4 + (int)(sid & 1u); pidx = (int)(sid & 1u); }
         else { producer = wid >= CONSUMERS; row = wid; pidx = wid - CONSUMERS; }
@@ -530,9 +549,76 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         pidx     = __builtin_amdgcn_readfirstlane(pidx);
     }
 
-    floatx16 acc[6];
+    // ---- output transform Y = A^T D A (A^T: M x 6) of one tile: the column half in registers (consumer i holds row i), the rows meet
+    // in LDS, CH channels at a time: Ex[i][CH][patch][c'] = 6 * CH * 32 * M floats = 48 KB (M = 4: 16 channels, M = 2: 32) = Us and
+    // the head of V1; every wave takes part in the second half.  Both roles carry a copy (the registers live across it differ).
+    constexpr int CH = (M == 4) ? 16 : 32, PASSES = 32 / CH;
+    float* const Ex = &Us[0][0][0][0];
+    const int OH = a.H, OW = a.W;
+    typedef float exv_t __attribute__((ext_vector_type(M)));      // the M column outputs of a (row, channel, patch): one LDS access
+#define PVW4_EPI_WRITE(pass)                                                                                     \
+    {                                                                                                            \
+        _Pragma("unroll") for (int rr = 0; rr < CH / 2; ++rr) {                                                  \
+            const int r  = pass * (CH / 2) + rr;                          /* accumulator register */              \
+            const int kl = (rr & 3) + 8 * (rr >> 2) + 4 * lh;             /* channel inside the pass: 0 .. CH-1 */ \
+            float so[4];                                                                                         \
+            if (M == 4) wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1], so[2], so[3]); \
+            else        wino2_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1]); \
+            exv_t sv;                                                                                            \
+            _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) sv[c2] = so[c2];                                    \
+            *reinterpret_cast<exv_t*>(Ex + ((row * CH + kl) * 32 + l31) * M) = sv;                               \
+        }                                                                                                        \
+    }
+#define PVW4_EPI_NOWRITE(pass) {}
+#define PVW4_EPILOGUE(WRITE_, tile_)                                                                             \
+    {                                                                                                            \
+        const int kb_e = (tile_) % a.n_kb, tb_e = (tile_) / a.n_kb;                                              \
+        const int tl = tid & 31;                                                  /* 512 threads = 16 channels x 32 patches per sweep */ \
+        const int t  = tb_e * NT + tl;                                                                           \
+        const int tc = t < a.T ? t : 0;                                                                          \
+        const int n_ = tc / TPI, rem_ = tc - n_ * TPI;                                                           \
+        const int ty_ = rem_ / a.TX, tx_ = rem_ - ty_ * a.TX;                                                    \
+        float* __restrict__ const yp0 = a.y + (((size_t)n_ * a.y_ctotal + a.y_coff) * OH + M * ty_) * OW + M * tx_; \
+        _Pragma("unroll") for (int pass = 0; pass < PASSES; ++pass) {                                            \
+            if (pass == 1) __syncthreads();                                                                      \
+            WRITE_(pass);                                                                                        \
+            __syncthreads();                                                                                     \
+            _Pragma("unroll") for (int sweep = 0; sweep < CH / 16; ++sweep) {                                    \
+                const int kl = (tid >> 5) + 16 * sweep;                                                          \
+                const int kg = kb_e * KB + pass * CH + kl;                                                       \
+                if (t < a.T && kg < a.K) {                                                                       \
+                    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)kg * 4u, 0, 0)); \
+                    float* __restrict__ yp = yp0 + (size_t)kg * (OH * OW);                                       \
+                    exv_t ev[6];                                                                                 \
+                    _Pragma("unroll") for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(Ex + ((i * CH + kl) * 32 + tl) * M); \
+                    float yv[M][M];                                                                              \
+                    _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) {                                           \
+                        float col[4];                                                                            \
+                        if (M == 4) wino4_at(ev[0][c2], ev[1][c2], ev[2][c2], ev[3][c2], ev[4][c2], ev[5][c2], col[0], col[1], col[2], col[3]); \
+                        else        wino2_at(ev[0][c2], ev[1][c2], ev[2][c2], ev[3][c2], ev[4][c2], ev[5][c2], col[0], col[1]); \
+                        _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) yv[r2][c2] = col[r2];                   \
+                    }                                                                                            \
+                    _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) {                                           \
+                        float ov[M];                                                                             \
+                        _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) {                                       \
+                            float v = yv[r2][c2];                                                                \
+                            if (a.bias != nullptr) v = v + bv;                                                   \
+                            if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;                                           \
+                            else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; } \
+                            ov[c2] = v;                                                                          \
+                        }                                                                                        \
+                        if (M == 4) *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = make_float4(ov[0], ov[1], ov[2], ov[3]); \
+                        else        *reinterpret_cast<float2*>(yp + (size_t)r2 * OW) = make_float2(ov[0], ov[1]); \
+                    }                                                                                            \
+                }                                                                                                \
+            }                                                                                                    \
+        }                                                                                                        \
+        __syncthreads();      /* the exchange area is read out: the next tile's U image may land in it */          \
+    }
+
     unsigned long long st[4] = {0ull, 0ull, 0ull, 0ull};      // ABL = 5 only
-    unsigned long long t_mid0 = 0ull, t_mid1 = 0ull;
+    unsigned long long t_epi = 0ull, t_head = 0ull;
+    (void)t_epi; (void)t_head;
     if (producer) {
         // ------------------------------------------------------------------ producers
         const int g_chan = pidx * 2 + lh;                             // channel inside the stage
@@ -543,72 +629,64 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         // and the last lane of a 32-patch row load their outer column themselves (one more dword load per row, two active
         // lanes per half).  A row in the padding gets an out-of-range offset (the hardware returns 0); columns in the
         // padding (first / last patch column) are zeroed by select.
-        typedef float float4v __attribute__((ext_vector_type(4)));
-        typedef float float2v __attribute__((ext_vector_type(2)));
+        typedef w4_float4v float4v;
+        typedef w4_float2v float2v;
         unsigned rowo[6];                 // byte offset of (row, first inner column) of this lane's channel
-        unsigned eoff;                    // edge lanes: byte distance of their outer column(s) from the first inner column
-        bool     zlo, zhi;
+        unsigned eo[6];                   // edge lanes: offset of the outer column(s) of row r; every other lane: out of range
+        bool     zlo, zhi, zlo_n, zhi_n;
         const bool first = l31 == 0, last = l31 == 31;
-        {
-            const int  t    = tb * NT + l31;
-            const bool live = t < a.T;
-            const int  n = live ? t / TPI : 0, rem = live ? t - n * TPI : 0;
-            const int  ty = rem / a.TX, tx = rem - ty * a.TX;
-            const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + M * tx) * 4u;
-            zlo = tx == 0;
-            zhi = tx == a.TX - 1;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const int iy = M * ty - PAD + r;
-                rowo[r] = (live && (unsigned)iy < (unsigned)a.H) ? base + (unsigned)(iy * a.W) * 4u : kOob + 16u;
-            }
-            // M = 4: inner columns 1..4 are the lane's own 16 bytes; first lane: column 0 (4 bytes before; on the left border the
-            // value is zeroed anyway: stay in place); last lane: column 5 (16 bytes after; on the right border: 12).
-            // M = 2: inner columns 2..3 are the lane's own 8 bytes; first lane: columns 0..1 (8 bytes before), last: 4..5 (8 after).
-            if (M == 4) eoff = first ? (zlo ? 0u : 0xFFFFFFFCu) : (zhi ? 12u : 16u);
-            else        eoff = first ? (zlo ? 0u : 0xFFFFFFF8u) : (zhi ? 0u : 8u);
-        }
-        // The gathers are asm loads with hand-counted waits: hipcc's own counter tracking merged the loop's states into a
-        // wait for the WHOLE previous gather before the last loads of the next one were issued (vmcnt(10) with 22 in flight),
-        // i.e. one stage in flight instead of two and the memory latency exposed in every stage (DESIGN.md lesson 23).
-        // A gather = 12 loads, always (stages past the end re-read the last one), so "the older gather has landed" is vmcnt(12).
+        // addresses of a tile's patches (a tile past the end: every row out of range -- zeros, no traffic)
+#define PVW4_ADDRESSES(tile_, zl_, zh_)                                                                          \
+    {                                                                                                            \
+        const int  t    = ((tile_) / a.n_kb) * NT + l31;                                                         \
+        const bool live = (tile_) < n_tiles && t < a.T;                                                          \
+        const int  n = live ? t / TPI : 0, rem = live ? t - n * TPI : 0;                                         \
+        const int  ty = rem / a.TX, tx = rem - ty * a.TX;                                                        \
+        const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + M * tx) * 4u;                              \
+        zl_ = tx == 0;                                                                                           \
+        zh_ = tx == a.TX - 1;                                                                                    \
+        /* M = 4: inner columns 1..4 are the lane's own 16 bytes; first lane: column 0 (4 bytes before; on the left border the */ \
+        /* value is zeroed anyway: stay in place); last lane: column 5 (16 bytes after; on the right border: 12).               */ \
+        /* M = 2: inner columns 2..3 are the lane's own 8 bytes; first lane: columns 0..1 (8 bytes before), last: 4..5 (8 after). */ \
+        unsigned eoff;                                                                                           \
+        if (M == 4) eoff = first ? (zl_ ? 0u : 0xFFFFFFFCu) : (zh_ ? 12u : 16u);                                 \
+        else        eoff = first ? (zl_ ? 0u : 0xFFFFFFF8u) : (zh_ ? 0u : 8u);                                   \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
+            const int iy = M * ty - PAD + r;                                                                     \
+            rowo[r] = (live && (unsigned)iy < (unsigned)a.H) ? base + (unsigned)(iy * a.W) * 4u : kOob + 16u;    \
+            eo[r]   = (first || last) ? rowo[r] + eoff : kOob;                                                   \
+            asm volatile("" : "+v"(rowo[r]), "+v"(eo[r]));                                                       \
+        }                                                                                                        \
+    }
+        // A gather = 12 loads; its row / edge offsets are loop invariants held in registers: with address temporaries inside the loop
+        // (the first version) hipcc reused a temporary's register as a load destination and put a wait for the WHOLE previous gather
+        // in front of the last loads of the next one -- one stage in flight instead of two (DESIGN.md lesson 23).
         using VecT = typename std::conditional<M == 4, float4v, float2v>::type;      // own (inner) columns of a row
         using EdgT = typename std::conditional<M == 4, float, float2v>::type;        // edge lanes: their outer column(s)
         VecT vA[6], vB[6];
         EdgT eA[6], eB[6];
-        unsigned eo[6];                   // edge lanes: offset of the outer column(s) of row r; every other lane: out of range
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            eo[r] = (first || last) ? rowo[r] + eoff : kOob;
-            asm volatile("" : "+v"(eo[r]));
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
+        // Compiler-tracked loads ON PURPOSE.  Asm loads with hand-counted vmcnt waits were 0-2 % faster, but hipcc is free to COPY
+        // a register between the asm that issues a load into it and the asm that waits for it -- it did, in the F(2x2,5x5)
+        // instantiation (different physical registers for the same patch in the steady loop and in the tile-boundary code) -- and the
+        // copy reads whatever the register held: wrong results whenever the load is slow, i.e. only with other kernels running
+        // beside this one (DESIGN.md lesson 24).  With the edge offsets precomputed (no address temporaries in the loop) hipcc's own
+        // waits come out where they belong: vmcnt(12) .. after the twelve loads of the next gather.
 #define PVW4_GATHER(v_, e_, s_)                                                                                  \
     {                                                                                                            \
-        const int se_ = (s_) < a.n_stages ? (s_) : a.n_stages - 1;     /* past the end: the last stage again (unused) */ \
+        const int se_ = (s_) < a.n_stages ? (s_) : a.n_stages - 1;     /* the padding stage: the last one again (its U is zero) */ \
         const unsigned soff = (unsigned)(se_ * kCB) * chan_bytes;                                                \
         _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
             if (ABL == 1) {                                                                                      \
                 v_[r] = __builtin_bit_cast(float, rowo[r] + soff);                                               \
                 e_[r] = 0.0f;                                                                                    \
-            } else if (M == 4) {                                                                                 \
-                asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dword %1, %3, %4, %5 offen" \
-                             : "=&v"(v_[r]), "=&v"(e_[r]) : "v"(rowo[r]), "v"(eo[r]), "s"(xr), "s"(soff));       \
             } else {                                                                                             \
-                asm volatile("buffer_load_dwordx2 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx2 %1, %3, %4, %5 offen" \
-                             : "=&v"(v_[r]), "=&v"(e_[r]) : "v"(rowo[r]), "v"(eo[r]), "s"(xr), "s"(soff));       \
+                w4_load(v_[r], xr, rowo[r], soff);                                                               \
+                w4_load(e_[r], xr, eo[r], soff);                                                                 \
             }                                                                                                    \
         }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
     }
-        // every register of the set passes through the wait: no use of a loaded value can be scheduled above it
-#define PVW4_LANDED(v_, e_, cnt_)                                                                                \
-    asm volatile("s_waitcnt vmcnt(%12)" : "+v"(v_[0]), "+v"(v_[1]), "+v"(v_[2]), "+v"(v_[3]), "+v"(v_[4]), "+v"(v_[5]), \
-                 "+v"(e_[0]), "+v"(e_[1]), "+v"(e_[2]), "+v"(e_[3]), "+v"(e_[4]), "+v"(e_[5]) : "i"(cnt_))
-#else
-#define PVW4_GATHER(v_, e_, s_) {}
-#define PVW4_LANDED(v_, e_, cnt_) {}
-#endif
-#define PVW4_TRANSFORM_STORE(v_, e_, buf_)                                                                       \
+#define PVW4_TRANSFORM_STORE(v_, e_, Vb_, zl_, zh_)                                                              \
     {                                                                                                            \
         float m[36];                                                                                             \
         _Pragma("unroll") for (int q = 0; q < 6; ++q) {                 /* columns: m = B^T d */                  \
@@ -619,12 +697,12 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                     float src_ = v_[r][NIN - IN0 + q];   /* opaque FLOAT copy: an integer cast of a loaded element folds back into */ \
                     asm volatile("" : "+v"(src_));        /* "element i of the loaded vector", which hipcc lowers to element 0      */ \
                     const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x138, 0xf, 0xf, false)); \
-                    c[r] = zlo ? 0.0f : (first ? w4_edge(e_[r], q) : nb);                                                 \
+                    c[r] = zl_ ? 0.0f : (first ? w4_edge(e_[r], q) : nb);                                        \
                 } else if (q >= IN0 + NIN) {   /* from the right neighbour's first inner columns (wave_shl:1), own load in the last lane */ \
                     float src_ = v_[r][q - IN0 - NIN];                                                           \
                     asm volatile("" : "+v"(src_));                                                               \
                     const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x130, 0xf, 0xf, false)); \
-                    c[r] = zhi ? 0.0f : (last ? w4_edge(e_[r], q - IN0 - NIN) : nb);                                      \
+                    c[r] = zh_ ? 0.0f : (last ? w4_edge(e_[r], q - IN0 - NIN) : nb);                             \
                 } else {                                                                                         \
                     c[r] = v_[r][q - IN0];                                                                       \
                 }                                                                                                \
@@ -636,172 +714,117 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             float v0, v1, v2, v3, v4, v5;                                                                        \
             if (ABL == 2) { v0 = m[i * 6 + 0]; v1 = m[i * 6 + 1]; v2 = m[i * 6 + 2]; v3 = m[i * 6 + 3]; v4 = m[i * 6 + 4]; v5 = m[i * 6 + 5]; } \
             else wino4_bt(m[i * 6 + 0], m[i * 6 + 1], m[i * 6 + 2], m[i * 6 + 3], m[i * 6 + 4], m[i * 6 + 5], v0, v1, v2, v3, v4, v5); \
-            Vs[buf_][i * 6 + 0][g_chan][l31] = v0;                                                               \
-            Vs[buf_][i * 6 + 1][g_chan][l31] = v1;                                                               \
-            Vs[buf_][i * 6 + 2][g_chan][l31] = v2;                                                               \
-            Vs[buf_][i * 6 + 3][g_chan][l31] = v3;                                                               \
-            Vs[buf_][i * 6 + 4][g_chan][l31] = v4;                                                               \
-            Vs[buf_][i * 6 + 5][g_chan][l31] = v5;                                                               \
+            Vb_[i * 6 + 0][g_chan][l31] = v0;                                                                    \
+            Vb_[i * 6 + 1][g_chan][l31] = v1;                                                                    \
+            Vb_[i * 6 + 2][g_chan][l31] = v2;                                                                    \
+            Vb_[i * 6 + 3][g_chan][l31] = v3;                                                                    \
+            Vb_[i * 6 + 4][g_chan][l31] = v4;                                                                    \
+            Vb_[i * 6 + 5][g_chan][l31] = v5;                                                                    \
         }                                                                                                        \
     }
-        t_mid0 = PVW4_NOW();
+        int tile = L;
+        PVW4_ADDRESSES(tile, zlo, zhi);
         PVW4_GATHER(vA, eA, 0);
         PVW4_GATHER(vB, eB, 1);
-        PVW4_LANDED(vA, eA, 12);
-        t_mid1 = PVW4_NOW();
-        PVW4_TRANSFORM_STORE(vA, eA, 0);
-        __syncthreads();
-        // stage s: V(s+1) from the gather issued one stage ago, gather of stage s+2 issued now (two stages in flight)
-        int s = 0;
-        for (; s + 1 < a.n_stages; s += 2) {
-            const unsigned long long t0 = PVW4_NOW();
-            PVW4_GATHER(vA, eA, s + 2);
-            const unsigned long long t1 = PVW4_NOW();
-            PVW4_LANDED(vB, eB, 12);
-            const unsigned long long t2 = PVW4_NOW();
-            PVW4_TRANSFORM_STORE(vB, eB, 1);
-            const unsigned long long t3 = PVW4_NOW();
+        PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo, zhi);
+        t_head = PVW4_NOW() - t_entry;
+        for (;;) {
+            __syncthreads();              // V(0) of this tile is in V0 (and the consumers' U(0) has landed)
+            // stage s: V(s+1) from the gather issued one stage ago, gather of stage s+2 issued now (two stages in flight)
+            for (int s = 0; s + 2 < n_eff; s += 2) {
+                const unsigned long long t0 = PVW4_NOW();
+                PVW4_GATHER(vA, eA, s + 2);
+                const unsigned long long t1 = PVW4_NOW();
+                const unsigned long long t2 = PVW4_NOW();
+                PVW4_TRANSFORM_STORE(vB, eB, sm.V1, zlo, zhi);
+                const unsigned long long t3 = PVW4_NOW();
+                __syncthreads();
+                const unsigned long long t4 = PVW4_NOW();
+                PVW4_GATHER(vB, eB, s + 3);
+                const unsigned long long u1 = PVW4_NOW();
+                const unsigned long long u2 = PVW4_NOW();
+                PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo, zhi);
+                const unsigned long long u3 = PVW4_NOW();
+                __syncthreads();
+                const unsigned long long u4 = PVW4_NOW();
+                st[0] += (t1 - t0) + (u1 - t4); st[1] += (t2 - t1) + (u2 - u1); st[2] += (t3 - t2) + (u3 - u2); st[3] += (t4 - t3) + (u4 - u3);
+            }
+            // the last two stages: the gathers are stages 0 / 1 of the NEXT tile, and the second transform its stage 0
+            PVW4_ADDRESSES(tile + G, zlo_n, zhi_n);
+            PVW4_GATHER(vA, eA, 0);
+            PVW4_TRANSFORM_STORE(vB, eB, sm.V1, zlo, zhi);
             __syncthreads();
-            const unsigned long long t4 = PVW4_NOW();
-            PVW4_GATHER(vB, eB, s + 3);
-            const unsigned long long u1 = PVW4_NOW();
-            PVW4_LANDED(vA, eA, 12);
-            const unsigned long long u2 = PVW4_NOW();
-            PVW4_TRANSFORM_STORE(vA, eA, 0);
-            const unsigned long long u3 = PVW4_NOW();
+            PVW4_GATHER(vB, eB, 1);
+            PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo_n, zhi_n);
             __syncthreads();
-            const unsigned long long u4 = PVW4_NOW();
-            st[0] += (t1 - t0) + (u1 - t4); st[1] += (t2 - t1) + (u2 - u1); st[2] += (t3 - t2) + (u3 - u2); st[3] += (t4 - t3) + (u4 - u3);
+            zlo = zlo_n;
+            zhi = zhi_n;
+            const unsigned long long e0 = PVW4_NOW();
+            PVW4_EPILOGUE(PVW4_EPI_NOWRITE, tile);
+            t_epi += PVW4_NOW() - e0;
+            tile += G;
+            if (tile >= n_tiles) break;
         }
-        if (s < a.n_stages) {             // odd stage count: the last stage's V (buffer 1) is still to come
-            PVW4_LANDED(vB, eB, 0);
-            PVW4_TRANSFORM_STORE(vB, eB, 1);
-            __syncthreads();
-        }
-        // nothing may still be on its way into these registers when the epilogue reuses them
-        PVW4_LANDED(vA, eA, 0);
-        PVW4_LANDED(vB, eB, 0);
+#undef PVW4_ADDRESSES
 #undef PVW4_GATHER
-#undef PVW4_LANDED
 #undef PVW4_TRANSFORM_STORE
     } else {
         // ------------------------------------------------------------------ consumers: one row of the 6x6 transform domain each
+        floatx16 acc[6];
+        for (int tile = L; tile < n_tiles; tile += G) {
+            const unsigned long long h0 = PVW4_NOW();
+            const unsigned u_base = (unsigned)((tile % a.n_kb) * (a.n_stages + 1)) * u_stage_bytes;
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+            for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-        PVW4_LOAD_U(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int s = 0; s < a.n_stages; ++s) {
-            const int buf = s & 1;
-            const unsigned long long t0 = PVW4_NOW();
-            PVW4_LOAD_U(s + 1, buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < kCB / 2; ++kk) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const float af = Us[buf][row * 6 + j][2 * kk + lh][l31];
-                    const float bf = Vs[buf][row * 6 + j][2 * kk + lh][l31];
-                    if (ABL == 3) acc[j][0] += af * bf;
-                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long t1 = PVW4_NOW();
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            PVW4_LOAD_U(0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long t2 = PVW4_NOW();
             __syncthreads();
-            const unsigned long long t3 = PVW4_NOW();
-            st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2;
+            t_head += PVW4_NOW() - h0;
+            for (int s = 0; s < n_eff; ++s) {
+                const int buf = s & 1;
+                const unsigned long long t0 = PVW4_NOW();
+                if (s + 1 < n_eff) PVW4_LOAD_U(s + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const float* vb = buf ? &sm.V1[0][0][0] : &sm.V0[0][0][0];
+#pragma unroll
+                for (int kk = 0; kk < kCB / 2; ++kk) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const float af = Us[buf][row * 6 + j][2 * kk + lh][l31];
+                        const float bf = vb[((row * 6 + j) * kCB + 2 * kk + lh) * NT + l31];
+                        if (ABL == 3) acc[j][0] += af * bf;
+                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t1 = PVW4_NOW();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t2 = PVW4_NOW();
+                __syncthreads();
+                const unsigned long long t3 = PVW4_NOW();
+                st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2;
+            }
+            const unsigned long long e0 = PVW4_NOW();
+            PVW4_EPILOGUE(PVW4_EPI_WRITE, tile);
+            t_epi += PVW4_NOW() - e0;
         }
     }
 #undef PVW4_LOAD_U
-#ifdef PVHIP_DIAG
-    if (ABL == 5) {
-        __shared__ unsigned ticket;
-        if (tid == 0) ticket = atomicAdd(&g_w4_hw_ticket, 1u);
-        __syncthreads();
-        if (ticket >= 300u && ticket < 364u && lane == 0) {
-            g_w4_hw[ticket - 300u][wid][0] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11));      // HW_REG_LDS_ALLOC, all 32 bits
-            g_w4_hw[ticket - 300u][wid][1] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-        }
-    }
-#endif
-    const unsigned long long t_loops = PVW4_NOW();
-
-    // ---- output transform Y = A^T D A (A^T: M x 6): the column half in registers (consumer i holds row i), the rows meet in
-    // LDS, CH channels at a time: Ex[i][c'][CH][patch] = 6 * M * CH * 32 floats = 48 KB of the 72 (M = 4: 16 channels, M = 2: 32).
-    constexpr int CH = (M == 4) ? 16 : 32, PASSES = 32 / CH;
-    float* Ex = &Us[0][0][0][0];
-    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
-                                                                        a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
-    const int OH = a.H, OW = a.W;
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        if (pass == 1) __syncthreads();
-        if (!producer) {
-#pragma unroll
-            for (int rr = 0; rr < CH / 2; ++rr) {
-                const int r  = pass * (CH / 2) + rr;                          // accumulator register
-                const int kl = (rr & 3) + 8 * (rr >> 2) + 4 * lh;             // channel inside the pass: 0 .. CH-1
-                float so[4];
-                if (M == 4) wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1], so[2], so[3]);
-                else        wino2_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1]);
-#pragma unroll
-                for (int c2 = 0; c2 < M; ++c2) Ex[((row * M + c2) * CH + kl) * 32 + l31] = so[c2];
-            }
-        }
-        __syncthreads();
-        const int tl = tid & 31;                                              // 512 threads = 16 channels x 32 patches per sweep
-        const int t  = tb * NT + tl;
-#pragma unroll
-        for (int sweep = 0; sweep < CH / 16; ++sweep) {
-            const int kl = (tid >> 5) + 16 * sweep;
-            const int kg = kb * KB + pass * CH + kl;
-            if (t < a.T && kg < a.K) {
-                const int n = t / TPI, rem = t - n * TPI;
-                const int ty = rem / a.TX, tx = rem - ty * a.TX;
-                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)kg * 4u, 0, 0));
-                float* __restrict__ yp = a.y + (((size_t)n * a.y_ctotal + a.y_coff + kg) * OH + M * ty) * OW + M * tx;
-                float yv[M][M];
-#pragma unroll
-                for (int c2 = 0; c2 < M; ++c2) {
-                    float e[6], col[4];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) e[i] = Ex[((i * M + c2) * CH + kl) * 32 + tl];
-                    if (M == 4) wino4_at(e[0], e[1], e[2], e[3], e[4], e[5], col[0], col[1], col[2], col[3]);
-                    else        wino2_at(e[0], e[1], e[2], e[3], e[4], e[5], col[0], col[1]);
-#pragma unroll
-                    for (int r2 = 0; r2 < M; ++r2) yv[r2][c2] = col[r2];
-                }
-#pragma unroll
-                for (int r2 = 0; r2 < M; ++r2) {
-                    float ov[M];
-#pragma unroll
-                    for (int c2 = 0; c2 < M; ++c2) {
-                        float v = yv[r2][c2];
-                        if (a.bias != nullptr) v = v + bv;
-                        if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;
-                        else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
-                        ov[c2] = v;
-                    }
-                    if (M == 4) *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-                    else        *reinterpret_cast<float2*>(yp + (size_t)r2 * OW) = make_float2(ov[0], ov[1]);
-                }
-            }
-        }
-    }
+#undef PVW4_EPILOGUE
+#undef PVW4_EPI_WRITE
+#undef PVW4_EPI_NOWRITE
 #ifdef PVHIP_DIAG
     if (ABL == 5 && blockIdx.x % 61 == 7 && lane == 0) {
         const unsigned long long t_end = PVW4_NOW();
         const int who = producer ? CONSUMERS + pidx : row;
 #pragma unroll
         for (int i = 0; i < 4; ++i) atomicAdd(&g_w4_stamps[who][i], st[i]);
-        atomicAdd(&g_w4_stamps[who][4], t_loops - t_entry);
-        atomicAdd(&g_w4_stamps[who][5], t_end - t_loops);
-        atomicAdd(&g_w4_stamps[who][6], ((t_mid0 - t_entry) << 32) | ((t_mid1 - t_mid0) & 0xffffffffull));
+        atomicAdd(&g_w4_stamps[who][4], t_end - t_entry);      // the workgroup's life
+        atomicAdd(&g_w4_stamps[who][5], t_epi);                // in epilogues
+        atomicAdd(&g_w4_stamps[who][6], t_head);
+        atomicAdd(&g_w4_stamps[who][3], producer ? 0ull : (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_entry));   // consumers: life in 10 ns ticks               // consumers: tile heads (zero, U(0), first barrier); producers: before the first tile
         atomicAdd(&g_w4_stamps[who][7], 1ull);
     }
 #endif
@@ -931,8 +954,10 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
     const long n_tb = ((long)a.T + 31) / 32;
-    if (n_tb * a.n_kb > 0x7fffffffL) return fail(PVHIP_EUNSUPPORTED, "wino4_conv: grid too large");
-    const dim3 grid((unsigned)(n_tb * a.n_kb));
+    if (n_tb * a.n_kb > 0x3fffffffL) return fail(PVHIP_EUNSUPPORTED, "wino4_conv: too many tiles");
+    a.n_tiles = (int)(n_tb * a.n_kb);
+    // persistent: two workgroups per CU (72 KB of LDS each), each walking tiles L, L + G, ...
+    const dim3 grid((unsigned)(a.n_tiles < 2 * kNumCU ? a.n_tiles : 2 * kNumCU));
     if (m == 2) {
         hipLaunchKernelGGL((conv_wino4_kernel<2, 0>), grid, dim3(512), 0, state().stream, a);
         return PVHIP_OK;

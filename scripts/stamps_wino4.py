@@ -55,18 +55,17 @@ for name, xs, k in LAYERS:
                     [int(v) & 15 for v in hw[k_, :, 1]]))
         if abl == '5':
             stages = c // 4
+            tiles = ((n * (h // 4) * (w // 4) + 31) // 32) * ((k + 31) // 32)
+            per_wg = tiles / min(tiles, 512)
             for wv in range(8):
                 cnt = st[wv, 7]
                 if cnt == 0:
                     continue
-                per = st[wv, :4] / cnt / stages
-                whole = st[wv, 4:6] / cnt
-                tail_ = '   || per workgroup: prologue {:6.0f}  main loop {:7.0f}  epilogue {:6.0f}'.format(
-                    whole[0] - st[wv, :4].sum() / cnt, st[wv, :4].sum() / cnt, whole[1])
+                per = st[wv, :4] / cnt / stages / per_wg
+                life, epi, head = st[wv, 4] / cnt, st[wv, 5] / cnt, st[wv, 6] / cnt
                 if wv < 6:
-                    print('  consumer {}: per stage  MFMA segment {:7.0f}  U wait {:6.0f}  barrier {:6.0f}  | total {:7.0f} cycles  ({} workgroups)'.format(
-                        wv, per[0], per[1], per[2], per[:3].sum(), int(cnt)) + tail_)
+                    print('  consumer {}: per stage  MFMA segment {:5.0f}  U wait {:4.0f}  barrier {:5.0f} | per tile: head {:6.0f}  main loop {:7.0f}  epilogue {:6.0f} | life {:8.0f} cycles = {:.1f} us: {:.2f} GHz, {:.1f} tiles'.format(
+                        wv, per[0], per[1], per[2], head / per_wg, st[wv, :3].sum() / cnt / per_wg, epi / per_wg, life, st[wv, 3] / cnt / 100.0, life / max(1.0, st[wv, 3] / cnt) / 10.0, per_wg))
                 else:
-                    tail_ += '  (prologue: entry -> first gather {:.0f}, -> landed {:.0f})'.format((int(out[wv * 8 + 6]) >> 32) / cnt, (int(out[wv * 8 + 6]) & 0xffffffff) / cnt)
-                    print('  producer {}: per stage  gather issue {:6.0f}  gather wait {:6.0f}  transform+store {:6.0f}  barrier {:6.0f}  | total {:7.0f}'.format(
-                        wv, per[0], per[1], per[2], per[3], per.sum()) + tail_)
+                    print('  producer {}: per stage (all but the last two of a tile)  gather issue {:4.0f}  gather wait {:4.0f}  transform+store {:5.0f}  barrier {:5.0f} | before the first tile {:6.0f}  epilogues per tile {:6.0f} | life {:8.0f}'.format(
+                        wv - 6, per[0] * stages / max(1, stages - 2), per[1] * stages / max(1, stages - 2), per[2] * stages / max(1, stages - 2), per[3] * stages / max(1, stages - 2), head, epi / per_wg, life))

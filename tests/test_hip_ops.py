@@ -172,6 +172,40 @@ def test_conv_winograd_stress_elementwise(hip, monkeypatch, form):
         assert excess <= 0.5, '{} {}: only {:.2f} x inside the element-wise bound'.format(form, xs, 1.0 / max(excess, 1e-9))
 
 
+def test_convolution_kernels_side_by_side_on_several_streams_at_batch_256(hip):
+    """Batch 256 makes a persistent workgroup of the six-point Winograd kernel walk several tiles (the small cases above stop at
+    one), and four streams make the loads slow: a register copied while a load was still on its way into it gave wrong results
+    ONLY in this setting.  Every layer, launched next to the others three times over, must give the bits it gives alone."""
+    from pyopenvino_amd import device as dev, synth
+    from pyopenvino_amd.op_plugins import Convolution as conv
+    layers = [((256, 16, 28, 28), 64, 3), ((256, 32, 28, 28), 96, 5), ((256, 16, 14, 14), 48, 5), ((256, 64, 28, 28), 96, 1)]
+    jobs = []
+    for i, (xs, k, ks) in enumerate(layers):
+        n, c, h, w = xs
+        x = dev.DeviceTensor.from_numpy(synth.normal(1 + i, 2, n * c * h * w).astype(np.float32).reshape(xs))
+        wt = dev.DeviceTensor.from_numpy((synth.normal(3 + i, 4, k * c * ks * ks) * (2.0 / (c * ks * ks)) ** 0.5).astype(np.float32).reshape((k, c, ks, ks)))
+        b = dev.DeviceTensor.from_numpy(synth.normal(5 + i, 6, k).astype(np.float32).reshape((1, k, 1, 1)))
+        pd = (ks // 2, ks // 2)
+        run = (lambda node={}, x=x, wt=wt, b=b, pd=pd: conv.launch(node, x, wt, (1, 1), pd, pd, 'explicit', bias=b, act=('relu',)))
+        dev.select_stream(0)
+        jobs.append((xs, ks, run, np.asarray(run())))
+    try:
+        for rnd_ in range(2):
+            outs = []
+            for rep in range(3):
+                for i, (xs, ks, run, alone) in enumerate(jobs):
+                    dev.select_stream(i)
+                    outs.append((xs, ks, alone, run()))
+            for i in range(len(jobs)):
+                dev.select_stream(i)
+                dev.synchronize()
+            dev.select_stream(0)
+            for xs, ks, alone, y in outs:
+                assert_bit_exact(np.asarray(y), alone, 'conv {}x{} {} next to the others'.format(ks, ks, xs))
+    finally:
+        dev.select_stream(0)
+
+
 def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     """F(4x4, 3x3) (the layers with extents divisible by 4 and enough patches; forced here): one, odd and many channel
     stages, ragged channel blocks, fewer patches than a workgroup holds, several images, fused bias + ReLU written in place
