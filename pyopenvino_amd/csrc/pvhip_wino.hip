@@ -451,6 +451,53 @@ __device__ __forceinline__ void w4_load(float& d, __amdgpu_buffer_rsrc_t r, unsi
     d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+// ---- the input transform V = B^T d B of the six-point kernels in packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes of arithmetic per
+// instruction): 84 (M = 4) / 72 (M = 2) instructions for the 144 scalar operations of wino4_bt twelve times over -- the same
+// operations in the same order with the same roundings (a + b is fma(b, 1, a), d4 - d2 is fma(d2, -1, d4): exact products), so the
+// bits do not change.  The producers' transform is the long pole of a stage (s_memtime stamps: 2700 cycles of 3500).
+__device__ __forceinline__ w4_float2v w4_fma2(w4_float2v a, w4_float2v b, w4_float2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ w4_float2v w4_splat(float x) { return w4_float2v{x, x}; }
+
+// pass 1: B^T along the rows of a PAIR of columns (elementwise on the pair)
+__device__ __forceinline__ void wino4_bt2(w4_float2v d0, w4_float2v d1, w4_float2v d2, w4_float2v d3, w4_float2v d4, w4_float2v d5,
+                                          w4_float2v& o0, w4_float2v& o1, w4_float2v& o2, w4_float2v& o3, w4_float2v& o4, w4_float2v& o5) {
+    o0 = w4_fma2(w4_splat(4.0f), d0, w4_fma2(w4_splat(-5.0f), d2, d4));
+    const w4_float2v a = w4_fma2(w4_splat(-4.0f), d2, d4), b = w4_fma2(w4_splat(-4.0f), d1, d3);
+    o1 = a + b;
+    o2 = a - b;
+    const w4_float2v e = d4 - d2, f = d3 - d1;
+    o3 = w4_fma2(w4_splat(2.0f), f, e);
+    o4 = w4_fma2(w4_splat(-2.0f), f, e);
+    o5 = w4_fma2(w4_splat(4.0f), d1, w4_fma2(w4_splat(-5.0f), d3, d5));
+}
+
+// pass 2: B^T along the six columns m0..m5 of one row, the columns arriving as the pairs of pass 1.
+// PAIRING 0: pa = {m1, m2}, pb = {m3, m4}, pc = {m0, m5} (M = 4: a lane's own 16 bytes are columns 1..4, columns 0 and 5 come from
+// its neighbours);  PAIRING 1: pa = {m0, m1}, pb = {m2, m3}, pc = {m4, m5} (M = 2: own 8 bytes are columns 2..3).
+// {a, e} = {m4 - 4 m2, m4 - m2} and {b, f} = {m3 - 4 m1, m3 - m1} are one packed fma each, {o1, o3} = {a + b, e + 2 f} and
+// {o2, o4} = {a - b, e - 2 f} too.
+template <int PAIRING>
+__device__ __forceinline__ void wino4_bt_row(w4_float2v pa, w4_float2v pb, w4_float2v pc, float& o0, float& o1, float& o2, float& o3,
+                                             float& o4, float& o5) {
+    const w4_float2v k41 = {-4.0f, -1.0f}, k12 = {1.0f, 2.0f}, k12n = {-1.0f, -2.0f};
+    w4_float2v ae, bf;
+    if (PAIRING == 0) {
+        ae = w4_fma2(pa.yy, k41, pb.yy);
+        bf = w4_fma2(pa.xx, k41, pb.xx);
+        o0 = __builtin_fmaf(4.0f, pc.x, __builtin_fmaf(-5.0f, pa.y, pb.y));
+        o5 = __builtin_fmaf(4.0f, pa.x, __builtin_fmaf(-5.0f, pb.x, pc.y));
+    } else {
+        ae = w4_fma2(pb.xx, k41, pc.xx);
+        bf = w4_fma2(pa.yy, k41, pb.yy);
+        const w4_float2v o05 = w4_fma2(w4_splat(4.0f), pa, w4_fma2(w4_splat(-5.0f), pb, pc));
+        o0 = o05.x;
+        o5 = o05.y;
+    }
+    const w4_float2v o13 = w4_fma2(bf, k12, ae), o24 = w4_fma2(bf, k12n, ae);
+    o1 = o13.x; o3 = o13.y;
+    o2 = o24.x; o4 = o24.y;
+}
+
 #ifdef PVHIP_DIAG
 // ABL = 5 (diagnostic build): per-wave cycle accounts of every 61st workgroup, [wave][segment]; segment 7 counts the workgroups.
 // consumers: 0 MFMA segment (LDS reads + MFMA issue), 1 wait for the U DMA, 2 barrier;  producers: 0 gather issue, 1 wait for the older
@@ -688,32 +735,41 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     }
 #define PVW4_TRANSFORM_STORE(v_, e_, Vb_, zl_, zh_)                                                              \
     {                                                                                                            \
-        float m[36];                                                                                             \
-        _Pragma("unroll") for (int q = 0; q < 6; ++q) {                 /* columns: m = B^T d */                  \
-            float c[6];                                                                                          \
-            _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                      \
-                constexpr int IN0 = (M == 4) ? 1 : 2, NIN = M;      /* own (inner) columns IN0 .. IN0 + NIN - 1 */ \
-                if (q < IN0) {           /* from the left neighbour's last inner columns (wave_shr:1), own load in the first lane */ \
-                    float src_ = v_[r][NIN - IN0 + q];   /* opaque FLOAT copy: an integer cast of a loaded element folds back into */ \
-                    asm volatile("" : "+v"(src_));        /* "element i of the loaded vector", which hipcc lowers to element 0      */ \
-                    const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x138, 0xf, 0xf, false)); \
-                    c[r] = zl_ ? 0.0f : (first ? w4_edge(e_[r], q) : nb);                                        \
-                } else if (q >= IN0 + NIN) {   /* from the right neighbour's first inner columns (wave_shl:1), own load in the last lane */ \
-                    float src_ = v_[r][q - IN0 - NIN];                                                           \
-                    asm volatile("" : "+v"(src_));                                                               \
-                    const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src_), 0x130, 0xf, 0xf, false)); \
-                    c[r] = zh_ ? 0.0f : (last ? w4_edge(e_[r], q - IN0 - NIN) : nb);                             \
-                } else {                                                                                         \
-                    c[r] = v_[r][q - IN0];                                                                       \
-                }                                                                                                \
+        /* the six columns of row r as three pairs: lo = from the left neighbour (wave_shr:1; own load in the first lane), */ \
+        /* hi = from the right neighbour (wave_shl:1; own load in the last lane), own = the lane's load                     */ \
+        float2v pa[6], pb[6], pc[6];                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
+            constexpr int NB = (M == 4) ? 1 : 2;              /* columns taken from each neighbour */             \
+            float lo_[NB], hi_[NB];                                                                              \
+            _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                     \
+                /* v_mov_b32_dpp, bound_ctrl: a lane without a source (lane 0 / 63) gets 0 -- and takes its own edge load anyway */ \
+                const float nl = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)v_[r][M - NB + q]), 0x138, 0xf, 0xf, true)); \
+                const float nh = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)v_[r][q]), 0x130, 0xf, 0xf, true)); \
+                lo_[q] = zl_ ? 0.0f : (first ? w4_edge(e_[r], q) : nl);                                          \
+                hi_[q] = zh_ ? 0.0f : (last ? w4_edge(e_[r], q) : nh);                                           \
             }                                                                                                    \
-            if (ABL == 2) { _Pragma("unroll") for (int r = 0; r < 6; ++r) m[r * 6 + q] = c[r]; }                 \
-            else wino4_bt(c[0], c[1], c[2], c[3], c[4], c[5], m[0 * 6 + q], m[1 * 6 + q], m[2 * 6 + q], m[3 * 6 + q], m[4 * 6 + q], m[5 * 6 + q]); \
+            if (M == 4) {                                                                                        \
+                pa[r] = float2v{v_[r][0], v_[r][1]};                                                             \
+                pb[r] = float2v{v_[r][M - 2], v_[r][M - 1]};                                                     \
+                pc[r] = float2v{lo_[0], hi_[0]};                                                                 \
+            } else {                                                                                             \
+                pa[r] = float2v{lo_[0], lo_[NB - 1]};                                                         \
+                pb[r] = float2v{v_[r][0], v_[r][1]};                                                             \
+                pc[r] = float2v{hi_[0], hi_[NB - 1]};                                                         \
+            }                                                                                                    \
         }                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                 /* rows: V = m B */                       \
+        float2v ma[6], mb[6], mc[6];                                        /* columns: m = B^T d */              \
+        if (ABL == 2) {                                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r) { ma[r] = pa[r]; mb[r] = pb[r]; mc[r] = pc[r]; }       \
+        } else {                                                                                                 \
+            wino4_bt2(pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], ma[0], ma[1], ma[2], ma[3], ma[4], ma[5]);       \
+            wino4_bt2(pb[0], pb[1], pb[2], pb[3], pb[4], pb[5], mb[0], mb[1], mb[2], mb[3], mb[4], mb[5]);       \
+            wino4_bt2(pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], mc[0], mc[1], mc[2], mc[3], mc[4], mc[5]);       \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                     /* rows: V = m B */                   \
             float v0, v1, v2, v3, v4, v5;                                                                        \
-            if (ABL == 2) { v0 = m[i * 6 + 0]; v1 = m[i * 6 + 1]; v2 = m[i * 6 + 2]; v3 = m[i * 6 + 3]; v4 = m[i * 6 + 4]; v5 = m[i * 6 + 5]; } \
-            else wino4_bt(m[i * 6 + 0], m[i * 6 + 1], m[i * 6 + 2], m[i * 6 + 3], m[i * 6 + 4], m[i * 6 + 5], v0, v1, v2, v3, v4, v5); \
+            if (ABL == 2) { v0 = mc[i].x; v1 = ma[i].x; v2 = ma[i].y; v3 = mb[i].x; v4 = mb[i].y; v5 = mc[i].y; } \
+            else wino4_bt_row<(M == 4) ? 0 : 1>(ma[i], mb[i], mc[i], v0, v1, v2, v3, v4, v5);                    \
             Vb_[i * 6 + 0][g_chan][l31] = v0;                                                                    \
             Vb_[i * 6 + 1][g_chan][l31] = v1;                                                                    \
             Vb_[i * 6 + 2][g_chan][l31] = v2;                                                                    \
