@@ -25,6 +25,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) carrying
   cpu_baseline  the oracle (CPU restatement of the reference's 'special' path) timed on this host, N=1 per
                 image like the reference, on a bounded sample of the same workload;
   single_request_images_per_sec   one synchronous infer() at a time (SURVEY 8(d): B / wall time of one infer, median);
+  roofline.sustained              what fp32 MFMA alone sustains on THIS box (TFLOP/s, shader clock) and executed flops against it;
   hbm_copy_ceiling_GBs            what a plain device-to-device copy and the 16-byte ReLU stream reach on THIS box;
   extra_configs                   BASELINE configs 2 (mnist batch 64) and 5 (ssd_mobilenet_v1_coco batch 128).
 A per-op-type breakdown goes to stderr and, if the directory exists, the per-layer table to gpurun_out/bench_layers.json
@@ -108,6 +109,17 @@ def cpu_baseline(blob, n_images):
         pass
     return {'value': n_images / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': '{} googlenet-v1 images, one N=1 forward each, oracle numpy/OpenBLAS plugins, {:.1f} s'.format(n_images, dt)}
+
+
+def mfma_ceiling(device):
+    """What THIS box sustains on v_mfma_f32_32x32x2_f32 with nothing else in the instruction stream (pvhip_mfma_ceiling_f32: one
+    wave per SIMD, operands in registers, random data, a 2-3 ms kernel), the shader clock it holds meanwhile, and the same with a
+    VALU-only wave beside every MFMA wave.  157.3 TFLOP/s is the rate at 2.4 GHz; the chip lowers its clock under matrix load."""
+    tf, ghz = device.mfma_ceiling_f32(False, 20000)
+    tf_v, ghz_v = device.mfma_ceiling_f32(True, 20000)
+    return {'TFLOPs': round(tf, 1), 'clock_GHz': round(ghz, 2), 'with_a_VALU_wave_per_SIMD_TFLOPs': round(tf_v, 1),
+            'note': 'fp32 MFMA alone, every SIMD of every CU issuing; with an fp32 VALU wave on the same SIMD the MFMA rate drops by '
+                    'that wave\'s share of the issue cycles: matrix and vector fp32 instructions of a SIMD do not overlap'}
 
 
 def copy_ceiling(device):
@@ -298,9 +310,10 @@ def main():
             req.infer({in_name: x_req[req.index]})
     informational = rank == 0 and world == 1 and not args.no_node_timing
     per_node = {}
-    pcie_ms = single_rate = single_ms = ceiling = graph_ms = None
+    pcie_ms = single_rate = single_ms = ceiling = graph_ms = sustained = None
     if informational:
         ceiling = copy_ceiling(device)
+        sustained = mfma_ceiling(device)
         # the same step fed from a HOST array (Parameter uploads 154 MB over PCIe from pageable memory, then the forward
         # pass) -- SURVEY 8(d) asks for the end-to-end rate beside the resident one
         ex.device_timing, ex.compute_streams = None, n_streams
@@ -530,6 +543,7 @@ def main():
                         'frac_note': '`achieved` / `frac` count ALGORITHMIC flops (2*N*K*C*kh*kw*oh*ow: SURVEY 8(d)); the Winograd families execute 16/36 '
                                      '(F(2x2,3x3)), 36/144 (F(4x4,3x3)) or 36/100 (F(2x2,5x5)) of them on the matrix cores, so `frac` can exceed what the MFMA pipe '
                                      'does: `frac_executed` is executed flops / peak, the figure that compares with matrix-core utilisation',
+                        'sustained': dict(sustained, frac_executed_of_sustained=round(tf_exec / sustained['TFLOPs'], 3)) if sustained else None,
                         'traffic': traffic, 'traffic_source': traffic_src,
                         'kernel': 'all Convolution launches of a step: conv_wino4_kernel (F(4x4,3x3), F(2x2,5x5)) + conv_wino_kernel (F(2x2,3x3)) + conv_pw_kernel '
                                   '(1x1; the 1x1 / 3x3_reduce / 5x5_reduce convolutions of an inception module are one launch) + conv_pool1x1_kernel (MaxPool + pool_proj) '

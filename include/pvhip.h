@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   9
+#define PVHIP_ABI_VERSION   10
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -154,6 +154,12 @@ int pvhip_transpose_f32(const float* x, float* y, int rank, const int64_t* in_sh
  * trans_a), B is stored [K,N] (or [N,K] when trans_b); fp32 MFMA (v_mfma_f32_32x32x2_f32).        */
 int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int k,
                      int trans_a, int trans_b);
+
+/* Measurement utility, no reference counterpart: TFLOP/s this device SUSTAINS on v_mfma_f32_32x32x2_f32 alone (one wave per
+ * SIMD, operands in registers, random data) and the shader clock it holds meanwhile (s_memtime / s_memrealtime) -- the chip
+ * lowers its clock under matrix load, so this is the ceiling bench.py quotes beside the 157.3 TFLOP/s of 2.4 GHz.
+ * mode 1: a second wave per SIMD issues v_fma_f32 only (fp32 matrix and vector instructions of a SIMD do not overlap).      */
+int pvhip_mfma_ceiling_f32(int mode, int iters, double* tflops, double* clock_ghz);
 
 /* Convolution.py:57-87 im2col + kernel_Convolution_im2col ("special"), as an implicit GEMM:
  *   y[n,k,oy,ox] = sum_{c,r,s} xpad[n,c,oy*sh+r,ox*sw+s] * w[k,c,r,s]      (dilation ignored, as :72-87 does)

@@ -136,3 +136,79 @@ int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Measurement utility (bench.py's roofline.sustained): what THIS device sustains on v_mfma_f32_32x32x2_f32 with nothing else in
+// the instruction stream -- operands in registers, random data (all-zero operands let the chip hold a higher clock), every SIMD
+// of every CU issuing.  The chip lowers its clock under such a load, so this, not 157.3 TFLOP/s (the rate at 2.4 GHz), is the
+// ceiling a convolution kernel can be held against on the box it ran on.  mode 1 adds a second wave per SIMD that issues only
+// v_fma_f32: the fp32 matrix and vector instructions of one SIMD do not overlap (the MFMA rate drops by the VALU wave's share).
+namespace {
+__global__ __launch_bounds__(512) void mfma_ceiling_kernel(float* sink, unsigned long long* clocks, int iters, int mode) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float a = 1.0f + 0.001f * (float)((lane * 37 + wid * 11 + blockIdx.x) & 255), b = 0.5f + 0.002f * (float)((lane * 17 + blockIdx.x * 3) & 127);
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (mode == 1 && wid >= 4) {                      // waves 4-7 share the SIMDs of waves 0-3: VALU only
+        float v0 = a, v1 = b, v2 = a + b, v3 = a - b;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                v0 = __builtin_fmaf(v0, 0.999f, b); v1 = __builtin_fmaf(v1, 0.998f, a);
+                v2 = __builtin_fmaf(v2, 0.997f, b); v3 = __builtin_fmaf(v3, 0.996f, a);
+            }
+        }
+        if (v0 + v1 + v2 + v3 == 123.456f) sink[0] = v0;
+    } else {
+        floatx16 c0, c1, c2, c3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[r] = 0.0f; c1[r] = 0.0f; c2[r] = 0.0f; c3[r] = 0.0f; }
+        for (int i = 0; i < iters; ++i) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, c3, 0, 0, 0);
+            a = a * 0.99999f;                         // keeps the operands from being loop invariants folded away; stays finite
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += c0[r] + c1[r] + c2[r] + c3[r];
+        if (sum == 123.456f) sink[1] = sum;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clocks[0] = __builtin_readcyclecounter() - t0;
+        clocks[1] = __builtin_amdgcn_s_memrealtime() - r0;       // 100 MHz
+    }
+}
+}  // namespace
+
+extern "C" int pvhip_mfma_ceiling_f32(int mode, int iters, double* tflops, double* clock_ghz) {
+    PVHIP_REQUIRE_INIT();
+    if (iters <= 0 || (mode != 0 && mode != 1) || tflops == nullptr || clock_ghz == nullptr)
+        return pvhip::fail(PVHIP_EINVAL, "pvhip_mfma_ceiling_f32: mode 0 | 1, iters > 0");
+    float*              sink = nullptr;
+    unsigned long long* clocks = nullptr;
+    PVHIP_HIP(hipMalloc(&sink, 16));
+    PVHIP_HIP(hipMalloc(&clocks, 16));
+    hipEvent_t e0, e1;
+    PVHIP_HIP(hipEventCreate(&e0));
+    PVHIP_HIP(hipEventCreate(&e1));
+    hipStream_t st = pvhip::state().stream;
+    const int   threads = mode == 1 ? 512 : 256;     // one MFMA wave per SIMD (+ one VALU wave per SIMD in mode 1)
+    const dim3  grid(pvhip::kNumCU);
+    hipLaunchKernelGGL(mfma_ceiling_kernel, grid, dim3(threads), 0, st, sink, clocks, iters / 8 + 1, mode);      // clocks ramp up
+    PVHIP_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(mfma_ceiling_kernel, grid, dim3(threads), 0, st, sink, clocks, iters, mode);
+    PVHIP_HIP(hipEventRecord(e1, st));
+    PVHIP_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    PVHIP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[2] = {0, 0};
+    PVHIP_HIP(hipMemcpy(h, clocks, sizeof(h), hipMemcpyDeviceToHost));
+    *tflops    = (double)pvhip::kNumCU * 4.0 * (double)iters * 4.0 * 4096.0 / ((double)ms * 1e-3) / 1e12;
+    *clock_ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    (void)hipFree(clocks);
+    return PVHIP_OK;
+}

@@ -538,6 +538,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     auto& Us = sm.Us;
     const unsigned long long t_entry = PVW4_NOW();
     const unsigned long long r_entry = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
+    (void)r_entry;
 
     const int G = gridDim.x;
     int       L;                 // first tile: workgroups of one XCD (blockIdx & 7) take neighbouring tiles (same patches, other channel blocks)

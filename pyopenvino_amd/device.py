@@ -68,6 +68,7 @@ SIGNATURES = {
     'pvhip_concat_f32': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _i64p, _fp, _c.c_int64]),
     'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'pvhip_mfma_ceiling_f32': (_c.c_int, [_c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
     'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
     'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
@@ -185,6 +186,15 @@ def device_name() -> str:
 def synchronize():
     ensure_init()
     call('pvhip_sync')
+
+
+def mfma_ceiling_f32(with_valu_partner: bool = False, iters: int = 20000):
+    """(TFLOP/s, shader clock in GHz) this device sustains on v_mfma_f32_32x32x2_f32 alone -- or with a VALU-only wave beside
+    every MFMA wave (include/pvhip.h: pvhip_mfma_ceiling_f32).  A measurement utility for bench.py's roofline."""
+    ensure_init()
+    tf, ghz = _c.c_double(0.0), _c.c_double(0.0)
+    call('pvhip_mfma_ceiling_f32', 1 if with_valu_partner else 0, int(iters), _c.byref(tf), _c.byref(ghz))
+    return float(tf.value), float(ghz.value)
 
 
 def pool_stats():
