@@ -158,6 +158,24 @@ __global__ __launch_bounds__(512) void mfma_ceiling_kernel(float* sink, unsigned
             }
         }
         if (v0 + v1 + v2 + v3 == 123.456f) sink[0] = v0;
+    } else if (mode == 2) {                           // the 16x16x4 shape: the same flops per cycle, half the operand reuse
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        floatx4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+        for (int i = 0; i < iters; ++i) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, c3, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c4, 0, 0, 0);
+            c5 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, c5, 0, 0, 0);
+            c6 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, c6, 0, 0, 0);
+            c7 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, c7, 0, 0, 0);
+            a = a * 0.99999f;
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += c0[r] + c1[r] + c2[r] + c3[r] + c4[r] + c5[r] + c6[r] + c7[r];
+        if (sum == 123.456f) sink[1] = sum;
     } else {
         floatx16 c0, c1, c2, c3;
 #pragma unroll
@@ -183,8 +201,8 @@ __global__ __launch_bounds__(512) void mfma_ceiling_kernel(float* sink, unsigned
 
 extern "C" int pvhip_mfma_ceiling_f32(int mode, int iters, double* tflops, double* clock_ghz) {
     PVHIP_REQUIRE_INIT();
-    if (iters <= 0 || (mode != 0 && mode != 1) || tflops == nullptr || clock_ghz == nullptr)
-        return pvhip::fail(PVHIP_EINVAL, "pvhip_mfma_ceiling_f32: mode 0 | 1, iters > 0");
+    if (iters <= 0 || (mode < 0 || mode > 2) || tflops == nullptr || clock_ghz == nullptr)
+        return pvhip::fail(PVHIP_EINVAL, "pvhip_mfma_ceiling_f32: mode 0 | 1 | 2, iters > 0");
     float*              sink = nullptr;
     unsigned long long* clocks = nullptr;
     PVHIP_HIP(hipMalloc(&sink, 16));

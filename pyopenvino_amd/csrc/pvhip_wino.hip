@@ -86,6 +86,18 @@ __device__ __forceinline__ void wino_dma_b128(__amdgpu_buffer_rsrc_t r, float* d
 #endif
 }
 
+#ifdef PVHIP_DIAG
+// ABL = 5 (diagnostic build): per-wave cycle accounts of every 61st workgroup, [wave][segment]; segment 7 counts the workgroups.
+// consumers: 0 MFMA segment (LDS reads + MFMA issue), 1 wait for the U DMA, 2 barrier;  producers: 0 gather issue, 1 wait for the older
+// gather, 2 transform + LDS writes, 3 barrier.
+__device__ unsigned long long g_w4_stamps[8][8];
+__device__ unsigned g_w4_hw[64][8][2];          // ABL = 5: HW_REG_LDS_ALLOC / HW_REG_HW_ID of the waves of the first 64 workgroups
+__device__ unsigned g_w4_hw_ticket;
+#define PVW4_NOW() ((ABL == 5) ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#else
+#define PVW4_NOW() 0ull
+#endif
+
 // MT x NTL = 32-channel tiles x 32-patch tiles per workgroup: (2, 1) = 64 channels x 32 patches, (1, 2) = 32 x 64,
 // (1, 1) = 32 x 32 on four waves.
 // The second form gathers (and transforms) each input patch once per 64 output channels instead of once per 32 and is
@@ -211,8 +223,17 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef PVHIP_DIAG
+    const bool stamp = a.balance == 5;
+    unsigned long long st[4] = {0ull, 0ull, 0ull, 0ull};
+    const unsigned long long t_entry = stamp ? __builtin_readcyclecounter() : 0ull;
+#define PVW_NOW() (stamp ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#else
+#define PVW_NOW() 0ull
+#endif
     for (int s = 0; s < a.n_stages; ++s) {
         const int buf = s & 1;
+        const unsigned long long t0 = PVW_NOW();
         PVW_GATHER(s + 1);            // one stage ahead (past the end: the next image's channels / out of range -> unused)
         PVW_LOAD_U(s + 1, buf ^ 1);   // past the end: the spare zero stage of the block
         __builtin_amdgcn_sched_barrier(0);
@@ -243,20 +264,34 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t1 = PVW_NOW();
         PVW_TRANSFORM_STORE(buf ^ 1, s + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t2 = PVW_NOW();
         __syncthreads();
+#ifdef PVHIP_DIAG
+        const unsigned long long t3 = PVW_NOW();
+        st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2;
+#else
+        (void)t0; (void)t1; (void)t2;
+#endif
     }
+#ifdef PVHIP_DIAG
+    const unsigned long long t_loop = PVW_NOW();
+#endif
 #undef PVW_GATHER
 #undef PVW_LOAD_U
 #undef PVW_TRANSFORM_STORE
 
     // ---- output transform  Y = A^T D A,  A^T = [[1,1,1,0],[0,1,-1,-1]]: columns in registers (this wave holds row i = wid),
-    // rows through LDS, one 32-channel x 32-patch tile at a time: Ex[i][b][k][patch].
-    float* Ex = (sizeof(sm.Vs) >= 32 * 1024) ? &Vs[0][0][0][0] : &Us[0][0][0][0];     // 4 * 2 * 32 * 32 floats = 32 KB (may span Us and Vs)
+    // rows through LDS, one 32-channel x 32-patch tile at a time: Ex[i][k][patch][2 columns] -- the two column results of a
+    // (row, channel, patch) are one 8-byte LDS access, and an output row of the 2x2 patch one 8-byte store (even widths).
+    typedef float ex2_t __attribute__((ext_vector_type(2)));
+    float* Ex = (sizeof(sm.Vs) >= 32 * 1024) ? &Vs[0][0][0][0] : &Us[0][0][0][0];     // 4 * 32 * 32 * 2 floats = 32 KB (may span Us and Vs)
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
                                                                         a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
-    const int OH = a.H, OW = a.W;
+    const int  OH = a.H, OW = a.W;
+    const bool pair_stores = (OW & 1) == 0;          // 2*tx + 1 < OW and 8-byte aligned rows
 #pragma unroll
     for (int h = 0; h < TILES; ++h) {
         if (h == 1) __syncthreads();         // the reads of the first tile are done
@@ -265,8 +300,10 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                Ex[((row * 2 + 0) * 32 + k) * 32 + l31] = acc[0][hh][r] + acc[1][hh][r] + acc[2][hh][r];
-                Ex[((row * 2 + 1) * 32 + k) * 32 + l31] = acc[1][hh][r] - acc[2][hh][r] - acc[3][hh][r];
+                ex2_t e;
+                e.x = acc[0][hh][r] + acc[1][hh][r] + acc[2][hh][r];
+                e.y = acc[1][hh][r] - acc[2][hh][r] - acc[3][hh][r];
+                *reinterpret_cast<ex2_t*>(Ex + ((row * 32 + k) * 32 + l31) * 2) = e;
             }
         }
         __syncthreads();
@@ -281,35 +318,47 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
                 const int k  = (tid >> 5) + (THREADS / 32) * q;
                 const int kg = kb * KB + ((MT == 2) ? h * 32 : 0) + k;
                 if (kg >= a.K) continue;
-                float T_[4][2];
+                ex2_t T_[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T_[i][0] = Ex[((i * 2 + 0) * 32 + k) * 32 + tl];
-                    T_[i][1] = Ex[((i * 2 + 1) * 32 + k) * 32 + tl];
-                }
-                float yv[2][2];
-                yv[0][0] = T_[0][0] + T_[1][0] + T_[2][0];
-                yv[0][1] = T_[0][1] + T_[1][1] + T_[2][1];
-                yv[1][0] = T_[1][0] - T_[2][0] - T_[3][0];
-                yv[1][1] = T_[1][1] - T_[2][1] - T_[3][1];
+                for (int i = 0; i < 4; ++i) T_[i] = *reinterpret_cast<const ex2_t*>(Ex + ((i * 32 + k) * 32 + tl) * 2);
+                ex2_t yv[2];
+                yv[0] = T_[0] + T_[1] + T_[2];
+                yv[1] = T_[1] - T_[2] - T_[3];
                 const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)kg * 4u, 0, 0));
                 float* __restrict__ yp = a.y + (((size_t)n * a.y_ctotal + a.y_coff + kg) * OH + oy) * OW + ox;
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
                     if (oy + r2 >= OH) continue;
+                    float ov[2];
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
-                        if (ox + c2 >= OW) continue;
                         float v = yv[r2][c2];
                         if (a.bias != nullptr) v = v + bv;
                         if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;
                         else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
-                        yp[(size_t)r2 * OW + c2] = v;
+                        ov[c2] = v;
+                    }
+                    if (pair_stores) {
+                        *reinterpret_cast<float2*>(yp + (size_t)r2 * OW) = make_float2(ov[0], ov[1]);
+                    } else {
+                        yp[(size_t)r2 * OW] = ov[0];
+                        if (ox + 1 < OW) yp[(size_t)r2 * OW + 1] = ov[1];
                     }
                 }
             }
         }
     }
+#ifdef PVHIP_DIAG
+    if (stamp && blockIdx.x % 61 == 7 && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        for (int i = 0; i < 3; ++i) atomicAdd(&g_w4_stamps[wid][i], st[i]);
+        atomicAdd(&g_w4_stamps[wid][4], t_loop - t_entry - (st[0] + st[1] + st[2]));   // (stamp overhead only)
+        atomicAdd(&g_w4_stamps[wid][5], t_end - t_loop);                                 // epilogue
+        atomicAdd(&g_w4_stamps[wid][6], t_end - t_entry);                                // from the first stage to the end
+        atomicAdd(&g_w4_stamps[wid][7], 1ull);
+    }
+#endif
+#undef PVW_NOW
 }
 
 
@@ -498,17 +547,6 @@ __device__ __forceinline__ void wino4_bt_row(w4_float2v pa, w4_float2v pb, w4_fl
     o2 = o24.x; o4 = o24.y;
 }
 
-#ifdef PVHIP_DIAG
-// ABL = 5 (diagnostic build): per-wave cycle accounts of every 61st workgroup, [wave][segment]; segment 7 counts the workgroups.
-// consumers: 0 MFMA segment (LDS reads + MFMA issue), 1 wait for the U DMA, 2 barrier;  producers: 0 gather issue, 1 wait for the older
-// gather, 2 transform + LDS writes, 3 barrier.
-__device__ unsigned long long g_w4_stamps[8][8];
-__device__ unsigned g_w4_hw[64][8][2];          // ABL = 5: HW_REG_LDS_ALLOC / HW_REG_HW_ID of the waves of the first 64 workgroups
-__device__ unsigned g_w4_hw_ticket;
-#define PVW4_NOW() ((ABL == 5) ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
-#else
-#define PVW4_NOW() 0ull
-#endif
 
 // M = 4: F(4x4, 3x3), pad 1.  M = 2: F(2x2, 5x5), pad 2 -- the same six interpolation points, hence the same B^T, the same 36 products
 // per channel and patch (for 4 outputs of a 5x5 window: 9 per output instead of 25) and the same kernel; only the gather geometry (an
@@ -934,6 +972,10 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.u_bytes = (unsigned)(wino_pack_elems(k_out, c) * 4);
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
+    a.balance = 0; a.n_tiles = 0;
+#ifdef PVHIP_DIAG
+    if (settings().wino4_ablate == 5) a.balance = 5;          // diagnostic build: s_memtime stamps (scripts/stamps_wino.py)
+#endif
     // 32-channel blocks run as 32 channels x 32 patches on four waves (more, smaller workgroups: the layers whose K is not
     // made of 64-channel blocks are the small 14x14 ones); PVHIP_WINO_SMALL=0 selects 32 x 64 on eight waves (tuning runs)
     const bool  small = kb == 32 && settings().wino_small;
