@@ -14,13 +14,13 @@ import sys
 
 
 def is_conv(name):
-    """The kernels behind the Convolution nodes: implicit GEMM (also with the MaxPool in front folded in), the Winograd forms, the 7x7 stem."""
-    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_stem' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name
+    """The kernels behind the Convolution nodes: implicit GEMM (also with the MaxPool in front folded in), the Winograd forms, the pointwise kernel."""
+    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name
 
 
 def find(root, pattern):
     hits = glob.glob(os.path.join(root, '**', pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None      # gpurun MERGES into gpurun_out/: an older run's files may still be there
 
 
 def main():
@@ -136,8 +136,10 @@ def main():
                 dur = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(kt)) if is_conv(r['Kernel_Name']))
                 if dur:
                     ghz = cyc / dur
-                    md += ['- shader clock while these kernels ran: {:.2f} GHz (GRBM_GUI_ACTIVE / 8 / summed kernel time) -> fp32 MFMA ceiling at that clock '
-                           '{:.0f} TFLOP/s (157.3 at 2.4 GHz)'.format(ghz, 157.3 * ghz / 2.4)]
+                    md += ['- GRBM_GUI_ACTIVE / 8 / summed kernel time = {:.2f} GHz: an UPPER bound of the shader clock (the quotient reads high on '
+                           'dispatches shorter than ~0.3 ms, and these are 0.03-0.7 ms); s_memtime / s_memrealtime stamps inside the Winograd kernels '
+                           '(diagnostic build, scripts/stamps_wino4.py) read 1.98-2.10 GHz, and fp32 MFMA alone sustains 141-148 TFLOP/s at 2.26-2.40 GHz '
+                           '(bench.py: roofline.sustained)'.format(ghz)]
             for k in sorted(agg):
                 md.append('- {} = {:.4g}'.format(k, agg[k]))
     md += forked_md
