@@ -381,6 +381,15 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
 //     (16 channels at a time), then bias / activation and four 16-byte stores per (channel, patch).
 constexpr int kXi4 = 36;
 
+// Where element (xi = 6 i + j, channel cl of the stage, output channel kl of the block) of a U stage image lives: in the order the
+// consumers of conv_wino4_kernel read it -- consumer i, MFMA m = 6 kk + j of a stage (kk = cl >> 1: reduction step), lane = 32 (cl & 1)
+// + kl: [i][m >> 2][lane][m & 3], so that the A operands of four consecutive MFMAs are ONE 16-byte load per lane and a load
+// instruction reads 1 KiB of consecutive bytes.  The images never pass through LDS.
+__device__ __forceinline__ int wino4_u_offset(int i, int j, int cl, int kl) {
+    const int m = (cl >> 1) * 6 + j, lane = (cl & 1) * 32 + kl;
+    return ((i * 3 + (m >> 2)) * 64 + lane) * 4 + (m & 3);
+}
+
 __global__ __launch_bounds__(kBlock) void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int K, int C,
                                                              int n_stages) {
     constexpr int KB = 32;
@@ -403,12 +412,12 @@ __global__ __launch_bounds__(kBlock) void wino4_pack_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < 3; ++q) r[i][q] = G[i][0] * g[0][q] + G[i][1] * g[1][q] + G[i][2] * g[2][q];
         const int kb = k / KB, kl = k % KB, st = c / kCB, cl = c % kCB;
-        float* up = u + ((size_t)kb * (n_stages + 1) + st) * kUStage + cl * KB + kl;
+        float* up = u + ((size_t)kb * (n_stages + 1) + st) * kUStage;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j)
-                up[(i * 6 + j) * kCB * KB] = r[i][0] * G[j][0] + r[i][1] * G[j][1] + r[i][2] * G[j][2];
+                up[wino4_u_offset(i, j, cl, kl)] = r[i][0] * G[j][0] + r[i][1] * G[j][1] + r[i][2] * G[j][2];
     }
 }
 
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void wino25_pack_kernel(const float* __rest
                 r[i][q] = acc;
             }
         const int kb = k / KB, kl = k % KB, st = c / kCB, cl = c % kCB;
-        float* up = u + ((size_t)kb * (n_stages + 1) + st) * kUStage + cl * KB + kl;
+        float* up = u + ((size_t)kb * (n_stages + 1) + st) * kUStage;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void wino25_pack_kernel(const float* __rest
                 float acc = 0.0f;
 #pragma unroll
                 for (int z = 0; z < 5; ++z) acc += r[i][z] * G[j][z];
-                up[(i * 6 + j) * kCB * KB] = acc;
+                up[wino4_u_offset(i, j, cl, kl)] = acc;
             }
     }
 }
@@ -563,17 +572,17 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     constexpr int PAD = (M == 4) ? 1 : 2;               // 6 = M + kernel - 1 input rows / columns starting at M*t - PAD
     constexpr int KB = 32, NT = 32, WAVES = 8, CONSUMERS = 6;
     constexpr unsigned kOob = 0x80000000u;
-    constexpr int U_PIECES = kXi4 * kCB * KB * 4 / 1024;      // 18 one-KiB pieces per U stage image
-    // V0 first: the epilogue's exchange area is Us + the head of V1, and V0 holds stage 0 of the NEXT tile by then
+    // V0 first: the epilogue's exchange area is V1 and the space behind it, and V0 holds stage 0 of the NEXT tile by then.  The
+    // weight images U do not pass through LDS: every consumer loads its own MFMA A operands straight into registers (three 16-byte
+    // loads per lane and stage from a panel packed in that order: wino4_u_offset) -- an LDS-DMA piece costs its wave 60-185 issue
+    // cycles (18 per stage were 0.18 of conv2/3x3's 0.81 ms), a register load a tenth of that, and twelve LDS reads per stage go too.
     struct Stage {
         float V0[kXi4][kCB][NT];
-        float Us[2][kXi4][kCB][KB];
         float V1[kXi4][kCB][NT];
+        float ex_tail[(48 - 18) * 256];
     };
     __shared__ __attribute__((aligned(1024))) Stage sm;
-    static_assert(sizeof(Stage) == 72 * 1024, "72 KB of LDS (+ 32 bytes of role table): two workgroups per CU");
-    static_assert(U_PIECES % CONSUMERS == 0, "whole pieces per consumer wave");
-    auto& Us = sm.Us;
+    static_assert(sizeof(Stage) == 66 * 1024, "66 KB of LDS (+ 32 bytes of role table): two workgroups per CU");
     const unsigned long long t_entry = PVW4_NOW();
     const unsigned long long r_entry = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
     (void)r_entry;
@@ -603,14 +612,9 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     constexpr unsigned u_stage_bytes = (unsigned)kXi4 * kCB * KB * 4u;
     const unsigned u_lane = (unsigned)lane * 16u;
 
-    // the U image of a stage: 18 one-KiB pieces, three per consumer wave
-#define PVW4_LOAD_U(s_, buf_)                                                                                   \
-    {                                                                                                           \
-        const unsigned soff = u_base + (unsigned)(s_) * u_stage_bytes;                                           \
-        _Pragma("unroll") for (int q = 0; q < U_PIECES / CONSUMERS; ++q)                                         \
-            if (ABL != 4)                                                                                        \
-                wino_dma_b128(ur, &Us[buf_][0][0][0] + (row + CONSUMERS * q) * 256, u_lane + (unsigned)(row + CONSUMERS * q) * 1024u, soff); \
-    }
+    // the A operands of this consumer's twelve MFMAs of a stage: group g_ = MFMAs 4 g_ .. 4 g_ + 3
+#define PVW4_LOAD_U(ua_, s_, g_)                                                                                  \
+    w4_load(ua_[g_], ur, u_lane + (unsigned)(row * 3 + (g_)) * 1024u, u_base + (unsigned)(s_) * u_stage_bytes)
 
     // ---- roles.  Two workgroups share a CU, and waves w and w + 4 of a workgroup share a SIMD: with fixed roles (producers = waves
     // 6, 7) two SIMDs carry four consumers (48 MFMAs per stage of both workgroups) and two carry two consumers and two producers (24).
@@ -636,10 +640,10 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     }
 
     // ---- output transform Y = A^T D A (A^T: M x 6) of one tile: the column half in registers (consumer i holds row i), the rows meet
-    // in LDS, CH channels at a time: Ex[i][CH][patch][c'] = 6 * CH * 32 * M floats = 48 KB (M = 4: 16 channels, M = 2: 32) = Us and
-    // the head of V1; every wave takes part in the second half.  Both roles carry a copy (the registers live across it differ).
+    // in LDS, CH channels at a time: Ex[i][CH][patch][c'] = 6 * CH * 32 * M floats = 48 KB (M = 4: 16 channels, M = 2: 32) = V1 and
+    // the space behind it; every wave takes part in the second half.  Both roles carry a copy (the registers live across it differ).
     constexpr int CH = (M == 4) ? 16 : 32, PASSES = 32 / CH;
-    float* const Ex = &Us[0][0][0][0];
+    float* const Ex = &sm.V1[0][0][0];
     const int OH = a.H, OW = a.W;
     typedef float exv_t __attribute__((ext_vector_type(M)));      // the M column outputs of a (row, channel, patch): one LDS access
 #define PVW4_EPI_WRITE(pass)                                                                                     \
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                 }                                                                                                \
             }                                                                                                    \
         }                                                                                                        \
-        __syncthreads();      /* the exchange area is read out: the next tile's U image may land in it */          \
+        __syncthreads();      /* the exchange area is read out: V1 may be written again */                                  \
     }
 
     unsigned long long st[4] = {0ull, 0ull, 0ull, 0ull};      // ABL = 5 only
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo, zhi);
         t_head = PVW4_NOW() - t_entry;
         for (;;) {
-            __syncthreads();              // V(0) of this tile is in V0 (and the consumers' U(0) has landed)
+            __syncthreads();              // V(0) of this tile is in V0
             // stage s: V(s+1) from the gather issued one stage ago, gather of stage s+2 issued now (two stages in flight)
             for (int s = 0; s + 2 < n_eff; s += 2) {
                 const unsigned long long t0 = PVW4_NOW();
@@ -873,30 +877,44 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             for (int j = 0; j < 6; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-            PVW4_LOAD_U(0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            w4_float4v ua[3];
+            PVW4_LOAD_U(ua, 0, 0);
+            PVW4_LOAD_U(ua, 0, 1);
+            PVW4_LOAD_U(ua, 0, 2);
             __syncthreads();
             t_head += PVW4_NOW() - h0;
             for (int s = 0; s < n_eff; ++s) {
-                const int buf = s & 1;
                 const unsigned long long t0 = PVW4_NOW();
-                if (s + 1 < n_eff) PVW4_LOAD_U(s + 1, buf ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const float* vb = buf ? &sm.V1[0][0][0] : &sm.V0[0][0][0];
+                const float* vb = (s & 1) ? &sm.V1[0][0][0] : &sm.V0[0][0][0];
+                const int    sn = s + 1 < n_eff ? s + 1 : s;          // the last stage reloads its own image (unused)
+                // B operands one group (four MFMAs) ahead, A operands of a group reloaded for the next stage as soon as its MFMAs are
+                // issued: the sched_barriers keep hipcc from sinking the loads to the end of the stage (it did)
+                float bfr[2][4];
+#define PVW4_READ_B(dst_, g_)                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+        const int m = 4 * (g_) + e, kk = m / 6, j = m % 6;                                                       \
+        dst_[e] = vb[((row * 6 + j) * kCB + 2 * kk + lh) * NT + l31];                                            \
+    }
+                PVW4_READ_B(bfr[0], 0);
 #pragma unroll
-                for (int kk = 0; kk < kCB / 2; ++kk) {
+                for (int g = 0; g < 3; ++g) {
+                    if (g < 2) PVW4_READ_B(bfr[(g + 1) & 1], g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const float af = Us[buf][row * 6 + j][2 * kk + lh][l31];
-                        const float bf = vb[((row * 6 + j) * kCB + 2 * kk + lh) * NT + l31];
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = 4 * g + e, j = m % 6;
+                        const float af = ua[g][e];
+                        const float bf = bfr[g & 1][e];
                         if (ABL == 3) acc[j][0] += af * bf;
                         else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ABL != 4) PVW4_LOAD_U(ua, sn, g);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#undef PVW4_READ_B
                 const unsigned long long t1 = PVW4_NOW();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned long long t2 = PVW4_NOW();
+                const unsigned long long t2 = t1;
                 __syncthreads();
                 const unsigned long long t3 = PVW4_NOW();
                 st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2;
