@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   10
+#define PVHIP_ABI_VERSION   11
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -140,6 +140,13 @@ int pvhip_lrn_maxpool_supported(int n, int c, int h, int w, int size, float beta
 int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, int size, float alpha, float beta,
                           float bias, int oh, int ow, int kh, int kw, int sh, int sw, int pad_top, int pad_left,
                           int pad_bottom, int pad_right);
+/* The other order, MaxPool.py:41-72 (3x3 window, stride 1 or 2) followed by LRN.py:10-22, as ONE launch: y = lrn(maxpool(x)),
+ * bit-identical to calling pvhip_maxpool2d_f32 then pvhip_lrn_f32; the pooled tensor is never written.  x is (n, c, h, w), y is
+ * (n, c, oh, ow).  Same coverage as pvhip_lrn_maxpool_f32 (size == 5, beta == 0.75, c % 8 == 0, bands that fit one workgroup).   */
+int pvhip_maxpool_lrn_supported(int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw, int pad_top,
+                                int pad_left, int pad_bottom, int pad_right, int size, float beta, float bias);
+int pvhip_maxpool_lrn_f32(const float* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw,
+                          int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha, float beta, float bias);
 
 /* ---------------------------------------------------------------- data movement ------------- */
 /* Concat.py:9-13 kernel_Concat_numpy: srcs[i] is viewed as [outer][inner[i]] and copied to

@@ -304,6 +304,131 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
 #undef PV_LRN_TO_LDS
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The other order: a 3x3 MaxPool followed by LRN (GoogLeNet's pool1/3x3_s2 -> pool1/norm1) in ONE pass: the pooled
+// tensor (411 MB at batch 256: written once, read once) never exists.  Same bands, same lane <-> input pixels for the
+// loads; the RAW planes of a chunk of 8 channels go to LDS, every lane pools its own NI output pixels out of them (the
+// geometry of lrn_maxpool3x3_kernel, computed once) and the pooled values of consecutive channels ARE the stream the LRN
+// window slides over: five of them in registers per owned pixel, squares summed in ascending channel order, the
+// arithmetic of lrn_window_kernel -- the bits of the two separate launches.
+template <int SIZE, int VEC, int BETA_MODE, int ST, int NI>
+__global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_kernel(LrnPoolArgs a, FastDiv d_bands, FastDiv d_ow) {
+    constexpr int beta_mode = BETA_MODE;
+    constexpr int HALF = SIZE / 2;
+    constexpr int T    = 8;
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) float planes[];   // [T][plane_l]
+
+    const int tid = threadIdx.x;
+    const int img = (int)fdiv(blockIdx.x, d_bands), band = (int)blockIdx.x - img * a.n_bands;
+    const int oy0 = band * a.band_rows, oy1 = min(a.oh, oy0 + a.band_rows);
+    const int rows_t = oy1 - oy0;
+    const int iy_lo = max(0, oy0 * ST - a.pt), iy_hi = min(a.h, (oy1 - 1) * ST + 3 - a.pt);
+    const int band_px = (iy_hi - iy_lo) * a.w;
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+    const bool   active  = tid * VEC < band_px;
+    const size_t cstride = (size_t)hw / VEC;
+    const vec_t* __restrict__ xv =
+        reinterpret_cast<const vec_t*>(a.x + (size_t)img * a.c * hw + (size_t)iy_lo * a.w + (active ? tid * VEC : 0));
+    float* const mine = planes + tid * VEC;
+    const int    n_chunks = a.c / T;
+    const int    out_pp   = a.band_rows * a.ow;
+
+    unsigned tap[NI][9];
+    unsigned outo[NI];
+    bool     live[NI], zpad[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const unsigned rem = (unsigned)(tid + i * kBlock);
+        const unsigned oyl = fdiv(rem, d_ow), ox = rem - oyl * (unsigned)a.ow;
+        live[i] = (int)rem < out_pp && (int)oyl < rows_t;
+        const int oy = oy0 + (int)oyl;
+        const int py0 = oy * ST - a.pt, px0 = (int)ox * ST - a.pl;
+        const int c0 = min(max(px0, 0), a.w - 1), c1 = min(max(px0 + 1, 0), a.w - 1), c2 = min(max(px0 + 2, 0), a.w - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int r = (min(max(py0 + k, 0), a.h - 1) - iy_lo) * a.w;
+            tap[i][3 * k + 0] = live[i] ? (unsigned)(r + c0) * 4u : 0u;
+            tap[i][3 * k + 1] = live[i] ? (unsigned)(r + c1) * 4u : 0u;
+            tap[i][3 * k + 2] = live[i] ? (unsigned)(r + c2) * 4u : 0u;
+        }
+        const bool zc = (px0 < 0) || (min((int)ox * ST + 2, a.wp - 1) - a.pl >= a.w);
+        const bool zr = (py0 < 0) || (min(oy * ST + 2, a.hp - 1) - a.pt >= a.h);
+        zpad[i] = zc || zr;
+        outo[i] = (unsigned)(oy * a.ow) + ox;
+    }
+    float* const yimg = a.y + (size_t)img * a.c * ohw;
+    const char* const planes_b = reinterpret_cast<const char*>(planes);
+    const unsigned plane_bytes = (unsigned)a.plane_l * 4u;
+
+    float win[NI][SIZE];                   // pooled values of channels ch - SIZE + 1 .. ch of the owned pixels
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int q = 0; q < SIZE; ++q) win[i][q] = 0.0f;
+
+    // a new pooled value v_ of channel ch_ enters the window; the window is then centred on channel ch_ - HALF
+#define PV_PUSH_EMIT(i_, v_, ch_)                                                              \
+    {                                                                                          \
+        _Pragma("unroll") for (int q = 0; q + 1 < SIZE; ++q) win[i_][q] = win[i_][q + 1];      \
+        win[i_][SIZE - 1] = (v_);                                                              \
+        if ((ch_) >= HALF) {                                                                   \
+            float s_ = win[i_][0] * win[i_][0];                                                \
+            _Pragma("unroll") for (int q = 1; q < SIZE; ++q) s_ = s_ + win[i_][q] * win[i_][q]; \
+            const float d_ = a.bias + a.alpha * s_;                                            \
+            yimg[(size_t)((ch_) - HALF) * ohw + outo[i_]] = lrn_div(win[i_][HALF], d_, a.beta, beta_mode); \
+        }                                                                                      \
+    }
+
+    vec_t cur[T], nxt[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) cur[j] = xv[(size_t)j * cstride];
+    for (int k = 0; k < n_chunks; ++k) {
+        if (k + 1 < n_chunks) {
+            const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
+#pragma unroll
+            for (int j = 0; j < T; ++j) nxt[j] = xn[(size_t)j * cstride];
+        }
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) *reinterpret_cast<vec_t*>(mine + j * a.plane_l) = cur[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (!live[i]) continue;
+            unsigned pb = 0u;
+#pragma unroll
+            for (int p = 0; p < T; ++p, pb += plane_bytes) {
+                float m      = -INFINITY;
+                bool  anynan = false;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float v0 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * q + 0]);
+                    const float v1 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * q + 1]);
+                    const float v2 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * q + 2]);
+                    m      = fmaxf(m, fmaxf(fmaxf(v0, v1), v2));
+                    anynan = anynan | __builtin_isunordered(v0, v1) | (v2 != v2);
+                }
+                if (zpad[i]) m = fmaxf(m, 0.0f);
+                const float pooled = anynan ? NAN : m;
+                PV_PUSH_EMIT(i, pooled, k * T + p)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < T; ++j) cur[j] = nxt[j];
+    }
+    // the trailing HALF channels: their windows run past the tensor (zeros)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (!live[i]) continue;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) PV_PUSH_EMIT(i, 0.0f, a.c + j)
+    }
+#undef PV_PUSH_EMIT
+}
+
 // Geometry of the fused launch, or false when the pair is outside what lrn_maxpool3x3_kernel covers.
 bool plan_lrn_pool(int n, int c, int h, int w, int size, float beta, float bias, int oh, int ow, int kh, int kw, int sh, int sw,
                    int pt, int pl, int pb, int pr, LrnPoolArgs& a, int& vec, int& bm, size_t& lds) {
@@ -456,6 +581,50 @@ int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, 
     }
 #undef PV_LP_NI
 #undef PV_LP
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+// MaxPool (3x3) then LRN as one launch: same coverage rules as the other order (the geometry is the pooling's either way).
+int pvhip_maxpool_lrn_supported(int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw, int pad_top, int pad_left,
+                                int pad_bottom, int pad_right, int size, float beta, float bias) {
+    LrnPoolArgs a{};
+    int vec = 0, bm = 0;
+    size_t lds = 0;
+    return plan_lrn_pool(n, c, h, w, size, beta, bias, oh, ow, kh, kw, sh, sw, pad_top, pad_left, pad_bottom, pad_right, a, vec, bm, lds) ? 1 : 0;
+}
+
+int pvhip_maxpool_lrn_f32(const float* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw,
+                          int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha, float beta, float bias) {
+    PVHIP_REQUIRE_INIT();
+    LrnPoolArgs a{};
+    int vec = 0, bm = 0;
+    size_t lds = 0;
+    if (!plan_lrn_pool(n, c, h, w, size, beta, bias, oh, ow, kh, kw, sh, sw, pad_top, pad_left, pad_bottom, pad_right, a, vec, bm, lds))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_maxpool_lrn_f32: shape outside the fused kernel (ask pvhip_maxpool_lrn_supported first)");
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+    a.x = x; a.y = y; a.alpha = alpha; a.beta = beta; a.bias = bias;
+    const dim3 grid((unsigned)(n * a.n_bands));
+    const FastDiv d_bands = make_fastdiv((unsigned)a.n_bands), d_ow = make_fastdiv((unsigned)ow);
+    const int ni = (a.band_rows * ow + kBlock - 1) / kBlock;
+    if (ni > 4) return fail(PVHIP_EUNSUPPORTED, "pvhip_maxpool_lrn_f32: more than four pooled outputs per lane and plane");
+#define PV_PL(VEC_, BM_, ST_, NI_) \
+    hipLaunchKernelGGL((maxpool3x3_lrn_kernel<5, VEC_, BM_, ST_, NI_>), grid, dim3(kBlock), lds, state().stream, a, d_bands, d_ow)
+#define PV_PL_NI(VEC_, BM_, ST_)                                  \
+    {                                                             \
+        if (ni <= 1) PV_PL(VEC_, BM_, ST_, 1);                    \
+        else if (ni <= 2) PV_PL(VEC_, BM_, ST_, 2);               \
+        else PV_PL(VEC_, BM_, ST_, 4);                            \
+    }
+    if (vec == 4) {
+        if (bm == 4) { if (sh == 1) PV_PL_NI(4, 4, 1) else PV_PL_NI(4, 4, 2) }
+        else         { if (sh == 1) PV_PL_NI(4, 1, 1) else PV_PL_NI(4, 1, 2) }
+    } else {
+        if (bm == 4) { if (sh == 1) PV_PL_NI(1, 4, 1) else PV_PL_NI(1, 4, 2) }
+        else         { if (sh == 1) PV_PL_NI(1, 1, 1) else PV_PL_NI(1, 1, 2) }
+    }
+#undef PV_PL_NI
+#undef PV_PL
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -65,6 +65,8 @@ SIGNATURES = {
     'pvhip_lrn_f32': (_c.c_int, [_fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float]),
     'pvhip_lrn_maxpool_supported': (_c.c_int, [_c.c_int] * 5 + [_c.c_float, _c.c_float] + [_c.c_int] * 10),
     'pvhip_lrn_maxpool_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 5 + [_c.c_float] * 3 + [_c.c_int] * 10),
+    'pvhip_maxpool_lrn_supported': (_c.c_int, [_c.c_int] * 15 + [_c.c_float, _c.c_float]),
+    'pvhip_maxpool_lrn_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 15 + [_c.c_float] * 3),
     'pvhip_concat_f32': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _i64p, _fp, _c.c_int64]),
     'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -92,7 +94,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported',
+_NOT_STATUS = {'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 

@@ -348,7 +348,7 @@ class Executable_Network:
         self._fusion = {}               # conv node id -> {'bias': const id, 'add': id, 'relu': id or None}
         self._fused_away = set()        # node ids whose compute() is folded into their producer
         self._concat_direct = {}        # Concat node id -> total channels, when every input is written in place
-        self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it
+        self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it, or MaxPool id -> id of the LRN folded into it
         self._siblings = {}             # Convolution node id -> ids of the convolutions of the same input launched with it
         self._pool_conv = {}            # Convolution node id -> (MaxPool node folded into its input tile, id of the MaxPool's data input)
         self.fuse_siblings = os.environ.get('PVHIP_FUSE_SIBLINGS', '1') != '0'
@@ -403,7 +403,7 @@ class Executable_Network:
                 del node[key]
             for port in node.get('output', {}).values():
                 port.pop('data', None)
-            for key in ('result', 'param', '_sibling_out', '_fuse_bias', '_out_into', '_siblings', '_fuse_pool', '_fuse_pool_in'):
+            for key in ('result', 'param', '_sibling_out', '_fuse_bias', '_out_into', '_siblings', '_fuse_pool', '_fuse_pool_in', '_fuse_lrn'):
                 node.pop(key, None)
 
     def start_async(self, request_id: int, inputs: dict):
@@ -461,6 +461,20 @@ class Executable_Network:
                     continue
                 if lrn_plugin.pool_fusable(G.nodes[lid], G.nodes[succ[0]]):
                     self._lrn_pool[lid] = succ[0]
+                    self._fused_away.add(succ[0])
+        # the other order: a MaxPool whose only consumer is an LRN (GoogLeNet: pool1/3x3_s2 -> pool1/norm1)
+        pool_plugin = self.ienet.ie.plugins.plugins.get('MaxPool')
+        if pool_plugin is not None and getattr(pool_plugin, 'SUPPORTS_FUSED_LRN', False):
+            for pid in G.nodes:
+                if G.nodes[pid]['type'] != 'MaxPool' or pid in self._fused_away:
+                    continue
+                succ = list(G.successors(pid))
+                if len(succ) != 1 or G.nodes[succ[0]]['type'] != 'LRN' or G.edges[(pid, succ[0])]['connection'][3] != 0:
+                    continue
+                if succ[0] in self._lrn_pool or succ[0] in self._fused_away:
+                    continue                 # that LRN already leads an LRN -> MaxPool launch
+                if pool_plugin.lrn_fusable(G.nodes[pid], G.nodes[succ[0]]):
+                    self._lrn_pool[pid] = succ[0]
                     self._fused_away.add(succ[0])
         conv_plugin = self.ienet.ie.plugins.plugins.get('Convolution')
         if conv_plugin is None or not getattr(conv_plugin, 'SUPPORTS_FUSED_EPILOGUE', False):
@@ -803,11 +817,12 @@ class Executable_Network:
                                               'into': (self._concat_buffer(sf['into'][0]), sf['into'][1]) if sf['into'] is not None else None})
             else:
                 node.pop('_siblings', None)
-            pooled = self._lrn_pool.get(task)
+            pooled = self._lrn_pool.get(task)        # the node folded into this one: a MaxPool behind an LRN, or an LRN behind a MaxPool
+            fuse_key = '_fuse_pool' if node_type == 'LRN' else '_fuse_lrn'
             if pooled is not None:
-                node['_fuse_pool'] = G.nodes[pooled]
+                node[fuse_key] = G.nodes[pooled]
             else:
-                node.pop('_fuse_pool', None)
+                node.pop(fuse_key, None)
             plugin = registry.get(node_type)
             if plugin is None:
                 print("ERROR: Operation '{}' (node={}) is not supported.".format(node_type, node['name']))
@@ -850,7 +865,7 @@ class Executable_Network:
                             if nid is not None:
                                 out = G.nodes[nid]['output']
                                 out[next(iter(out))]['data'] = tensor
-                if pooled is not None:           # the folded MaxPool's port carries the tensor
+                if pooled is not None:           # the folded node's port carries the tensor
                     out = G.nodes[pooled]['output']
                     out[next(iter(out))]['data'] = next(iter(res.values()))
         if open_run is not None:

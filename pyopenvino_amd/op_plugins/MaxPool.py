@@ -6,6 +6,39 @@ from .. import common_def
 from .. import device as dev
 
 
+# The engine may hand over a 3x3 MaxPool whose only consumer is an LRN as one call: node['_fuse_lrn'] is then the LRN's node
+# dict, the kernel normalises the pooled values while it walks the channels and the pooled tensor (written once and read once
+# otherwise) never exists; what is returned is the LRN's output.  The engine asks lrn_fusable() first.
+SUPPORTS_FUSED_LRN = True
+
+
+def _geometry(node: dict, h: int, w: int):
+    attrs = node['data']
+    strides = common_def.string_to_tuple(attrs['strides'])
+    pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
+    pads_end = common_def.string_to_tuple(attrs['pads_end'])
+    kernel = common_def.string_to_tuple(attrs['kernel'])
+    oh, ow = calc_output_shape((h, w), kernel, strides, pads_begin, pads_end, attrs['rounding_type'], attrs['auto_pad'])
+    return kernel, strides, pads_begin, pads_end, oh, ow
+
+
+def lrn_fusable(node: dict, lrn_node: dict) -> bool:
+    """True when libpvhip's fused MaxPool -> LRN kernel covers this pair (shapes from the IR ports; no device needed)."""
+    try:
+        dims = node['input'][0]['dims']
+        if len(dims) != 4 or node['input'][0]['precision'] != 'FP32':
+            return False
+        n, c, h, w = (int(d) for d in dims)
+        kernel, strides, pads_begin, pads_end, oh, ow = _geometry(node, h, w)
+        if len(kernel) != 2 or tuple(lrn_node['output'][common_def.first_output_port(lrn_node)]['dims']) != (n, c, oh, ow):
+            return False
+        la = lrn_node['data']
+        return bool(dev.call('pvhip_maxpool_lrn_supported', n, c, h, w, oh, ow, kernel[0], kernel[1], strides[0], strides[1],
+                             pads_begin[0], pads_begin[1], pads_end[0], pads_end[1], int(la['size']), float(la['beta']), float(la['bias'])))
+    except (KeyError, ValueError, AssertionError):
+        return False
+
+
 def name():
     print('MaxPool')
 
@@ -32,6 +65,13 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         # np.max over an empty patch (MaxPool.py:69-70)
         raise ValueError('zero-size array to reduction operation maximum which has no identity')
     y = dev.DeviceTensor.empty((n, c, oh, ow))
+    lrn_node = node.get('_fuse_lrn')
+    if lrn_node is not None:
+        la = lrn_node['data']
+        dev.call('pvhip_maxpool_lrn_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, oh, ow,
+                 kernel[0], kernel[1], strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1],
+                 int(la['size']), float(la['alpha']), float(la['beta']), float(la['bias']))
+        return {common_def.first_output_port(node): y}
     dev.call('pvhip_maxpool2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, oh, ow,
              kernel[0], kernel[1], strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1])
     return {common_def.first_output_port(node): y}

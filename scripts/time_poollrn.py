@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""GPU-box tool: GoogLeNet's pool1/3x3_s2 + pool1/norm1 at batch 256 as one launch against the two launches; checks the bits too."""
+import os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from pyopenvino_amd import device as dev, synth
+import ctypes as _c
+dev.init(0)
+n, c, h, w = 256, 64, 112, 112
+oh = ow = 56
+P = _c.c_void_p
+x = dev.DeviceTensor.from_numpy(np.maximum(synth.normal(1, 2, n * c * h * w), 0).astype(np.float32).reshape((n, c, h, w)))
+y = dev.DeviceTensor.empty((n, c, oh, ow), np.float32)
+t = dev.DeviceTensor.empty((n, c, oh, ow), np.float32)
+y2 = dev.DeviceTensor.empty((n, c, oh, ow), np.float32)
+al, be, bi = _c.c_float(1e-4), _c.c_float(0.75), _c.c_float(1.0)
+def fused():
+    dev.call('pvhip_maxpool_lrn_f32', P(x.ptr), P(y.ptr), n, c, h, w, oh, ow, 3, 3, 2, 2, 0, 0, 0, 0, 5, al, be, bi)
+def two():
+    dev.call('pvhip_maxpool2d_f32', P(x.ptr), P(t.ptr), n, c, h, w, oh, ow, 3, 3, 2, 2, 0, 0, 0, 0)
+    dev.call('pvhip_lrn_f32', P(t.ptr), P(y2.ptr), n, c, oh * ow, 5, al, be, bi)
+for name, f in (('one launch', fused), ('two launches', two)):
+    for _ in range(3):
+        f()
+    dev.synchronize()
+    e0 = dev.Event().record()
+    for _ in range(10):
+        f()
+    e1 = dev.Event().record(); e1.synchronize()
+    ms = e0.elapsed_ms(e1) / 10
+    mb = (x.nbytes + y.nbytes) / 1e6
+    print('{:13s} {:.3f} ms  {:.0f} GB/s of input + output'.format(name, ms, mb / ms))
+a, b = np.asarray(y), np.asarray(y2)
+print('same bits:', bool((a.view(np.uint32) == b.view(np.uint32)).all()))

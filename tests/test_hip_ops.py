@@ -704,6 +704,53 @@ def test_fused_lrn_maxpool_has_the_bits_of_the_two_launches(hip, xs, st, pb, pe,
     assert_bit_exact(got, two, 'fused LRN+MaxPool vs two launches {}'.format(xs))
 
 
+@pytest.mark.parametrize('xs,st,pb,pe,rounding', [((2, 64, 112, 112), (2, 2), (0, 0), (0, 0), 'ceil'),     # GoogLeNet pool1 -> norm1
+                                                   ((1, 16, 13, 11), (2, 2), (0, 0), (0, 0), 'ceil'),
+                                                   ((3, 8, 9, 20), (1, 1), (1, 1), (1, 1), 'floor'),
+                                                   ((2, 24, 28, 28), (1, 1), (1, 1), (1, 1), 'floor'),     # several outputs per lane
+                                                   ((1, 40, 7, 7), (2, 2), (0, 0), (1, 1), 'ceil')])
+def test_fused_maxpool_lrn_has_the_bits_of_the_two_launches(hip, xs, st, pb, pe, rounding):
+    """3x3 MaxPool -> LRN as one launch (node['_fuse_lrn']): the oracle's MaxPool then LRN within the tolerance of the LRN, and
+    bit for bit what the two HIP launches give (a NaN in the input included)."""
+    x = rnd(sum(xs), xs, 40.0)
+    x[0, 1, 2, 3] = np.nan if xs[0] == 1 and xs[1] == 16 else x[0, 1, 2, 3]
+    axes = np.array([1], dtype=np.int64)
+    pool_node = make_node('MaxPool', [x], pool_data((3, 3), st, pb, pe, rounding))
+    pooled = first_out(oracle_plugin('MaxPool').compute(pool_node, {0: x}, kernel_type='special'))
+    lrn_data = {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'}
+    lrn_node = make_node('LRN', [pooled, axes], lrn_data)
+    want = first_out(oracle_plugin('LRN').compute(lrn_node, {0: pooled, 1: axes}, kernel_type='special'))
+    lrn_node['output'][2]['dims'] = tuple(want.shape)
+    pool_plugin = hip_plugin('MaxPool')
+    assert pool_plugin.lrn_fusable(pool_node, lrn_node)
+    two_a = first_out(pool_plugin.compute(dict(pool_node), {0: x}))
+    two = first_out(hip_plugin('LRN').compute(dict(lrn_node), {0: two_a, 1: axes}))
+    fused_node = dict(pool_node)
+    fused_node['_fuse_lrn'] = lrn_node
+    got = first_out(pool_plugin.compute(fused_node, {0: x}))
+    finite = np.isfinite(want)
+    assert (np.isfinite(got) == finite).all()
+    assert_close(np.where(finite, got, 0.0), np.where(finite, want, 0.0), helpers.REL_TOL, 'fused MaxPool+LRN {}'.format(xs))
+    assert_bit_exact(got, two, 'fused MaxPool+LRN vs two launches {}'.format(xs))
+
+
+def test_fused_maxpool_lrn_declines_what_it_does_not_cover(hip):
+    pool_plugin = hip_plugin('MaxPool')
+    axes = np.array([1], dtype=np.int64)
+    def pair(xs, size='5', beta='0.75', kernel=(3, 3), st=(2, 2)):
+        x = np.zeros(xs, dtype=np.float32)
+        pn = make_node('MaxPool', [x], pool_data(kernel, st, (0, 0), (0, 0), 'ceil'))
+        oh, ow = pool_plugin.calc_output_shape(xs[2:], kernel, st, (0, 0), (0, 0), 'ceil', 'explicit')
+        ln = make_node('LRN', [np.zeros((xs[0], xs[1], oh, ow), dtype=np.float32), axes], {'alpha': '1e-4', 'beta': beta, 'bias': '1', 'size': size})
+        ln['output'][2]['dims'] = (xs[0], xs[1], oh, ow)
+        return pn, ln
+    assert pool_plugin.lrn_fusable(*pair((2, 64, 112, 112)))
+    assert not pool_plugin.lrn_fusable(*pair((2, 60, 112, 112)))           # channels not a multiple of 8
+    assert not pool_plugin.lrn_fusable(*pair((2, 64, 112, 112), size='3'))
+    assert not pool_plugin.lrn_fusable(*pair((2, 64, 112, 112), beta='0.6'))
+    assert not pool_plugin.lrn_fusable(*pair((2, 64, 112, 112), kernel=(2, 2)))
+
+
 def test_fused_lrn_maxpool_declines_what_it_does_not_cover(hip):
     lrn_plugin = hip_plugin('LRN')
     axes = np.array([1], dtype=np.int64)

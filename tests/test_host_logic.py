@@ -213,8 +213,8 @@ def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
                     assert position[w] < position[task]
                     assert stream_of[w] == st or (w in waits[task] and w in records), (G.nodes[task]['name'], G.nodes[w]['name'])
         by_name = {G.nodes[n]['name']: n for n in G.nodes}
-        # LRN -> MaxPool pairs the fused kernel covers are one dispatched task (conv2/norm2 -> pool2; pool1 -> norm1 is the other order)
-        assert ex._lrn_pool == ({by_name['conv2/norm26321']: by_name['pool2/3x3_s2']} if fuse else {})
+        # LRN -> MaxPool and MaxPool -> LRN pairs the fused kernels cover are one dispatched task each (conv2/norm2 -> pool2; pool1 -> norm1)
+        assert ex._lrn_pool == ({by_name['conv2/norm26321']: by_name['pool2/3x3_s2'], by_name['pool1/3x3_s2']: by_name['pool1/norm16325']} if fuse else {})
         conv = lambda a: by_name['inception_3a/' + a + '/WithoutBiases']
         if fuse:     # 1x1 + 3x3_reduce + 5x5_reduce are one launch; behind it and the pool three arms run side by side
             assert ex._siblings[conv('1x1')] == [conv('3x3_reduce'), conv('5x5_reduce')] and len(ex._siblings) == 9
