@@ -482,8 +482,8 @@ def main():
                     name = G.nodes[pin[0]]['name'] + ' + ' + name
                     family = 'MaxPool + 1x1 (conv_pool1x1_kernel)'
                 pooled = getattr(ex, '_lrn_pool', {}).get(nid)
-                if pooled is not None:   # LRN and the MaxPool behind it as one launch: reads the LRN input once, writes the pooled tensor once
-                    typ = family = 'LRN+MaxPool'
+                if pooled is not None:   # LRN and the MaxPool behind it (or the other order) as one launch: reads the first one's input once, writes the second one's output once
+                    typ = family = 'LRN+MaxPool' if typ == 'LRN' else 'MaxPool+LRN'
                     lrn_in = G.nodes[nid]['input'][0]['dims']
                     pool_out = next(iter(G.nodes[pooled]['output'].values()))['dims']
                     by = 4.0 * (int(np.prod(lrn_in)) + int(np.prod(pool_out)))
