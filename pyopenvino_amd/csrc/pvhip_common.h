@@ -49,6 +49,7 @@ struct Settings {
     int  wino_kb = 0;                      // PVHIP_WINO_KB=32|64
     bool wino_small = true;                // PVHIP_WINO_SMALL=0
     int  wino_waves = 8;                   // PVHIP_WINO_WAVES=4
+    bool wino_ragged = true;               // PVHIP_WINO_RAGGED=0: the six-point Winograd kernel only where the extents are multiples of its patch (A/B runs)
     bool wino_balance = true;              // PVHIP_WINO_BALANCE=0: fixed producer waves in the six-point Winograd kernel (A/B runs)
     // ---- wrong-on-purpose ablations: honoured only by the diagnostic build (make diag -> libpvhip_diag.so, -DPVHIP_DIAG)
     int  conv_ablate = 0, wino4_ablate = 0, pw_ablate = 0;

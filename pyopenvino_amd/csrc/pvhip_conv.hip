@@ -1001,7 +1001,7 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
         const int rc = pw_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out, c);
         if (rc) return rc;
     }
-    if (kh == 5 && kw == 5 && wino4_pack_elems(k_out, c) > 0 && h % 2 == 0 && w % 2 == 0) {
+    if (kh == 5 && kw == 5 && wino4_pack_elems(k_out, c) > 0) {          // used or not: wino25_eligible (extents, batch)
         const int rc = wino25_pack(w_oihw, wp + (size_t)(kred_pad + kPanelSpare) * kout_pad, k_out, c);
         if (rc) return rc;
     }
@@ -1009,7 +1009,7 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
         float* const u2 = wp + (size_t)(kred_pad + kPanelSpare) * kout_pad;
         int rc = wino_pack(w_oihw, u2, k_out, c);
         if (rc) return rc;
-        if (h % 4 == 0 && w % 4 == 0) {       // the F(4x4, 3x3) panel behind it (whether it is used depends on the batch too)
+        {                                     // the F(4x4, 3x3) panel behind it (whether it is used depends on extents and batch: wino4_eligible)
             rc = wino4_pack(w_oihw, u2 + wino_pack_elems(k_out, c), k_out, c);
             if (rc) return rc;
         }

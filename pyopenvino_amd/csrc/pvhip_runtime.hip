@@ -63,6 +63,7 @@ void load_settings() {
     s.wino_small = !is0("PVHIP_WINO_SMALL");
     s.wino_waves = num("PVHIP_WINO_WAVES", 8) == 4 ? 4 : 8;
     s.wino_balance = num("PVHIP_WINO_BALANCE", 1) != 0;
+    s.wino_ragged = num("PVHIP_WINO_RAGGED", 1) != 0;
 #ifdef PVHIP_DIAG
     s.conv_ablate  = num("PVHIP_CONV_ABLATE", 0);
     s.wino4_ablate = num("PVHIP_WINO4_ABLATE", 0);

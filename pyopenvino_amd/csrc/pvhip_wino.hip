@@ -566,7 +566,11 @@ __device__ __forceinline__ void wino4_bt_row(w4_float2v pa, w4_float2v pb, w4_fl
 // of a tile they gather stages 0 / 1 of the next tile and transform its stage 0, so that the next tile's main loop starts as soon as
 // the epilogue is over (one workgroup per tile spent 15 k cycles of a 50-110 k cycle life between its first instruction and its first
 // MFMA, and two workgroups per CU cannot cover that for each other: s_memtime stamps, scripts/stamps_wino4.py).
-template <int M, int ABL>   // ABL: diagnostic ablations (wrong results on purpose): 1 no gather, 2 no transform, 3 no MFMA, 4 no U DMA
+// RAGGED: extents that are not multiples of M (14x14, 7x7): the last patch of a row / column hangs over the edge; its input columns
+// at and beyond the width are zeroed after the load (the row behind them belongs to the next row), rows beyond the height are
+// out-of-range offsets, and the epilogue stores only what exists.  F(4x4,3x3) on 14x14 executes 0.33 of the direct multiplies
+// (16x16 computed for 14x14) against F(2x2)'s 0.44; on 7x7 0.33 against 0.58.
+template <int M, int ABL, bool RAGGED = false>   // ABL: diagnostic ablations (wrong results on purpose): 1 no gather, 2 no transform, 3 no MFMA, 4 no U loads
 __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     static_assert(M == 4 || M == 2, "F(4x4,3x3) or F(2x2,5x5)");
     constexpr int PAD = (M == 4) ? 1 : 2;               // 6 = M + kernel - 1 input rows / columns starting at M*t - PAD
@@ -669,6 +673,9 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         const int n_ = tc / TPI, rem_ = tc - n_ * TPI;                                                           \
         const int ty_ = rem_ / a.TX, tx_ = rem_ - ty_ * a.TX;                                                    \
         float* __restrict__ const yp0 = a.y + (((size_t)n_ * a.y_ctotal + a.y_coff) * OH + M * ty_) * OW + M * tx_; \
+        const int  rows_ok = min(M, OH - M * ty_), cols_ok = min(M, OW - M * tx_);                               \
+        const bool even_w = (OW & 1) == 0;                                                                       \
+        (void)rows_ok; (void)cols_ok; (void)even_w;                                                              \
         _Pragma("unroll") for (int pass = 0; pass < PASSES; ++pass) {                                            \
             if (pass == 1) __syncthreads();                                                                      \
             WRITE_(pass);                                                                                        \
@@ -697,7 +704,17 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                             else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; } \
                             ov[c2] = v;                                                                          \
                         }                                                                                        \
-                        if (M == 4) *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = make_float4(ov[0], ov[1], ov[2], ov[3]); \
+                        if (RAGGED) {            /* only what exists; pairs where the rows are 8-byte aligned (even width) */ \
+                            if (r2 < rows_ok) {                                                                  \
+                                _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {                            \
+                                    if (even_w && c2 + 1 < cols_ok) *reinterpret_cast<float2*>(yp + (size_t)r2 * OW + c2) = make_float2(ov[c2], ov[c2 + 1]); \
+                                    else {                                                                       \
+                                        if (c2 < cols_ok) yp[(size_t)r2 * OW + c2] = ov[c2];                     \
+                                        if (c2 + 1 < cols_ok) yp[(size_t)r2 * OW + c2 + 1] = ov[c2 + 1];         \
+                                    }                                                                            \
+                                }                                                                                \
+                            }                                                                                    \
+                        } else if (M == 4) *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = make_float4(ov[0], ov[1], ov[2], ov[3]); \
                         else        *reinterpret_cast<float2*>(yp + (size_t)r2 * OW) = make_float2(ov[0], ov[1]); \
                     }                                                                                            \
                 }                                                                                                \
@@ -724,9 +741,10 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         unsigned rowo[6];                 // byte offset of (row, first inner column) of this lane's channel
         unsigned eo[6];                   // edge lanes: offset of the outer column(s) of row r; every other lane: out of range
         bool     zlo, zhi, zlo_n, zhi_n;
+        int      nv = M | 256, nv_n = M | 256;    // RAGGED: which columns of the lane's patch exist (see PVW4_ADDRESSES)
         const bool first = l31 == 0, last = l31 == 31;
         // addresses of a tile's patches (a tile past the end: every row out of range -- zeros, no traffic)
-#define PVW4_ADDRESSES(tile_, zl_, zh_)                                                                          \
+#define PVW4_ADDRESSES(tile_, zl_, zh_, nv_)                                                                       \
     {                                                                                                            \
         const int  t    = ((tile_) / a.n_kb) * NT + l31;                                                         \
         const bool live = (tile_) < n_tiles && t < a.T;                                                          \
@@ -735,6 +753,8 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + M * tx) * 4u;                              \
         zl_ = tx == 0;                                                                                           \
         zh_ = tx == a.TX - 1;                                                                                    \
+        /* RAGGED: bits 0-7 the inner columns that exist, bit 8: the SECOND column a last lane loads for itself exists (M = 2) */ \
+        if (RAGGED) nv_ = min(M, a.W - M * tx) | ((M * tx + M + 1 < a.W) ? 256 : 0);                             \
         /* M = 4: inner columns 1..4 are the lane's own 16 bytes; first lane: column 0 (4 bytes before; on the left border the */ \
         /* value is zeroed anyway: stay in place); last lane: column 5 (16 bytes after; on the right border: 12).               */ \
         /* M = 2: inner columns 2..3 are the lane's own 8 bytes; first lane: columns 0..1 (8 bytes before), last: 4..5 (8 after). */ \
@@ -776,11 +796,15 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         }                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
     }
-#define PVW4_TRANSFORM_STORE(v_, e_, Vb_, zl_, zh_)                                                              \
+#define PVW4_TRANSFORM_STORE(v_, e_, Vb_, zl_, zh_, nv_)                                                              \
     {                                                                                                            \
         /* the six columns of row r as three pairs: lo = from the left neighbour (wave_shr:1; own load in the first lane), */ \
         /* hi = from the right neighbour (wave_shl:1; own load in the last lane), own = the lane's load                     */ \
         float2v pa[6], pb[6], pc[6];                                                                             \
+        if (RAGGED) {            /* columns at / beyond the width: zero (before the neighbours read them by DPP) */ \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                        \
+                _Pragma("unroll") for (int q = 1; q < M; ++q) v_[r][q] = q < ((nv_) & 255) ? v_[r][q] : 0.0f;   \
+        }                                                                                                        \
         _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
             constexpr int NB = (M == 4) ? 1 : 2;              /* columns taken from each neighbour */             \
             float lo_[NB], hi_[NB];                                                                              \
@@ -789,7 +813,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                 const float nl = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)v_[r][M - NB + q]), 0x138, 0xf, 0xf, true)); \
                 const float nh = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)v_[r][q]), 0x130, 0xf, 0xf, true)); \
                 lo_[q] = zl_ ? 0.0f : (first ? w4_edge(e_[r], q) : nl);                                          \
-                hi_[q] = zh_ ? 0.0f : (last ? w4_edge(e_[r], q) : nh);                                           \
+                hi_[q] = zh_ ? 0.0f : (last ? ((RAGGED && q >= 1 && !((nv_) & 256)) ? 0.0f : w4_edge(e_[r], q)) : nh); \
             }                                                                                                    \
             if (M == 4) {                                                                                        \
                 pa[r] = float2v{v_[r][0], v_[r][1]};                                                             \
@@ -822,10 +846,10 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         }                                                                                                        \
     }
         int tile = L;
-        PVW4_ADDRESSES(tile, zlo, zhi);
+        PVW4_ADDRESSES(tile, zlo, zhi, nv);
         PVW4_GATHER(vA, eA, 0);
         PVW4_GATHER(vB, eB, 1);
-        PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo, zhi);
+        PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo, zhi, nv);
         t_head = PVW4_NOW() - t_entry;
         for (;;) {
             __syncthreads();              // V(0) of this tile is in V0
@@ -835,29 +859,30 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                 PVW4_GATHER(vA, eA, s + 2);
                 const unsigned long long t1 = PVW4_NOW();
                 const unsigned long long t2 = PVW4_NOW();
-                PVW4_TRANSFORM_STORE(vB, eB, sm.V1, zlo, zhi);
+                PVW4_TRANSFORM_STORE(vB, eB, sm.V1, zlo, zhi, nv);
                 const unsigned long long t3 = PVW4_NOW();
                 __syncthreads();
                 const unsigned long long t4 = PVW4_NOW();
                 PVW4_GATHER(vB, eB, s + 3);
                 const unsigned long long u1 = PVW4_NOW();
                 const unsigned long long u2 = PVW4_NOW();
-                PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo, zhi);
+                PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo, zhi, nv);
                 const unsigned long long u3 = PVW4_NOW();
                 __syncthreads();
                 const unsigned long long u4 = PVW4_NOW();
                 st[0] += (t1 - t0) + (u1 - t4); st[1] += (t2 - t1) + (u2 - u1); st[2] += (t3 - t2) + (u3 - u2); st[3] += (t4 - t3) + (u4 - u3);
             }
             // the last two stages: the gathers are stages 0 / 1 of the NEXT tile, and the second transform its stage 0
-            PVW4_ADDRESSES(tile + G, zlo_n, zhi_n);
+            PVW4_ADDRESSES(tile + G, zlo_n, zhi_n, nv_n);
             PVW4_GATHER(vA, eA, 0);
-            PVW4_TRANSFORM_STORE(vB, eB, sm.V1, zlo, zhi);
+            PVW4_TRANSFORM_STORE(vB, eB, sm.V1, zlo, zhi, nv);
             __syncthreads();
             PVW4_GATHER(vB, eB, 1);
-            PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo_n, zhi_n);
+            PVW4_TRANSFORM_STORE(vA, eA, sm.V0, zlo_n, zhi_n, nv_n);
             __syncthreads();
             zlo = zlo_n;
             zhi = zhi_n;
+            nv  = nv_n;
             const unsigned long long e0 = PVW4_NOW();
             PVW4_EPILOGUE(PVW4_EPI_NOWRITE, tile);
             t_epi += PVW4_NOW() - e0;
@@ -1014,10 +1039,12 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
 bool wino4_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int h, int w, int oh, int ow, int n) {
     const int mode = settings().conv_winograd4;                // PVHIP_CONV_WINOGRAD4: 0 = F(2x2, 3x3) everywhere, 2 = "force"
     if (mode == 0 || !wino_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return false;
-    if (h % 4 != 0 || w % 4 != 0) return false;
-    // 512 output pixels per workgroup: worth it where the patch blocks alone give every CU a workgroup
-    const long patches = (long)n * (h / 4) * (w / 4);
-    const long min_patches = mode == 2 ? 1 : 32L * kNumCU;           // "force": any size (tests)
+    const bool ragged = h % 4 != 0 || w % 4 != 0;                 // 14x14, 7x7: the last patches hang over the edge
+    if (ragged && !settings().wino_ragged) return false;
+    // 512 output pixels per workgroup: worth it where the patch blocks alone give every CU a workgroup; the ragged layers have
+    // fewer, larger-than-needed patches and win on the multiply count from 1024 patches on (7x7 at batch 256)
+    const long patches = (long)n * ((h + 3) / 4) * ((w + 3) / 4);
+    const long min_patches = mode == 2 ? 1 : (ragged ? 1024L : 32L * kNumCU);           // "force": any size (tests)
     return patches >= min_patches;
 }
 
@@ -1028,9 +1055,10 @@ bool wino25_eligible(int c, int kh, int kw, int sh, int sw, int pad_top, int pad
     if (mode == 0 || !settings().conv_winograd) return false;
     if (!(kh == 5 && kw == 5 && sh == 1 && sw == 1 && pad_top == 2 && pad_left == 2 && oh == h && ow == w && c % kCB == 0 && c >= kCB))
         return false;
-    if (h % 2 != 0 || w % 2 != 0) return false;
-    const long patches = (long)n * (h / 2) * (w / 2);
-    return patches >= (mode == 2 ? 1 : 32L * kNumCU);
+    const bool ragged = h % 2 != 0 || w % 2 != 0;
+    if (ragged && !settings().wino_ragged) return false;
+    const long patches = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
+    return patches >= (mode == 2 ? 1 : (ragged ? 4096L : 32L * kNumCU));
 }
 
 int wino25_pack(const float* w_oihw, float* u, int k, int c) {
@@ -1061,7 +1089,8 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     WinoArgs a;
     a.x = x; a.u = u; a.y = y; a.bias = bias;
     a.N = n; a.C = c; a.H = h; a.W = w; a.K = k_out;
-    a.TY = h / m; a.TX = w / m;
+    a.TY = (h + m - 1) / m; a.TX = (w + m - 1) / m;
+    const bool ragged = h % m != 0 || w % m != 0;
     a.T  = n * a.TY * a.TX;
     a.n_kb = (k_out + 31) / 32;
     a.balance = settings().wino_balance ? 1 : 0;
@@ -1076,7 +1105,14 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     // persistent: two workgroups per CU (72 KB of LDS each), each walking tiles L, L + G, ...
     const dim3 grid((unsigned)(a.n_tiles < 2 * kNumCU ? a.n_tiles : 2 * kNumCU));
     if (m == 2) {
-        hipLaunchKernelGGL((conv_wino4_kernel<2, 0>), grid, dim3(512), 0, state().stream, a);
+        if (ragged) hipLaunchKernelGGL((conv_wino4_kernel<2, 0, true>), grid, dim3(512), 0, state().stream, a);
+        else        hipLaunchKernelGGL((conv_wino4_kernel<2, 0>), grid, dim3(512), 0, state().stream, a);
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
+    if (ragged) {
+        hipLaunchKernelGGL((conv_wino4_kernel<4, 0, true>), grid, dim3(512), 0, state().stream, a);
+        PVHIP_LAUNCH_CHECK();
         return PVHIP_OK;
     }
 #ifdef PVHIP_DIAG
@@ -1090,6 +1126,7 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     }
 #endif
     hipLaunchKernelGGL((conv_wino4_kernel<4, 0>), grid, dim3(512), 0, state().stream, a);
+    PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }
 

@@ -109,7 +109,11 @@ def kernel_kind(node: dict):
     oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
     code = dev.call('pvhip_conv2d_kernel_kind', int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3]), oh, ow,
                     strides[0], strides[1], pb[0], pb[1])
-    return KERNEL_KINDS[int(code)]
+    family, frac = KERNEL_KINDS[int(code)]
+    m = {2: 2, 3: 4, 4: 2}.get(int(code))          # Winograd: whole m x m output patches are computed (14x14 as 16x16 under F(4x4))
+    if m:
+        frac *= (-(-oh // m) * m) * (-(-ow // m) * m) / float(oh * ow)
+    return family, frac
 
 
 def pooled_fusable(node: dict, pool_node: dict) -> bool:

@@ -9,7 +9,7 @@ sys.path.insert(0, REPO)
 from pyopenvino_amd import device as dev, synth
 from pyopenvino_amd.op_plugins import Convolution
 
-LAYERS = [('conv2/3x3', (256, 64, 56, 56), 192, 3), ('3a/3x3', (256, 96, 28, 28), 128, 3), ('3b/3x3', (256, 128, 28, 28), 192, 3),
+LAYERS = [('4a/3x3', (256, 96, 14, 14), 208, 3), ('4c/3x3', (256, 128, 14, 14), 256, 3), ('4d/3x3', (256, 144, 14, 14), 288, 3), ('5a/3x3', (256, 160, 7, 7), 320, 3), ('5b/3x3', (256, 192, 7, 7), 384, 3), ('5a/5x5', (256, 32, 7, 7), 128, 5), ('5b/5x5', (256, 48, 7, 7), 128, 5), ('conv2/3x3', (256, 64, 56, 56), 192, 3), ('3a/3x3', (256, 96, 28, 28), 128, 3), ('3b/3x3', (256, 128, 28, 28), 192, 3),
           ('4e/3x3', (256, 160, 14, 14), 320, 3),
           ('3a/5x5', (256, 16, 28, 28), 32, 5), ('3b/5x5', (256, 32, 28, 28), 96, 5), ('4a/5x5', (256, 16, 14, 14), 48, 5),
           ('4b/5x5', (256, 24, 14, 14), 64, 5), ('4d/5x5', (256, 32, 14, 14), 64, 5), ('4e/5x5', (256, 32, 14, 14), 128, 5)]
