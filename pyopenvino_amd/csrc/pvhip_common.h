@@ -32,7 +32,7 @@ struct Settings {
     int  conv_winograd4 = 1;     // PVHIP_CONV_WINOGRAD4: 0 off, 1 by size rule, 2 ("force") any size
     int  conv_winograd5 = 1;     // PVHIP_CONV_WINOGRAD5: likewise for F(2x2,5x5)
     bool conv_pointwise = true;  // PVHIP_CONV_POINTWISE=0: 1x1 layers on the general LDS-DMA kernel
-    int  fuse_poolconv  = 1;     // PVHIP_FUSE_POOLCONV: 0 off, 1 rows of whole 16-byte groups, 2 also 8-byte groups
+    int  fuse_poolconv  = 1;     // PVHIP_FUSE_POOLCONV: 0 off, 1 rows of whole 16- or 8-byte groups, 4 only 16-byte groups (A/B runs)
     bool pool3          = true;  // PVHIP_POOL3=0: the one-shot MaxPool kernel for 3x3 windows too
     // ---- tuning runs (scripts/): defaults are what the product uses
     int  tile_bm = 0, tile_bn = 0;         // PVHIP_CONV_TILE=BMxBN

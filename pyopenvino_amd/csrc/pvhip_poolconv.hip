@@ -46,6 +46,16 @@ __device__ __forceinline__ void pc_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst
 #endif
 }
 
+typedef float pc_f4 __attribute__((ext_vector_type(4)));
+typedef float pc_f2 __attribute__((ext_vector_type(2)));
+// a buffer load as wide as its destination (the whole vector is cast: see pvhip_wino.hip)
+__device__ __forceinline__ void pc_load(pc_f4& d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    d = __builtin_bit_cast(pc_f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void pc_load(pc_f2& d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    d = __builtin_bit_cast(pc_f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
 template <int BM, int VEC>
 __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
     constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
@@ -85,54 +95,64 @@ __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
         const int pl = (wid - CONSUMERS) * kWave + lane;       // 0 .. 255
         const int g = pl % GROUPS, cc = pl / GROUPS;
-        // byte offsets of this lane's group in rows y-1, y, y+1 (channel cc of the stage; image and pixel folded in) and of
-        // the columns left and right of it; whatever lies outside the image is out of range and reads as the pad value 0.0
-        unsigned offv[3], offl[3], offr[3];
+        // byte offsets of this lane's group in rows y-1, y, y+1 (channel cc of the stage; image and pixel folded in); whatever lies
+        // outside the image is out of range and reads as the pad value 0.0.  The columns left and right of the group are the
+        // neighbouring LANES' outer columns: their column maxima come over by DPP (wave_shr / wave_shl) when the pooling runs, so a
+        // pooled value costs 3 / VEC vector loads, not 9 / VEC loads (the first version; at VEC = 2 -- the 14x14 modules -- that made
+        // the fused launch slower than the two).  Only the first and the last group of the tile's row of groups load their outer
+        // column themselves (one more dword load per row, live in two lanes of GROUPS).
+        unsigned offv[3], offe[3];
+        bool     zl, zr;                         // the group touches the left / right border: its outer column is padding
+        const bool first = g == 0, last = g == GROUPS - 1;
         {
             const int gp = ptile * BN + g * VEC;
             const bool live = gp < a.P;
             const int n = live ? gp / HW : 0, rem = live ? gp - n * HW : 0;
             const int y = rem / a.W, x0 = rem - y * a.W;
             const unsigned base = (unsigned)((n * a.C + cc) * HW + x0) * 4u;
+            zl = x0 == 0;
+            zr = x0 + VEC >= a.W;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int  iy = y - 1 + r;
                 const bool ok = live && (unsigned)iy < (unsigned)a.H;
                 offv[r] = ok ? base + (unsigned)(iy * a.W) * 4u : kOob;
-                offl[r] = (ok && x0 > 0) ? base + (unsigned)(iy * a.W) * 4u - 4u : kOob;
-                offr[r] = (ok && x0 + VEC < a.W) ? base + (unsigned)(iy * a.W) * 4u + (unsigned)VEC * 4u : kOob;
+                offe[r] = (ok && first && !zl) ? offv[r] - 4u : ((ok && last && !zr) ? offv[r] + (unsigned)VEC * 4u : kOob);
             }
         }
-        float ring[ITER][3][VEC + 2];       // per iteration and row: left neighbour, the group, right neighbour
+        vec_t ring[ITER][3];                 // per iteration and row: the group
+        float edge[ITER][3];                 //                        first / last lane: its outer column
 #define PVP_LOAD(it_, s_)                                                                                        \
     {                                                                                                            \
         const int se_ = (s_) < nk ? (s_) : nk - 1;                 /* past the end: the last stage again (unused) */ \
         const unsigned soff = (unsigned)(se_ * kBK + (it_) * CSUB) * chan_bytes;                                 \
         _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
-            ring[it_][r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offl[r], soff, 0)); \
-            if (VEC == 4) {                                                                                      \
-                typedef float f4_ __attribute__((ext_vector_type(4)));     /* whole-vector cast: see pvhip_wino.hip */ \
-                const f4_ q_ = __builtin_bit_cast(f4_, __builtin_amdgcn_raw_buffer_load_b128(xr, offv[r], soff, 0)); \
-                ring[it_][r][1] = q_.x; ring[it_][r][2] = q_.y; ring[it_][r][3] = q_.z; ring[it_][r][VEC] = q_.w; \
-            } else {                                                                                             \
-                typedef float f2_ __attribute__((ext_vector_type(2)));                                           \
-                const f2_ q_ = __builtin_bit_cast(f2_, __builtin_amdgcn_raw_buffer_load_b64(xr, offv[r], soff, 0)); \
-                ring[it_][r][1] = q_.x; ring[it_][r][VEC] = q_.y;                                                \
-            }                                                                                                    \
-            ring[it_][r][VEC + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offr[r], soff, 0)); \
+            pc_load(ring[it_][r], xr, offv[r], soff);                                                            \
+            edge[it_][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offe[r], soff, 0));  \
         }                                                                                                        \
     }
-        // 3x3 max of iteration it_ into the B tile of buffer buf_ (columns first: one max3 and one NaN test per column of the
-        // group's 3 x (VEC + 2) patch, then a max3 over three adjacent columns per pixel), then the same registers fetch stage s_next_
+        // 3x3 max of iteration it_ into the B tile of buffer buf_ (columns first: one max3 and one NaN test per column, the
+        // outer columns' from the neighbour lanes, then a max3 over three adjacent columns per pixel), then the same registers
+        // fetch stage s_next_
 #define PVP_POOL(it_, buf_, s_next_)                                                                             \
     {                                                                                                            \
         float cm_[VEC + 2];                                                                                      \
-        bool  cn_[VEC + 2];                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < VEC + 2; ++c) {                                                    \
+        int   cn_[VEC + 2];                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < VEC; ++c) {                                                        \
             const float e0 = ring[it_][0][c], e1 = ring[it_][1][c], e2 = ring[it_][2][c];                        \
-            cm_[c] = fmaxf(fmaxf(e0, e1), e2);                                                                   \
-            cn_[c] = __builtin_isunordered(e0, e1) | (e2 != e2);                                                 \
+            cm_[c + 1] = fmaxf(fmaxf(e0, e1), e2);                                                               \
+            cn_[c + 1] = (__builtin_isunordered(e0, e1) | (e2 != e2)) ? 1 : 0;                                   \
         }                                                                                                        \
+        const float em_ = fmaxf(fmaxf(edge[it_][0], edge[it_][1]), edge[it_][2]);                                \
+        const int   en_ = (__builtin_isunordered(edge[it_][0], edge[it_][1]) | (edge[it_][2] != edge[it_][2])) ? 1 : 0; \
+        const float lm_ = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, cm_[VEC]), 0x138, 0xf, 0xf, true)); \
+        const int   ln_ = __builtin_amdgcn_mov_dpp(cn_[VEC], 0x138, 0xf, 0xf, true);                             \
+        const float rm_ = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, cm_[1]), 0x130, 0xf, 0xf, true)); \
+        const int   rn_ = __builtin_amdgcn_mov_dpp(cn_[1], 0x130, 0xf, 0xf, true);                               \
+        cm_[0]       = zl ? 0.0f : (first ? em_ : lm_);                                                          \
+        cn_[0]       = zl ? 0 : (first ? en_ : ln_);                                                             \
+        cm_[VEC + 1] = zr ? 0.0f : (last ? em_ : rm_);                                                           \
+        cn_[VEC + 1] = zr ? 0 : (last ? en_ : rn_);                                                              \
         vec_t o_;                                                                                                \
         _Pragma("unroll") for (int i = 0; i < VEC; ++i)                                                          \
             o_[i] = (cn_[i] | cn_[i + 1] | cn_[i + 2]) ? NAN : fmaxf(fmaxf(cm_[i], cm_[i + 1]), cm_[i + 2]);     \
@@ -233,11 +253,9 @@ __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
 inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 bool pooled_supported(int n, int c, int h, int w, int k_out) {
-    // Default: only rows that are whole 16-byte groups (the 28x28 modules: 3a 0.118 -> 0.099 ms, 3b 0.176 -> 0.138).  The 8-byte
-    // form (14x14 modules, PVHIP_FUSE_POOLCONV=2) issues 4.5 loads per pooled value and is slower than the two launches
-    // (0.081 -> 0.095 ms on 4a); with it the pass loses what the 28x28 modules gain.
+    // Rows of whole 16-byte groups (28x28 modules) or 8-byte groups (14x14); PVHIP_FUSE_POOLCONV=4 keeps it to the former (A/B runs)
     if (settings().fuse_poolconv == 0) return false;
-    const int min_vec = settings().fuse_poolconv == 2 ? 2 : 4;
+    const int min_vec = settings().fuse_poolconv == 4 ? 4 : 2;
     if (w % min_vec != 0) return false;
     if (n <= 0 || c < kBK || c % kBK != 0 || h <= 0 || w <= 0 || k_out <= 0 || k_out > 128) return false;
     if (w % 2 != 0) return false;                                       // aligned 8- or 16-byte groups that never straddle a row

@@ -37,7 +37,7 @@ void load_settings() {
     s.conv_winograd4 = tri("PVHIP_CONV_WINOGRAD4");
     s.conv_winograd5 = tri("PVHIP_CONV_WINOGRAD5");
     s.conv_pointwise = !is0("PVHIP_CONV_POINTWISE");
-    if (const char* e = env("PVHIP_FUSE_POOLCONV")) s.fuse_poolconv = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+    if (const char* e = env("PVHIP_FUSE_POOLCONV")) s.fuse_poolconv = e[0] == '0' ? 0 : (e[0] == '4' ? 4 : 1);
     s.pool3 = !(env("PVHIP_POOL3") != nullptr && num("PVHIP_POOL3", 1) == 0);
     if (const char* e = env("PVHIP_CONV_TILE")) {
         int bm = 0, bn = 0;

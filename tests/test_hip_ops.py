@@ -626,12 +626,11 @@ def test_sibling_convolutions_decline_other_geometries(hip):
 
 @pytest.mark.parametrize('xs,k', [((3, 192, 28, 28), 32), ((2, 480, 14, 14), 64), ((2, 528, 14, 14), 128), ((1, 32, 6, 10), 40),
                                   ((5, 16, 4, 4), 7), ((1, 48, 9, 36), 100)])
-def test_maxpool_then_1x1_convolution_as_one_launch_is_bit_identical(hip, monkeypatch, xs, k):
+def test_maxpool_then_1x1_convolution_as_one_launch_is_bit_identical(hip, xs, k):
     """3x3 / stride 1 / pad 1 MaxPool -> 1x1 convolution handed over as one call (node['_fuse_pool_in']): the bits of the two
     launches (zero pad cells take part in the max, NaN wins), also with fused bias + ReLU and written in place into a wider
     tensor; within the tolerance of the oracle's MaxPool -> Convolution."""
     from pyopenvino_amd import device as dev
-    helpers.setenv(monkeypatch, 'PVHIP_FUSE_POOLCONV', '2')          # also the 8-byte form (rows that are not whole 16-byte groups: off by default)
     conv, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
     x = rnd(sum(xs), xs, 1.0, -0.4)
     x[0, 1, 2, 3] = np.nan if k == 40 else x[0, 1, 2, 3]
@@ -665,7 +664,7 @@ def test_maxpool_then_convolution_declines_other_geometries(hip):
         pad = (kk // 2, kk // 2)
         return make_node('Convolution', [x, np.zeros((k, xs[1], kk, kk), dtype=np.float32)], conv_data((1, 1), pad, pad)), pn
     assert conv.pooled_fusable(*pair((2, 32, 12, 12)))
-    assert not conv.pooled_fusable(*pair((2, 32, 14, 14)))               # rows of 14: the 8-byte form is opt-in (slower than two launches)
+    assert conv.pooled_fusable(*pair((2, 32, 14, 14)))                   # rows of 14: 8-byte groups
     assert not conv.pooled_fusable(*pair((2, 32, 7, 7)))                 # odd width
     assert not conv.pooled_fusable(*pair((2, 24, 12, 12)))               # 24 channels: not whole 16-row stages
     assert not conv.pooled_fusable(*pair((2, 32, 12, 12), k=200))

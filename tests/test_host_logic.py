@@ -191,7 +191,7 @@ def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
         assert set(stream_of.values()) >= ({0, 1, 2} if fuse else {0, 1, 2, 3})      # fused siblings leave three arms per module
 
         folded = {p_: s for p_, s in ex._pool_conv.values()}             # MaxPools folded into the pool_proj convolutions
-        assert len(ex._pool_conv) == (2 if fuse else 0)                  # the 28x28 modules (rows of whole 16-byte groups)
+        assert len(ex._pool_conv) == (7 if fuse else 0)                  # the 28x28 and 14x14 modules (rows of whole 16- / 8-byte groups)
         lead_of = {n: lead for lead, sibs in ex._siblings.items() for s in sibs
                    for n in (s, ex._fusion[s]['add'], ex._fusion[s]['relu']) if n is not None}
 
