@@ -116,6 +116,29 @@ __global__ __launch_bounds__(kBlock) void binary_channel_kernel(const float* __r
     }
 }
 
+// The same with inner % 4 == 0 (a float4 never straddles two channels: data/mean on (N,3,224,224), per-channel bias rows): ONE
+// channel index per float4, by multiply-high instead of two runtime divisions and a four-step carry chain (that form ran the
+// 308 MB data/mean Add of GoogLeNet at 2.1 TB/s, vector-ALU-bound).  n < 2^31.
+template <class Op, bool kSwap>
+__global__ __launch_bounds__(kBlock) void binary_channel4_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                  float* __restrict__ out, unsigned n4, unsigned C, FastDiv d_inner4,
+                                                                  FastDiv d_c, Op op) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    const float4* __restrict__ a4 = reinterpret_cast<const float4*>(a);
+    float4* __restrict__       o4 = reinterpret_cast<float4*>(out);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4         v  = a4[i];
+        const unsigned q  = fdiv(i, d_inner4);               // i / (inner / 4)
+        const float    bv = b[q - fdiv(q, d_c) * C];         // q % C
+        if (kSwap) {
+            v.x = op(bv, v.x); v.y = op(bv, v.y); v.z = op(bv, v.z); v.w = op(bv, v.w);
+        } else {
+            v.x = op(v.x, bv); v.y = op(v.y, bv); v.z = op(v.z, bv); v.w = op(v.w, bv);
+        }
+        o4[i] = v;
+    }
+}
+
 struct StridedArgs {
     int     rank;
     int64_t shape[PVHIP_MAX_RANK];
@@ -202,6 +225,11 @@ int launch_binary(const char* who, const float* a, const float* b, float* out, i
     if (n < (1ull << 32)) {
         if (a_full && channel_pattern(rank, shape, bs, &C, &inner)) {
             const int g = grid_for(n4 > 0 ? n4 : 1);
+            if (inner % 4 == 0 && n % 4 == 0 && n < (1ull << 31)) {
+                hipLaunchKernelGGL((binary_channel4_kernel<Op, false>), dim3(g), dim3(kBlock), 0, state().stream, a, b, out, (unsigned)n4,
+                                   (unsigned)C, make_fastdiv((unsigned)(inner / 4)), make_fastdiv((unsigned)C), op);
+                return PVHIP_OK;
+            }
             hipLaunchKernelGGL((binary_channel_kernel<Op, false>), dim3(g), dim3(kBlock), 0, state().stream, a, b, out,
                                (unsigned)n4, (unsigned)n, (unsigned)C, (unsigned)inner, op);
             return PVHIP_OK;
@@ -209,6 +237,15 @@ int launch_binary(const char* who, const float* a, const float* b, float* out, i
         if (b_full && channel_pattern(rank, shape, as, &C, &inner)) {
             // the broadcast operand is `a`: stream b, keep operand order for non-commutative ops
             const int g = grid_for(n4 > 0 ? n4 : 1);
+            if (inner % 4 == 0 && n % 4 == 0 && n < (1ull << 31)) {
+                if (commutative)
+                    hipLaunchKernelGGL((binary_channel4_kernel<Op, false>), dim3(g), dim3(kBlock), 0, state().stream, b, a, out,
+                                       (unsigned)n4, (unsigned)C, make_fastdiv((unsigned)(inner / 4)), make_fastdiv((unsigned)C), op);
+                else
+                    hipLaunchKernelGGL((binary_channel4_kernel<Op, true>), dim3(g), dim3(kBlock), 0, state().stream, b, a, out,
+                                       (unsigned)n4, (unsigned)C, make_fastdiv((unsigned)(inner / 4)), make_fastdiv((unsigned)C), op);
+                return PVHIP_OK;
+            }
             if (commutative)
                 hipLaunchKernelGGL((binary_channel_kernel<Op, false>), dim3(g), dim3(kBlock), 0, state().stream, b, a, out,
                                    (unsigned)n4, (unsigned)n, (unsigned)C, (unsigned)inner, op);
