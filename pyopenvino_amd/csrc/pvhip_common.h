@@ -91,6 +91,26 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
     return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shift);
 }
 
+// Fused bias + activation of the convolution epilogues WITHOUT branches.  `act` (0 none, 1 ReLU, 2 Clamp) is a launch constant,
+// but written as `if (act == 1) ... else if (act == 2) ...` per value hipcc kept scalar branches around every one of the 16-32
+// values of a lane (the pointwise kernel's epilogue was 1262 instructions with ~300 branches and took a fifth of a workgroup's
+// life).  Two compare-and-selects against bounds computed once give the same bits: ReLU is (v < 0) ? 0 : v with hi = +inf,
+// none has lo = -inf; NaN and -0.0 pass through as before.  A missing bias is -0.0 (v + -0.0 == v for every v, -0.0 included).
+struct ActBounds {
+    float lo, hi;
+};
+__device__ __forceinline__ ActBounds act_bounds(int act, float lo, float hi) {
+    ActBounds b;
+    b.lo = act == 1 ? 0.0f : (act == 2 ? lo : -__builtin_inff());
+    b.hi = act == 2 ? hi : __builtin_inff();
+    return b;
+}
+__device__ __forceinline__ float act_apply(float v, const ActBounds& b) {
+    v = (v < b.lo) ? b.lo : v;
+    v = (v > b.hi) ? b.hi : v;
+    return v;
+}
+
 // (bias + alpha * sum)^beta of the LRN kernels.  beta_mode: 1 -> d^0.75 as sqrt(d)*sqrt(sqrt(d)) (two correctly
 // rounded roots), 2 -> d^0.5, 3 -> d, 0 -> powf.
 __device__ __forceinline__ float lrn_pow_f(float d, float beta, int beta_mode) {

@@ -264,8 +264,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
                 if (ko < a.K) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + a.bias[ko];
-                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
-                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                    v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
                     yp[(size_t)ko * OHW] = v;
                 }
             }
@@ -504,8 +503,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
                 if (row0 + dr < a.K) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + bv[r];
-                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
-                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                    v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
                     yp[(size_t)dr * OHW] = v;
                 }
             }
@@ -739,8 +737,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
             if (row0 + dr < klim) {
                 float v = acc[i][r];
                 if (a.bias != nullptr) v = v + bv[r];
-                if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
-                else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
                 yp[(size_t)dr * OHW] = v;
             }
         }
@@ -877,8 +874,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
                 if (ko < a.K) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + a.bias[ko];
-                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
-                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                    v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
                     yp[(size_t)ko * OHW] = v;
                 }
             }

@@ -241,8 +241,7 @@ __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
                 if (row0 + dr < a.K) {
                     float v = acc[i][r];
                     if (a.bias != nullptr) v = v + bv[r];
-                    if (a.relu == 1) v = (v < 0.0f) ? 0.0f : v;
-                    else if (a.relu == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                    v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
                     yp[(size_t)dr * HW] = v;
                 }
             }

@@ -87,6 +87,7 @@ template <int TN, bool kVec>
 __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[4], const float (&bv)[16], float* __restrict__ yb, int yct,
                                          int ycoff, int klim, int row0, int gp0) {
     typedef float bvec_t __attribute__((ext_vector_type(TN)));
+    const ActBounds ab = act_bounds(a.act, a.lo, a.hi);          // bv[] holds -0.0 where there is no bias
     if (kVec) {
         if (gp0 >= a.P) return;
         const int n = gp0 / a.HW, hw = gp0 - n * a.HW;
@@ -97,13 +98,7 @@ __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[
             if (row0 + dr < klim) {
                 bvec_t v;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float e = acc[j][r];
-                    if (a.bias != nullptr) e = e + bv[r];
-                    if (a.act == 1) e = (e < 0.0f) ? 0.0f : e;
-                    else if (a.act == 2) { e = (e < a.lo) ? a.lo : e; e = (e > a.hi) ? a.hi : e; }
-                    v[j] = e;
-                }
+                for (int j = 0; j < TN; ++j) v[j] = act_apply(acc[j][r] + bv[r], ab);
                 *reinterpret_cast<bvec_t*>(yp + (size_t)dr * a.HW) = v;
             }
         }
@@ -118,11 +113,7 @@ __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
                 if (row0 + dr < klim) {
-                    float e = acc[j][r];
-                    if (a.bias != nullptr) e = e + bv[r];
-                    if (a.act == 1) e = (e < 0.0f) ? 0.0f : e;
-                    else if (a.act == 2) { e = (e < a.lo) ? a.lo : e; e = (e > a.hi) ? a.hi : e; }
-                    yp[(size_t)dr * a.HW] = e;
+                    yp[(size_t)dr * a.HW] = act_apply(acc[j][r] + bv[r], ab);
                 }
             }
         }
@@ -139,8 +130,18 @@ __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[
 // a run-time value, or as three inlined bodies, hipcc keeps a set of accumulators per form and copies between them.)
 // ABL (diagnostic build only, results wrong on purpose): 1 = the activation copies read nothing (a descriptor of 0 records: zeros
 // land in LDS), 2 = no epilogue stores, 4 = no MFMAs.
+#ifdef PVHIP_DIAG
+__device__ unsigned long long g_pw_stamps[8];      // ABL = 8: cycles of every 61st workgroup's wave 0: prologue, main loop, epilogue, count; [4] 10 ns ticks
+#define PW_NOW() ((ABL == 8) ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#else
+#define PW_NOW() 0ull
+#endif
 template <int TN, bool kVec, int ABL = 0>
 __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
+    const unsigned long long pw_t0 = PW_NOW();
+#ifdef PVHIP_DIAG
+    const unsigned long long pw_r0 = (ABL == 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
     constexpr int BN = 128;
     constexpr int NP = kVec ? 2 : 8;                     // LDS-DMA instructions per wave and stage (1 KiB or 256 B each)
     __shared__ __attribute__((aligned(1024))) float Bs[4][kBK][BN];
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
     { const int s1 = 1 < S ? 1 : S - 1; PW_ISSUE(s1, 1); }
     { const int s2 = 2 < S ? 2 : S - 1; PW_ISSUE(s2, 2); }
     PW_WAIT_A(0, 2 * NP);
+    const unsigned long long pw_t1 = PW_NOW();
 
     for (int s = 0; s < S; s += 3) {
         PW_STAGE(s, 0, 2, 1);
@@ -261,6 +263,8 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
         PW_STAGE(s + 2, 2, 1, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead copies must not outlive the workgroup's LDS
+    const unsigned long long pw_t2 = PW_NOW();
+    (void)pw_t0; (void)pw_t1; (void)pw_t2;
 #undef PW_STAGE
 #undef PW_WAIT_A
 #undef PW_LOAD_A
@@ -294,11 +298,27 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
                                                                         a.bias != nullptr ? a.T * 32 * 4 : 0, 0x00020000);
     float bv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < 16; ++r) {
         bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * 4u, 0, 0));
+        if (a.bias == nullptr) bv[r] = -0.0f;
+    }
 
+    if (ABL == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long pw_tb = PW_NOW();
+    (void)pw_tb;
     const int gp0 = p0 + boff;
     pw_store<TN, kVec>(a, acc, bv, yb, yct, ycoff, klim, row0, gp0);
+#ifdef PVHIP_DIAG
+    if (ABL == 8 && blockIdx.x % 61 == 7 && threadIdx.x == 0) {
+        const unsigned long long pw_t3 = PW_NOW();
+        atomicAdd(&g_pw_stamps[5], pw_tb - pw_t2);
+        atomicAdd(&g_pw_stamps[0], pw_t1 - pw_t0);
+        atomicAdd(&g_pw_stamps[1], pw_t2 - pw_t1);
+        atomicAdd(&g_pw_stamps[2], pw_t3 - pw_t2);
+        atomicAdd(&g_pw_stamps[3], 1ull);
+        atomicAdd(&g_pw_stamps[4], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - pw_r0));
+    }
+#endif
 }
 
 template <int TN>
@@ -313,6 +333,7 @@ void launch_pw(const PwArgs& a, bool vec, int grid) {
         case 6: hipLaunchKernelGGL((conv_pw_kernel<4, true, 6>), dim3(grid), dim3(kBlock), 0, st, a); return;
         default: break;
     }
+    if (vec && settings().pw_ablate == 8) { hipLaunchKernelGGL((conv_pw_kernel<TN, true, 8>), dim3(grid), dim3(kBlock), 0, st, a); return; }   // s_memtime stamps
 #endif
     if (vec) hipLaunchKernelGGL((conv_pw_kernel<TN, true>), dim3(grid), dim3(kBlock), 0, st, a);
     else     hipLaunchKernelGGL((conv_pw_kernel<TN, false>), dim3(grid), dim3(kBlock), 0, st, a);
@@ -372,3 +393,14 @@ int pw_conv(const float* x, const float* ap, int n, int c, int hw, int k_panel, 
 }
 
 }  // namespace pvhip
+
+#ifdef PVHIP_DIAG
+// diagnostic build only: read and clear the cycle accounts of conv_pw_kernel<.., .., 8> (PVHIP_PW_ABLATE=8); out = 8 counters
+extern "C" int pvhip_diag_pw_stamps(unsigned long long* out) {
+    unsigned long long zero[8] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pw_stamps), sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pw_stamps), zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+#endif

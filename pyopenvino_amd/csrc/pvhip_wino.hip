@@ -292,6 +292,7 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
                                                                         a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
     const int  OH = a.H, OW = a.W;
     const bool pair_stores = (OW & 1) == 0;          // 2*tx + 1 < OW and 8-byte aligned rows
+    const ActBounds ab = act_bounds(a.act, a.act_lo, a.act_hi);
 #pragma unroll
     for (int h = 0; h < TILES; ++h) {
         if (h == 1) __syncthreads();         // the reads of the first tile are done
@@ -334,8 +335,7 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
                     for (int c2 = 0; c2 < 2; ++c2) {
                         float v = yv[r2][c2];
                         if (a.bias != nullptr) v = v + bv;
-                        if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;
-                        else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; }
+                        v = act_apply(v, ab);
                         ov[c2] = v;
                     }
                     if (pair_stores) {
@@ -649,6 +649,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     constexpr int CH = (M == 4) ? 16 : 32, PASSES = 32 / CH;
     float* const Ex = &sm.V1[0][0][0];
     const int OH = a.H, OW = a.W;
+    const ActBounds ab = act_bounds(a.act, a.act_lo, a.act_hi);
     typedef float exv_t __attribute__((ext_vector_type(M)));      // the M column outputs of a (row, channel, patch): one LDS access
 #define PVW4_EPI_WRITE(pass)                                                                                     \
     {                                                                                                            \
@@ -700,8 +701,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                         _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) {                                       \
                             float v = yv[r2][c2];                                                                \
                             if (a.bias != nullptr) v = v + bv;                                                   \
-                            if (a.act == 1) v = (v < 0.0f) ? 0.0f : v;                                           \
-                            else if (a.act == 2) { v = (v < a.act_lo) ? a.act_lo : v; v = (v > a.act_hi) ? a.act_hi : v; } \
+                            v = act_apply(v, ab);                                                                \
                             ov[c2] = v;                                                                          \
                         }                                                                                        \
                         if (RAGGED) {            /* only what exists; pairs where the rows are 8-byte aligned (even width) */ \

@@ -70,6 +70,7 @@ def main():
         best = {v[0]: 1e9 for v in variants}
         ref = None
         same = {}
+        stamp_note = ''
         for rnd in range(args.rounds):
             for vname, env in variants:
                 for kenv in ('PVHIP_CONV_POINTWISE', 'PVHIP_PW_STAGGER', 'PVHIP_PW_TN', 'PVHIP_PW_ABLATE'):
@@ -77,6 +78,8 @@ def main():
                 os.environ.update(env)
                 dev.reload_settings()
                 run(); dev.synchronize()
+                if env.get('PVHIP_PW_ABLATE') == '8':
+                    lib0 = ctypes.CDLL(dev.LIB_PATH); lib0.pvhip_diag_pw_stamps.argtypes = [ctypes.c_void_p]; lib0.pvhip_diag_pw_stamps((ctypes.c_ulonglong * 8)())
                 if rnd == 0:
                     got = [o.numpy() for o in outs]
                     if ref is None:
@@ -89,11 +92,19 @@ def main():
                     run()
                 e1 = dev.Event().record(); e1.synchronize()
                 best[vname] = min(best[vname], e0.elapsed_ms(e1) / args.reps)
+                if env.get('PVHIP_PW_ABLATE') == '8' and rnd == args.rounds - 1:      # s_memtime stamps of every 61st workgroup's wave 0
+                    lib = ctypes.CDLL(dev.LIB_PATH)
+                    lib.pvhip_diag_pw_stamps.argtypes = [ctypes.c_void_p]
+                    st = (ctypes.c_ulonglong * 8)()
+                    lib.pvhip_diag_pw_stamps(st)
+                    cnt = max(1, st[3])
+                    stamp_note = '  [per workgroup: prologue {:.0f}, main loop {:.0f}, epilogue {:.0f} cycles (of which {:.0f} until the bias has arrived); {:.2f} GHz]'.format(
+                        st[0] / cnt, st[1] / cnt, st[2] / cnt, st[5] / cnt, (st[0] + st[1] + st[2]) / max(1, st[4]) / 10.0)
         line = '{:18s} C={:4d} {:2d}x{:<2d} K={:<14s} {:6.2f} GF |'.format(name, c, side, side, '+'.join(map(str, ks)), gflop)
         for vname, _ in variants:
             total[vname] += best[vname]
             line += ' {}: {:.4f} ms {:5.1f} TF {} |'.format(vname, best[vname], gflop / best[vname], 'same' if same[vname] else 'DIFF')
-        print(line, flush=True)
+        print(line + stamp_note, flush=True)
     print('total ms: ' + '  '.join('{} {:.3f}'.format(k, v) for k, v in total.items()), flush=True)
 
 
