@@ -16,5 +16,5 @@ step() {  # step <seconds> <logfile> <cmd...>
 : > gpurun_out/ci.log
 step 900 test_gpu.log python -m pytest tests -m gpu -q -x --timeout=600 ${PYTEST_EXTRA:-}
 step 300 smoke.log python -c "import __graft_entry__ as g; g.smoke()"
-step 600 bench.log python bench.py --steps ${BENCH_STEPS:-5} --warmup 2
+step 600 bench.log python bench.py --gpus 1 --steps ${BENCH_STEPS:-20} --warmup ${BENCH_WARMUP:-5}
 exit 0
