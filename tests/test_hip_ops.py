@@ -438,6 +438,15 @@ def test_conv_linearity_full_size_layer(hip):
     assert_close(y1[:2], want, helpers.REL_TOL, 'first two images vs oracle')
 
 
+def test_mfma_ceiling_probe_reports_a_plausible_rate(hip):
+    """bench.py's roofline.sustained: fp32 MFMA alone is below the 157.3 TFLOP/s of 2.4 GHz and far above any convolution here; a
+    VALU-only wave beside every MFMA wave takes a visible share away (the two do not overlap on a SIMD)."""
+    alone = max(hip.mfma_ceiling_f32(False, 4000) for _ in range(3))
+    shared = max(hip.mfma_ceiling_f32(True, 4000) for _ in range(2))
+    assert 90.0 < alone[0] < 158.0 and 1.2 < alone[1] < 2.6, alone
+    assert shared[0] < 0.85 * alone[0], (alone, shared)
+
+
 def test_conv_error_behaviour_matches_reference(hip):
     """17x17 stride 2 'same_upper' with pads (0,0)/(1,1): the reference's im2col raises ValueError
     (window exceeds the padded input, Convolution.py:68); so do we."""
