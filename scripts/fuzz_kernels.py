@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""GPU-box tool: random shapes through the kernels that have a slower twin -- the six-point Winograd kernel (3x3, 5x5; forced) against the
+direct kernel, MaxPool + 1x1 convolution / MaxPool + LRN / LRN + MaxPool as one launch against two.  python scripts/fuzz_kernels.py [cases] [seed]"""
+import os, sys, random
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+from pyopenvino_amd import device as dev, synth
+from pyopenvino_amd.op_plugins import Convolution, MaxPool, LRN
+dev.init(0)
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def node(type_, ins, data):
+    return {'name': type_, 'type': type_, 'version': 'opset1', 'data': dict(data),
+            'input': {i: {'precision': 'I64' if a.dtype == np.int64 else 'FP32', 'dims': tuple(a.shape)} for i, a in enumerate(ins)},
+            'output': {len(ins): {'precision': 'FP32', 'dims': ()}}}
+def setenv(env):
+    for k_ in ('PVHIP_CONV_WINOGRAD4', 'PVHIP_CONV_WINOGRAD5', 'PVHIP_CONV_WINOGRAD'): os.environ.pop(k_, None)
+    os.environ.update(env); dev.reload_settings()
+bad = 0
+compared = {}
+for i in range(cases):
+    kind = rng.choice(['w3', 'w5', 'poolconv', 'poollrn', 'lrnpool'])
+    n, h, w = rng.randint(1, 9), rng.randint(1, 30), rng.randint(1, 30)
+    if kind in ('w3', 'w5'):
+        ks = 3 if kind == 'w3' else 5
+        c, k = 4 * rng.randint(1, 12), rng.randint(1, 100)
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w))
+        wt = (synth.normal(i, 3, k * c * ks * ks) * (2.0 / (c * ks * ks)) ** 0.5).astype(np.float32).reshape((k, c, ks, ks))
+        b = dev.DeviceTensor.from_numpy(synth.normal(i, 4, k).astype(np.float32).reshape((1, k, 1, 1)))
+        outs = []
+        for env in ({'PVHIP_CONV_WINOGRAD4': 'force', 'PVHIP_CONV_WINOGRAD5': 'force'}, {'PVHIP_CONV_WINOGRAD': '0', 'PVHIP_CONV_WINOGRAD5': '0'}):
+            setenv(env)
+            outs.append(np.asarray(Convolution.launch({}, dev.DeviceTensor.from_numpy(x), dev.DeviceTensor.from_numpy(wt), (1, 1), (ks // 2,) * 2, (ks // 2,) * 2, 'explicit', bias=b, act=('relu',))))
+        setenv({})
+        err = float(np.abs(outs[0] - outs[1]).max() / max(1e-20, np.abs(outs[1]).max()))
+        ok = err < 5e-5
+        what = '{}x{} conv x{} k{}: {:.1e}'.format(ks, ks, (n, c, h, w), k, err)
+    elif kind == 'poolconv':
+        c, k = 16 * rng.randint(1, 6), rng.randint(1, 128)
+        w = 2 * rng.randint(1, 15)
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w))
+        wt = (synth.normal(i, 3, k * c) * (2.0 / c) ** 0.5).astype(np.float32).reshape((k, c, 1, 1))
+        pn = node('MaxPool', [x], {'kernel': '3, 3', 'strides': '1, 1', 'pads_begin': '1, 1', 'pads_end': '1, 1', 'rounding_type': 'ceil', 'auto_pad': 'explicit'}); pn['output'][1]['dims'] = x.shape
+        cn = node('Convolution', [x, wt], {'strides': '1, 1', 'dilations': '1, 1', 'pads_begin': '0, 0', 'pads_end': '0, 0', 'auto_pad': 'explicit'})
+        if not Convolution.pooled_fusable(cn, pn):
+            continue
+        xd, wd = dev.DeviceTensor.from_numpy(x), dev.DeviceTensor.from_numpy(wt)
+        two = np.asarray(Convolution.compute(dict(cn), {0: MaxPool.compute(dict(pn), {0: xd})[1], 1: wd})[2])
+        one_n = dict(cn); one_n['_fuse_pool_in'] = pn
+        one = np.asarray(Convolution.compute(one_n, {0: xd, 1: wd})[2])
+        ok = bool((one.view(np.uint32) == two.view(np.uint32)).all()); what = 'MaxPool + 1x1 x{} k{}'.format(x.shape, k)
+    else:
+        c = 8 * rng.randint(1, 8)
+        st = rng.choice([1, 2]); pb = rng.choice([0, 1]); pe = rng.choice([0, 1])
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w)) * 30.0
+        axes = np.array([1], dtype=np.int64)
+        pdata = {'kernel': '3, 3', 'strides': '{0}, {0}'.format(st), 'pads_begin': '{0}, {0}'.format(pb), 'pads_end': '{0}, {0}'.format(pe), 'rounding_type': rng.choice(['ceil', 'floor']), 'auto_pad': 'explicit'}
+        ldata = {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'}
+        xd = dev.DeviceTensor.from_numpy(x)
+        try:
+            if kind == 'poollrn':
+                pn = node('MaxPool', [x], pdata)
+                p = MaxPool.compute(dict(pn), {0: xd})[1]
+                ln = node('LRN', [np.zeros(p.shape, np.float32), axes], ldata); ln['output'][2]['dims'] = tuple(p.shape)
+                if not MaxPool.lrn_fusable(pn, ln):
+                    continue
+                two = np.asarray(LRN.compute(dict(ln), {0: p, 1: axes})[2])
+                fn = dict(pn); fn['_fuse_lrn'] = ln
+                one = np.asarray(MaxPool.compute(fn, {0: xd})[1])
+            else:
+                ln = node('LRN', [x, axes], ldata)
+                l = LRN.compute(dict(ln), {0: xd, 1: axes})[2]
+                pn = node('MaxPool', [x], pdata)
+                two_t = MaxPool.compute(dict(pn), {0: l})[1]
+                pn['output'][1]['dims'] = tuple(two_t.shape)
+                if not LRN.pool_fusable(ln, pn):
+                    continue
+                two = np.asarray(two_t)
+                fn = dict(ln); fn['_fuse_pool'] = pn
+                one = np.asarray(LRN.compute(fn, {0: xd, 1: axes})[2])
+        except (ValueError, dev.PvhipError):      # a window that does not fit the input: the library (like the reference) refuses
+            continue
+        ok = bool((one.view(np.uint32) == two.view(np.uint32)).all()); what = '{} x{} stride {} pads {} {}'.format(kind, x.shape, st, pb, pe)
+    compared[kind] = compared.get(kind, 0) + 1
+    if not ok:
+        bad += 1
+        print('MISMATCH', what, flush=True)
+print('{} cases, compared {}, {} mismatches'.format(cases, compared, bad))
+sys.exit(1 if bad else 0)
