@@ -895,6 +895,8 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     } else {
         // ------------------------------------------------------------------ consumers: one row of the 6x6 transform domain each
         floatx16 acc[6];
+        static_assert(offsetof(Stage, V1) == offsetof(Stage, V0) + sizeof(float) * kXi4 * kCB * NT, "V1 follows V0");
+        const float* const vbs = &sm.V0[0][0][0] + ((row * 6) * kCB + lh) * NT + l31;      // this lane's B operand of MFMA (j = 0, kk = 0) in V0
         for (int tile = L; tile < n_tiles; tile += G) {
             const unsigned long long h0 = PVW4_NOW();
             const unsigned u_base = (unsigned)((tile % a.n_kb) * (a.n_stages + 1)) * u_stage_bytes;
@@ -910,7 +912,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             t_head += PVW4_NOW() - h0;
             for (int s = 0; s < n_eff; ++s) {
                 const unsigned long long t0 = PVW4_NOW();
-                const float* vb = (s & 1) ? &sm.V1[0][0][0] : &sm.V0[0][0][0];
+                const float* vb = vbs + (s & 1) * (kXi4 * kCB * NT);         // V1 follows V0: every read below is this address + a constant
                 const int    sn = s + 1 < n_eff ? s + 1 : s;          // the last stage reloads its own image (unused)
                 // B operands one group (four MFMAs) ahead, A operands of a group reloaded for the next stage as soon as its MFMAs are
                 // issued: the sched_barriers keep hipcc from sinking the loads to the end of the stage (it did)
@@ -918,7 +920,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
 #define PVW4_READ_B(dst_, g_)                                                                                   \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
         const int m = 4 * (g_) + e, kk = m / 6, j = m % 6;                                                       \
-        dst_[e] = vb[((row * 6 + j) * kCB + 2 * kk + lh) * NT + l31];                                            \
+        dst_[e] = vb[(j * kCB + 2 * kk) * NT];                                                                   \
     }
                 PVW4_READ_B(bfr[0], 0);
 #pragma unroll
