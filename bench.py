@@ -267,6 +267,8 @@ def main():
     n_streams = ex.compute_streams           # per request
     comm = shard.BatchShardComm(group)
     ex.comm = comm
+    lo, hi = comm.shard(args.batch * world)      # every rank: the same global batch (its own slice is args.batch images)
+    assert hi - lo == args.batch
     # The Result gather goes over RCCL; if the communicator cannot be created on ANY rank (no librccl, no peer access) all
     # ranks agree to gather through the host group instead -- said loudly on stderr and in the JSON line, never silently.
     gather_path, rccl_error = comm.agree_on_gather()

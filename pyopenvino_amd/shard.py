@@ -93,6 +93,9 @@ class BatchShardComm:
         self._rccl_ready = False
 
     def shard(self, total: int):
+        """This rank's slice of a batch of `total` rows.  Every rank calls it with the SAME total (it is how the batch gets
+        split in the first place), so the total is also what allgather_rows() derives every rank's row count from."""
+        self.total = int(total)
         return shard_bounds(total, self.rank, self.world)
 
     def init_device(self):
@@ -146,12 +149,22 @@ class BatchShardComm:
         return n.value
 
     def row_counts(self, rows: int):
-        """Rows of every rank's shard, in rank order (host exchange; cached per own row count: the shards of a run do
-        not change from one gather to the next)."""
-        cache = self.__dict__.setdefault('_row_counts', {})
-        if rows not in cache:
-            cache[rows] = [int(np.asarray(p).reshape(-1)[0]) for p in self.group.allgather_array(np.array([rows], dtype=np.int64))]
-        return cache[rows]
+        """Rows of every rank's shard, in rank order.  Derived from the global total every rank passed to shard() --
+        shard_bounds() is a pure function of (total, rank, world), so all ranks compute the same list without talking to
+        each other.  A communicator that was never told the total exchanges the counts through the host group EVERY time:
+        a cache keyed on this rank's own row count would let the ranks disagree on whether to enter that collective (world 2,
+        total 7 then 8: rank 0 stays at 4 rows, rank 1 goes from 3 to 4)."""
+        total = getattr(self, 'total', None)
+        if total is not None:
+            counts = []
+            for r in range(self.world):
+                lo, hi = shard_bounds(total, r, self.world)
+                counts.append(hi - lo)
+            if counts[self.rank] != int(rows):
+                raise ValueError('rank {} holds {} rows, its shard of a batch of {} on {} ranks has {}'.format(
+                    self.rank, rows, total, self.world, counts[self.rank]))
+            return counts
+        return [int(np.asarray(p).reshape(-1)[0]) for p in self.group.allgather_array(np.array([rows], dtype=np.int64))]
 
     def allgather_rows(self, value):
         """Concatenate every rank's tensor along axis 0, in rank order.  ncclAllGather moves the SAME count from every

@@ -158,3 +158,31 @@ def test_uneven_shards_are_padded_for_ncclallgather(monkeypatch):
     want = np.concatenate([100 * r + np.arange([3, 2, 2][r] * 4) for r in range(3)]).astype(np.float32)
     assert np.array_equal(heap[out.ptr][:28], want)
     assert [c[0] for c in calls].count('pvhip_comm_allgather_f32') == 1
+
+
+def test_row_counts_never_depend_on_a_rank_local_cache():
+    """World 2, a batch of 7 and then of 8 on the same communicator: rank 0 keeps 4 rows while rank 1 goes from 3 to 4.  The
+    counts come from the total every rank passed to shard() -- no rank enters a host collective the other one skips -- and a
+    communicator that was never told the total exchanges them every single time."""
+    from pyopenvino_amd import shard
+
+    class Group:
+        def __init__(self, rank):
+            self.rank, self.world, self.exchanges = rank, 2, 0
+        def allgather_array(self, arr):
+            self.exchanges += 1
+            return [np.array([4]), np.array([int(np.asarray(arr).reshape(-1)[0])])]
+
+    for rank in (0, 1):
+        g = Group(rank)
+        comm = shard.BatchShardComm(g, use_rccl=False)
+        for total, want in ((7, [4, 3]), (8, [4, 4]), (7, [4, 3])):
+            lo, hi = comm.shard(total)
+            assert comm.row_counts(hi - lo) == want
+        assert g.exchanges == 0
+        with pytest.raises(ValueError):
+            comm.row_counts(hi - lo + 1)          # a tensor that is not this rank's shard: loud, not a hang
+    g = Group(1)
+    comm = shard.BatchShardComm(g, use_rccl=False)
+    assert comm.row_counts(3) == [4, 3] and comm.row_counts(3) == [4, 3] and comm.row_counts(4) == [4, 4]
+    assert g.exchanges == 3
