@@ -452,6 +452,9 @@ bool plan_lrn_pool(int n, int c, int h, int w, int size, float beta, float bias,
     if (in_rows * w > kBlock * vec) return false;
     a.n = n; a.c = c; a.h = h; a.w = w; a.oh = oh; a.ow = ow; a.pt = pt; a.pl = pl; a.hp = h + pt + pb; a.wp = w + pl + pr;
     a.band_rows = rows; a.n_bands = bands;
+    // the kernels are instantiated for up to four pooled outputs per lane and plane; a pooled row wider than the input row (ow > w) with
+    // a tall band needs more: the QUERY must say no there, so that the caller falls back to two launches instead of failing at run time
+    if ((rows * ow + kBlock - 1) / kBlock > 4) return false;
     a.plane_l   = (in_rows * w + 3) & ~3;
     lds         = (size_t)8 * a.plane_l * sizeof(float);
     return lds <= 64 * 1024 && (long long)n * bands < (1ll << 31);

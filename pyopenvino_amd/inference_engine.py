@@ -338,6 +338,8 @@ class Executable_Network:
         self.ienet = ienetwork
         self.kernel_type = 'hip'        # the reference's 'naive' / 'numpy' / 'special' are accepted too
         self.expected_result = None     # {node name: ndarray}: per-layer compare hook (cf. :284-287)
+        self.pickle_node_args = []      # node ids whose (node, inputs) run_tasks dumps to node_args_<id>.pickle (cf. :216, :275-278)
+        self.pickle_dir = '.'           # where (the reference writes into the working directory)
         self.task_list = []
         self.last_node_times = []       # [(node id, type, name, host seconds)] of the last run_tasks
         self.comm = None                # shard.BatchShardComm when the batch is sharded over ranks
@@ -395,7 +397,9 @@ class Executable_Network:
 
     def release_device_state(self):
         """Drop every device tensor the graph holds (cached constants, packed weights, node outputs, results); the next
-        infer uploads and packs again."""
+        infer uploads and packs again.  A captured hipGraph holds raw addresses of exactly these tensors (packed weights, cached
+        constants, Concat buffers): it goes first, or a later infer_graph() would replay kernels over freed or reused pool blocks."""
+        self.release_graph()
         G = self.ienet.G
         for nid in G.nodes:
             node = G.nodes[nid]
@@ -834,6 +838,8 @@ class Executable_Network:
                 open_run[4] += 1
             elif open_run is not None and node_type not in self.NO_LAUNCH_TYPES:
                 open_run = self._close_run(open_run)
+            if task in self.pickle_node_args:
+                self.dump_node_args(task, node, inputs)
             t0 = time.time()
             res = plugin.compute(node, inputs, kernel_type=self.kernel_type, debug=False)
             dt = time.time() - t0
@@ -913,6 +919,7 @@ class Executable_Network:
         device.select_stream(self.stream_base)
         device.call('pvhip_graph_begin_capture')
         handle = ctypes_void_p()
+        first_error = None
         try:
             self.defer_sync = True
             try:
@@ -922,9 +929,18 @@ class Executable_Network:
                 self.device_timing = saved_timing
                 for nid, _ in results:
                     G.nodes[nid].pop('_async', None)
-        finally:
+        except BaseException as exc:            # noqa: BLE001 -- kept: end_capture below may fail too and must not mask it
+            first_error = exc
+        try:
             device.select_stream(self.stream_base)
             device.call('pvhip_graph_end_capture', byref(handle))       # (also after an error: the capture must be closed)
+        except Exception:                       # noqa: BLE001
+            if first_error is None:
+                raise
+        if first_error is not None:
+            if handle.value:
+                device.call('pvhip_graph_destroy', ctypes_void_p(handle.value))
+            raise first_error
         pending = self.__dict__.pop('_pending', None)   # its event belongs to the graph: nothing to wait for, just close the epoch
         if pending is not None:
             device.pool_epoch_end(pending[0])
@@ -933,6 +949,27 @@ class Executable_Network:
         self._graph = {'handle': handle.value, 'inputs': dict(inputs), 'keep': keep,
                        'results': {name: G.nodes[nid]['result'] for nid, name in results}}
         device.select_stream(0)
+
+    def dump_node_args(self, task, node, inputs):
+        """The reference's node-replay hook (`pyopenvino/inference_engine.py:216, 275-278`): `(node, inputs)` of a chosen node,
+        pickled as `node_args_<id>.pickle`, so that the node can be run on its own (`test_node_sample.py:1-16`; its fixture
+        `resources/node_args_6.pickle` was made this way).  What the file holds is what the REFERENCE's plugins can load: device
+        tensors are copied to host ndarrays, and the scheduler's private hints (`_fuse_bias`, `_out_into`, device caches: every key
+        that starts with an underscore) stay out, so a fused Convolution replays as the plain Convolution it is in the IR."""
+        import pickle
+        from . import device
+
+        def plain(obj):
+            if isinstance(obj, (device.DeviceTensor, device.ChannelSlice)):
+                return np.array(obj)
+            if isinstance(obj, dict):
+                return {k: plain(v) for k, v in obj.items() if not (isinstance(k, str) and (k.startswith('_') or k == 'comm'))}
+            if isinstance(obj, (list, tuple)):
+                return type(obj)(plain(v) for v in obj)
+            return obj
+
+        with open(os.path.join(self.pickle_dir, 'node_args_{}.pickle'.format(task)), 'wb') as f:
+            pickle.dump((plain(node), plain(inputs)), file=f)
 
     def infer_graph(self, inputs: dict = None) -> dict:
         """Replay the captured pass (for new inputs: copied device-to-device into the captured input tensors first) and return

@@ -411,3 +411,25 @@ def test_hipgraph_replay_of_a_forward_pass_is_bit_identical(hip, model, shape, s
     with pytest.raises(RuntimeError):
         ex.infer_graph()
     helpers.assert_bit_exact(infer_one(ex, net, d2), want2, 'eager pass after the graph is gone')
+
+
+def test_pickle_node_args_from_a_fused_device_pass_replays_through_the_oracle(hip, tmp_path):
+    """The reference's node-replay hook on the product path: a Convolution that runs fused (bias + ReLU in its epilogue, device
+    tensors in and out) is dumped as the plain IR node with host ndarrays, and replaying the file through the oracle's plugin
+    (`test_node_sample.py:1-16` style) gives the convolution the device computed before its epilogue."""
+    import importlib
+    import pickle
+    from pyopenvino_amd import synth
+    _, net, ex = build_network(HIP, 'mnist', batch=4)
+    conv = [n for n in net.G.nodes if net.G.nodes[n]['type'] == 'Convolution'][1]
+    ex.pickle_node_args, ex.pickle_dir = [conv], str(tmp_path)
+    x = np.concatenate([synth.uniform_pixels(70 + i, (1, 1, 28, 28)) for i in range(4)], 0)
+    infer_one(ex, net, x)
+    with open(os.path.join(str(tmp_path), 'node_args_{}.pickle'.format(conv)), 'rb') as f:
+        node, inputs = pickle.load(file=f)
+    assert all(type(v) is np.ndarray for v in inputs.values()) and '_fuse_bias' not in node
+    want = next(iter(importlib.import_module(ORACLE + '.Convolution').compute(node, inputs, kernel_type='special').values()))
+    _, net1, ex1 = build_network(HIP, 'mnist', batch=4, fuse=False)
+    infer_one(ex1, net1, x)
+    got = np.asarray(next(iter(net1.G.nodes[conv]['output'].values()))['data'])
+    assert_close(got, want, helpers.REL_TOL, 'replayed node {}'.format(node['name']))

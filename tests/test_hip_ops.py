@@ -783,6 +783,37 @@ def test_fused_lrn_maxpool_declines_what_it_does_not_cover(hip):
     assert not lrn_plugin.pool_fusable(*pair((1, 8, 5, 2000)))             # three input rows do not fit one workgroup
 
 
+def test_fused_lrn_pool_query_and_launch_agree(hip):
+    """pvhip_lrn_maxpool_supported / pvhip_maxpool_lrn_supported == 1 must imply that the launch does not answer EUNSUPPORTED
+    (plan_fusion folds the second node away on the query's word).  Random geometries plus the one that used to disagree: a pooled
+    row wider than the input row (pads of 2 at stride 1) with a tall band = more than four pooled outputs per lane."""
+    import ctypes
+    from pyopenvino_amd import device as dev
+    rng = np.random.default_rng(5)
+    cases = [(1, 8, 124, 8, 1, 2, 2, 2, 2), (1, 8, 126, 8, 1, 2, 2, 2, 2), (1, 8, 100, 10, 1, 2, 2, 2, 2)]
+    for _ in range(120):
+        st = int(rng.integers(1, 3))
+        cases.append((int(rng.integers(1, 3)), 8 * int(rng.integers(1, 4)), int(rng.integers(1, 140)), int(rng.integers(1, 80)), st,
+                      int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 3))))
+    said_yes = 0
+    for n, c, h, w, st, pt, pl, pb, pr in cases:
+        oh, ow = (h + pt + pb - 3) // st + 1, (w + pl + pr - 3) // st + 1
+        if oh < 1 or ow < 1:
+            continue
+        x = dev.DeviceTensor.from_numpy(rng.standard_normal((n, c, h, w)).astype(np.float32))
+        y = dev.DeviceTensor.empty((n, c, oh, ow))
+        geo = (oh, ow, 3, 3, st, st, pt, pl, pb, pr)
+        if dev.call('pvhip_lrn_maxpool_supported', n, c, h, w, 5, 0.75, 1.0, *geo):
+            said_yes += 1
+            dev.call('pvhip_lrn_maxpool_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, 5, 1e-4, 0.75, 1.0, *geo)
+        if dev.call('pvhip_maxpool_lrn_supported', n, c, h, w, *geo, 5, 0.75, 1.0):
+            said_yes += 1
+            dev.call('pvhip_maxpool_lrn_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, *geo, 5, 1e-4, 0.75, 1.0)
+    dev.synchronize()
+    assert said_yes > 40
+    assert not dev.call('pvhip_lrn_maxpool_supported', 1, 8, 124, 8, 5, 0.75, 1.0, 126, 10, 3, 3, 1, 1, 2, 2, 2, 2)
+
+
 def test_concat_inception_shapes_bit_exact(hip):
     parts = [rnd(i, (3, c, 7, 7)) for i, c in enumerate((384, 384, 128, 128))]
     vs_oracle('Concat', parts, {'axis': '1'})

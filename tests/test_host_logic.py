@@ -263,3 +263,30 @@ def test_device_blocks_cannot_be_copied():
     t = device.DeviceTensor(blk, (4,))
     with pytest.raises(device.PvhipError):
         copy.deepcopy({'w': t})
+
+
+def test_pickle_node_args_replays_a_node_like_the_reference(tmp_path):
+    """Executable_Network.pickle_node_args (reference `inference_engine.py:216, 275-278`): run_tasks dumps `(node, inputs)` of the
+    chosen nodes as node_args_<id>.pickle, and the node then runs on its own the way the reference's `test_node_sample.py:1-16`
+    replays `resources/node_args_6.pickle`: unpickle, `op.compute(node, inputs)`."""
+    import importlib
+    import pickle
+    from pyopenvino_amd import synth
+    _, net, ex = helpers.build_network('oracle.op_plugins', 'mnist', batch=2)
+    conv_ids = [n for n in net.G.nodes if net.G.nodes[n]['type'] == 'Convolution']
+    pool_ids = [n for n in net.G.nodes if net.G.nodes[n]['type'] == 'MaxPool']
+    chosen = [conv_ids[1], pool_ids[0]]
+    ex.pickle_node_args = list(chosen)
+    ex.pickle_dir = str(tmp_path)
+    x = np.concatenate([synth.uniform_pixels(40 + i, (1, 1, 28, 28)) for i in range(2)], 0)
+    helpers.infer_one(ex, net, x)
+    assert sorted(os.listdir(str(tmp_path))) == sorted('node_args_{}.pickle'.format(t) for t in chosen)
+    for task in chosen:
+        with open(os.path.join(str(tmp_path), 'node_args_{}.pickle'.format(task)), 'rb') as f:
+            node, inputs = pickle.load(file=f)
+        assert node['name'] == net.G.nodes[task]['name'] and not [k for k in node if isinstance(k, str) and k.startswith('_')]
+        assert all(type(v) is np.ndarray for v in inputs.values())
+        op = importlib.import_module('oracle.op_plugins.' + node['type'])
+        res = op.compute(node, inputs, kernel_type='special')
+        port = next(iter(res))
+        assert np.array_equal(res[port], np.asarray(net.G.nodes[task]['output'][port]['data']))
