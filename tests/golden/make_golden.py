@@ -24,6 +24,8 @@ Fixtures
                            synthetic weights, 1 image: the (1,1,100,7) detections and the (1,2,7668) prior tensor
   mnist_fp16_e2e.npz       models/mnist rewritten as an FP16 IR (pyopenvino_amd.synth.fp16_ir) through the reference (numpy float16), 3 images
   conv_node6_fp16.npz      the same node fixture in float16 as the reference computes it (x, w, float16 output), cropped to 64x64
+  googlenet_fp16_rows2.npz models/googlenet-v1 rewritten as an FP16 IR (synthetic weights seed 1234 rounded to f16) through the reference, which
+                           computes it in numpy float16: float16 logits (the MatMul + Add in front of the SoftMax) of 2 seeded images
   googlenet_rows8.npz      the reference's N=1 answers for 8 seeded images on the synthetic GoogLeNet weights
   conv_node6_crop.npz      the reference's own single-node fixture resources/node_args_6.pickle (SSD Conv2d_0,
                            3x3 stride 2 same_upper pads (0,0)/(1,1)), input cropped to 64x64 and cast to fp32
@@ -278,6 +280,38 @@ def fp16_case(IECore):
     print('  out', out.shape, 'argmax', out.argmax(axis=1), 'logits', logits[0])
 
 
+def googlenet_fp16_case(IECore, nimg=2):
+    """googlenet_fp16_rows2.npz: the benchmarked FP16 entry's parity anchor.  models/googlenet-v1 as an FP16 IR (synth.fp16_ir of the
+    synthetic seed-1234 blob: every constant stored as f16, every port FP16) through the reference, which then computes every node in
+    numpy float16 (`pyopenvino/common_def.py:13-17`); the float16 logits -- the tensor in front of the SoftMax, whose exp() overflows
+    float16 -- and the SoftMax output as it comes, for images 500 and 501 of googlenet_rows8.npz."""
+    print('googlenet-v1 as an FP16 IR through the reference (float16 numpy; slow: no BLAS for float16)')
+    tmp = '/tmp/pv_golden_models'
+    os.makedirs(tmp, exist_ok=True)
+    xml = os.path.join(REF, 'models', 'googlenet-v1.xml')
+    xml16, blob16 = synth.fp16_ir(xml, synth.synth_weights(xml, 1234), tmp)
+    stem = xml16[:-4]
+    with open(stem + '.bin', 'wb') as f:
+        f.write(blob16)
+    outs, logits = [], []
+    for i in range(nimg):
+        ie = IECore()
+        net = ie.read_network(stem + '.xml', stem + '.bin')
+        ex = ie.load_network(net, 'CPU')
+        ex.kernel_type = 'special'
+        o = np.ascontiguousarray(ex.infer({net.inputs[0]['name']: synth.uniform_pixels(500 + i, (1, 3, 224, 224))})[net.outputs[0]['name']])
+        assert o.dtype == np.float16, o.dtype
+        outs.append(o.astype(np.float32))
+        soft = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'SoftMax')
+        pre = next(iter(net.G.pred[soft]))
+        lg = np.asarray(next(iter(net.G.nodes[pre]['output'].values()))['data'])
+        assert lg.dtype == np.float16 and np.isfinite(lg).all()
+        logits.append(lg.astype(np.float32))
+        print('  image', 500 + i, 'logits max', float(np.abs(lg).max()), 'argmax', int(lg.argmax()))
+    np.savez_compressed(os.path.join(HERE, 'googlenet_fp16_rows2.npz'), logits=np.concatenate(logits, 0), out=np.concatenate(outs, 0),
+                        image_seeds=np.array([500 + i for i in range(nimg)]), weight_seed=np.array(1234))
+
+
 def run_model(IECore, model, x, input_name=None, capture_layers=False):
     """Reference, kernel_type='special', N=1.  Returns the Result array and {node id: float64 sum}."""
     ie = IECore()
@@ -448,6 +482,9 @@ def main():
         fp16_case(IECore)
         node6_fp16_case(plugins)
         return
+    if 'googlenet_fp16' in sys.argv[1:]:
+        googlenet_fp16_case(IECore)
+        return
     if 'head' in sys.argv[1:]:           # only the SSD head per-op fixtures and the end-to-end SSD fixture
         head_cases(plugins)
         ssd_full_case(IECore)
@@ -459,6 +496,7 @@ def main():
     model_cases(IECore)
     googlenet_rows_case(IECore)
     fp16_case(IECore)
+    googlenet_fp16_case(IECore)
     ssd_backbone_case(IECore)
     ssd_full_case(IECore)
     print('done')

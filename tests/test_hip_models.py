@@ -433,3 +433,38 @@ def test_pickle_node_args_from_a_fused_device_pass_replays_through_the_oracle(hi
     infer_one(ex1, net1, x)
     got = np.asarray(next(iter(net1.G.nodes[conv]['output'].values()))['data'])
     assert_close(got, want, helpers.REL_TOL, 'replayed node {}'.format(node['name']))
+
+
+def _googlenet_fp16_logits(plugin_package, fp16_as_fp32, images, tmp_path):
+    from pyopenvino_amd import IECore, synth
+    xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    xml16, blob16 = synth.fp16_ir(xml, synth.synth_weights(xml, 1234), str(tmp_path))
+    ie = IECore(plugin_package=plugin_package)
+    net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=fp16_as_fp32)
+    net.set_batch(len(images))
+    ex = ie.load_network(net)
+    prob = helpers.infer_one(ex, net, images)
+    soft = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'SoftMax')
+    return prob, np.asarray(next(iter(net.G.nodes[next(iter(net.G.pred[soft]))]['output'].values()))['data']), net
+
+
+def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp_path):
+    """The FP16 entry bench.py times (GoogLeNet as an FP16 IR, Convolution / MatMul on v_mfma_f32_32x32x16_f16 with fp32 accumulation)
+    against the REFERENCE's numpy-float16 run of the same IR (googlenet_fp16_rows2.npz: float16 logits of images 500 / 501; its
+    float16 SoftMax overflows): logits within 1e-2 of their maximum (the reference rounds every tensor and partial sum to float16; fp32
+    arithmetic on the same constants is 9e-4 away from it), the same class; and within 5e-3 of this build's fp32 pass on the same IR."""
+    from pyopenvino_amd import synth
+    z = np.load(os.path.join(GOLDEN, 'googlenet_fp16_rows2.npz'))
+    images = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
+    prob16, logits16, net16 = _googlenet_fp16_logits(HIP, False, images, tmp_path)
+    assert net16.f16_mfma and all('_hip_wpack16' in net16.G.nodes[n] for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution')
+    prob32, logits32, net32 = _googlenet_fp16_logits(HIP, True, images, tmp_path)
+    assert not net32.f16_mfma
+    err_ref, err_32 = helpers.rel_err(logits16, z['logits']), helpers.rel_err(logits16, logits32)
+    print('GoogLeNet FP16 IR on f16 MFMA: logits {:.2e} from the reference float16 run, {:.2e} from fp32 arithmetic; fp32 arithmetic {:.2e} '
+          'from the reference'.format(err_ref, err_32, helpers.rel_err(logits32, z['logits'])))
+    assert np.isfinite(prob16).all() and np.array_equal(logits16.argmax(axis=1), z['logits'].argmax(axis=1))
+    assert err_ref <= 1e-2, err_ref
+    assert helpers.rel_err(logits32, z['logits']) <= 3e-3
+    assert_close(logits16, logits32, 5e-3, 'f16 MFMA vs fp32 arithmetic, GoogLeNet FP16 IR', elementwise=False)
+    assert np.abs(prob16.sum(axis=1) - 1).max() <= 1e-4

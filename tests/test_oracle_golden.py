@@ -161,3 +161,24 @@ def test_oracle_on_the_reference_fp16_node_fixture():
             'output': {2: {'precision': 'FP32', 'dims': ref.shape}}}
     got = next(iter(importlib.import_module('oracle.op_plugins.Convolution').compute(node, {0: x, 1: w}, kernel_type='special').values()))
     assert got.shape == ref.shape and helpers.rel_err(got, ref) <= 2e-2
+
+
+def test_oracle_fp32_arithmetic_on_the_googlenet_fp16_ir_vs_reference_float16(tmp_path):
+    """googlenet_fp16_rows2.npz (the reference's numpy-float16 run of GoogLeNet as an FP16 IR, 2 images): the oracle's fp32 arithmetic on
+    the same f16 constants lands within float16 tolerance of its float16 logits and picks the same class -- what pins the fixture the
+    f16-MFMA pass is held against on the GPU (bench.py's FP16 entry)."""
+    from pyopenvino_amd import IECore, synth
+    z = np.load(os.path.join(GOLDEN, 'googlenet_fp16_rows2.npz'))
+    xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    xml16, blob16 = synth.fp16_ir(xml, synth.synth_weights(xml, int(z['weight_seed'])), str(tmp_path))
+    ie = IECore(plugin_package='oracle.op_plugins')
+    net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=True)
+    ex = ie.load_network(net)
+    ex.kernel_type = 'special'
+    soft = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'SoftMax')
+    pre = next(iter(net.G.pred[soft]))
+    for i, seed in enumerate(z['image_seeds'][:1]):
+        helpers.infer_one(ex, net, synth.uniform_pixels(int(seed), (1, 3, 224, 224)))
+        logits = np.asarray(next(iter(net.G.nodes[pre]['output'].values()))['data'])
+        assert helpers.rel_err(logits, z['logits'][i:i + 1]) <= 3e-3
+        assert logits.argmax() == z['logits'][i].argmax()
