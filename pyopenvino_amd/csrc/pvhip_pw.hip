@@ -206,16 +206,24 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
         }                                                                                                    \
     }
 
-    // ---- software pipeline.  The vector-memory counter retires in order, so what stays in flight is decided by the ORDER of
-    // issue.  Iteration j issues  [A(j+2): 2 loads into registers]  [B(j+3): NP LDS-DMA pieces]  and, after its MFMAs, waits
-    // for A(j+1) with vmcnt(2*NP + 2): everything up to A(j+1) has then landed -- B(j+1) among it, which the next iteration
-    // reads -- while B(j+2), A(j+2), B(j+3) stay in flight across the barrier: three stages of activations per workgroup are
-    // on their way at any time.  Four LDS buffers: stage j is read while j+1, j+2, j+3 land; B(j+3) overwrites the buffer
-    // stage j-1 was read from, behind the barrier every wave passes after its last read of it.  The weight loads are asm
-    // statements (hipcc would wait for "its" two loads with vmcnt(0) and drain the copies); three register sets rotate by
-    // name (an asm load's destination must not be copied before its wait).
+    // ---- software pipeline.  Iteration j issues  [A(j+2): 2 loads into registers]  [B(j+3): NP LDS-DMA pieces]  and, after its
+    // MFMAs, makes sure A(j+1) has landed.  Four LDS buffers: stage j is read while j+1, j+2, j+3 land; B(j+3) overwrites the buffer
+    // stage j-1 was read from, behind the barrier every wave passes after its last read of it.
+    //
+    // The weight loads are ORDINARY loads (hipcc tracks them and places their s_waitcnt itself); only the LDS-DMA copies, which have no
+    // register destination, are asm statements.  Rounds 1-2 issued the weight loads from asm too and waited for them in a second asm
+    // statement with a hand-counted vmcnt: between the two statements hipcc considers the destination register defined and may copy it
+    // before the data has landed (DESIGN lesson 24: wrong images at batch 256 next to other streams, in pvhip_wino.hip).  With tracked
+    // loads (buffer-load builtins: scalar panel offset, one lane offset) there is no such window, by construction: the vector-memory
+    // counter retires in order and hipcc counts only ITS loads, a
+    // subsequence of the real queue (the asm copies are invisible to it), so the vmcnt it emits can only wait for MORE than it needs.
+    // What that costs: its vmcnt(2) at the end of iteration j ("A(j+2) may still fly") lets only the last two operations of the
+    // iteration -- LDS-DMA pieces of B(j+3) -- stay in flight, everything issued before must have landed: one stage of latency hiding
+    // where the hand-counted vmcnt(2*NP+2) kept three (measured equal: latency was never this kernel's limit, lesson 18).
+    // B(j+1), which the next iteration reads after the barrier, is older than all of that (and has its own explicit wait, which names
+    // no register).  Three register sets rotate by name.
     const int S = a.S;
-    const float* ap_t = a.ap + (size_t)t * S * 512;      // wave-uniform
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ap), 0, (unsigned)(a.T * S) * 2048u, 0x00020000);
     const unsigned avoff = (unsigned)lane * 16u;
     const int boff = sub * 32 * tn + tn * l31;           // this lane's first pixel column in a tile row
 
@@ -229,11 +237,16 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
 #define PW_LOAD_A(set_, stage_)                                                                              \
     {                                                                                                        \
         const int sa_ = (stage_) < S ? (stage_) : S - 1;     /* past the end: the last stage again (never consumed) */ \
-        const float* pa_ = ap_t + (size_t)sa_ * 512;                                                         \
-        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"          \
-                     : "=&v"(ra[set_][0]), "=&v"(ra[set_][1]) : "v"(avoff), "s"(pa_) : "memory");             \
+        const unsigned so_ = (unsigned)(t * S + sa_) * 2048u;                                                \
+        ra[set_][0] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(ar, avoff, so_, 0));           \
+        ra[set_][1] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(ar, avoff + 1024u, so_, 0));   \
     }
-#define PW_WAIT_A(set_, cnt_) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[set_][0]), "+v"(ra[set_][1]) : "i"(cnt_) : "memory")
+    // a use of the set hipcc can see: its own s_waitcnt for the two loads goes in front of it
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PW_WAIT_A(set_) asm volatile("" : "+v"(ra[set_][0]), "+v"(ra[set_][1]) :: "memory")
+#else
+#define PW_WAIT_A(set_)
+#endif
 #define PW_STAGE(s_, cur_, ld_, nx_)                                                                         \
     {                                                                                                        \
         asm volatile("s_barrier" ::: "memory");                                                              \
@@ -243,7 +256,12 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
             PW_ISSUE(sd_, ((s_) + 3) & 3);                                                                   \
         }                                                                                                    \
         if (active && !(ABL & 4)) pw_mfma_stage<TN>(&Bs[(s_) & 3][lh][boff], ra[cur_], acc);   \
-        PW_WAIT_A(nx_, 2 * NP + 2);                                                                          \
+        PW_WAIT_A(nx_);                                                                                      \
+        /* this wave's pieces of B(j+1) must be in LDS before the next barrier.  Younger than them are B(j+2) and B(j+3) -- and */ \
+        /* the weight loads A(j+1), A(j+2), which are NOT counted: hipcc deletes the loads of the stages past the end, and a */ \
+        /* count that relied on them would let two pieces of B(j+1) fly there.  Not counting them only waits for more.  (No  */ \
+        /* register is involved: a hand-counted wait is safe here, and hipcc's own wait above has usually satisfied it.)     */ \
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NP) : "memory");                                       \
     }
 
     // prologue: A(0), A(1), B(0), B(1), B(2); A(0) and B(0) must have landed
@@ -252,15 +270,23 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
     PW_ISSUE(0, 0);
     { const int s1 = 1 < S ? 1 : S - 1; PW_ISSUE(s1, 1); }
     { const int s2 = 2 < S ? 2 : S - 1; PW_ISSUE(s2, 2); }
-    PW_WAIT_A(0, 2 * NP);
+    PW_WAIT_A(0);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NP) : "memory");     // B(0) of this wave (B(1), B(2) may fly)
     const unsigned long long pw_t1 = PW_NOW();
 
-    for (int s = 0; s < S; s += 3) {
+    // whole triples in the loop, the one or two stages left behind it: with `break`s inside the loop hipcc's structurizer gave the
+    // loop ONE latch that the break paths reach too, and its vmcnt bookkeeping then entered the header with "set 0 may still be in
+    // flight" (true on the path that leaves behind the second stage, which never comes back): a vmcnt(3) in front of the first MFMA
+    // of every third stage, i.e. a wait for a load issued a few instructions earlier.
+    int s = 0;
+    for (; s + 3 <= S; s += 3) {
         PW_STAGE(s, 0, 2, 1);
-        if (s + 1 >= S) break;
         PW_STAGE(s + 1, 1, 0, 2);
-        if (s + 2 >= S) break;
         PW_STAGE(s + 2, 2, 1, 0);
+    }
+    if (s < S) {
+        PW_STAGE(s, 0, 2, 1);
+        if (s + 1 < S) PW_STAGE(s + 1, 1, 0, 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead copies must not outlive the workgroup's LDS
     const unsigned long long pw_t2 = PW_NOW();

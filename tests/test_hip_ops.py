@@ -208,6 +208,48 @@ def test_convolution_kernels_side_by_side_on_several_streams_at_batch_256(hip):
         dev.select_stream(0)
 
 
+@pytest.mark.parametrize('tn', ['1', '2', '4'])
+def test_pointwise_kernel_forms_side_by_side_on_several_streams_at_batch_256(hip, monkeypatch, tn):
+    """Every instantiation of conv_pw_kernel -- 1 / 2 / 4 channel tiles per workgroup (PVHIP_PW_TN), 16-byte and dword activation
+    copies (28x28 and 7x7 images) -- next to each other and to a Winograd layer on four streams, three times over: the bits each
+    gives alone.  (Its weight loads were asm statements with a hand-counted wait in rounds 1-2; a register copied while a load was
+    still on its way into it would show here, as it did for the Winograd kernel.)"""
+    from pyopenvino_amd import device as dev, synth
+    from pyopenvino_amd.op_plugins import Convolution as conv
+    helpers.setenv(monkeypatch, 'PVHIP_PW_TN', tn)
+    layers = [((256, 64, 28, 28), 96, 1), ((256, 192, 7, 7), 128, 1), ((256, 16, 28, 28), 64, 3), ((256, 48, 14, 14), 160, 1)]
+    jobs = []
+    for i, (xs, k, ks) in enumerate(layers):
+        n, c, h, w = xs
+        x = dev.DeviceTensor.from_numpy(synth.normal(11 + i, 2, n * c * h * w).astype(np.float32).reshape(xs))
+        wt = dev.DeviceTensor.from_numpy((synth.normal(13 + i, 4, k * c * ks * ks) * (2.0 / (c * ks * ks)) ** 0.5).astype(np.float32).reshape((k, c, ks, ks)))
+        b = dev.DeviceTensor.from_numpy(synth.normal(15 + i, 6, k).astype(np.float32).reshape((1, k, 1, 1)))
+        pd = (ks // 2, ks // 2)
+        run = (lambda node={}, x=x, wt=wt, b=b, pd=pd: conv.launch(node, x, wt, (1, 1), pd, pd, 'explicit', bias=b, act=('relu',)))
+        dev.select_stream(0)
+        alone = np.asarray(run())
+        if ks == 1 and i == 0:      # the form asked for is the form that ran, and it is right
+            want = np.maximum(np.einsum('kc,nchw->nkhw', np.asarray(wt)[:, :, 0, 0].astype(np.float64), np.asarray(x)[:2].astype(np.float64))
+                              + np.asarray(b).astype(np.float64), 0)
+            assert_close(alone[:2], want.astype(np.float32), helpers.REL_TOL, 'pointwise TN={}'.format(tn))
+        jobs.append((xs, ks, run, alone))
+    try:
+        for rnd_ in range(2):
+            outs = []
+            for rep in range(3):
+                for i, (xs, ks, run, alone) in enumerate(jobs):
+                    dev.select_stream(i)
+                    outs.append((xs, ks, alone, run()))
+            for i in range(len(jobs)):
+                dev.select_stream(i)
+                dev.synchronize()
+            dev.select_stream(0)
+            for xs, ks, alone, y in outs:
+                assert_bit_exact(np.asarray(y), alone, 'conv {}x{} {} (PVHIP_PW_TN={}) next to the others'.format(ks, ks, xs, tn))
+    finally:
+        dev.select_stream(0)
+
+
 def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     """F(4x4, 3x3) (the layers with extents divisible by 4 and enough patches; forced here): one, odd and many channel
     stages, ragged channel blocks, fewer patches than a workgroup holds, several images, fused bias + ReLU written in place

@@ -290,3 +290,20 @@ def test_pickle_node_args_replays_a_node_like_the_reference(tmp_path):
         res = op.compute(node, inputs, kernel_type='special')
         port = next(iter(res))
         assert np.array_equal(res[port], np.asarray(net.G.nodes[task]['output'][port]['data']))
+
+
+def test_no_inline_asm_statement_loads_into_a_register(tmp_path):
+    """scripts/check_asm_loads.py (part of `make` and of build()): the sources pass, and the pattern of rounds 1-2 -- a load in one
+    asm statement, its s_waitcnt in another -- is what it rejects."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_asm_loads', os.path.join(helpers.REPO, 'scripts', 'check_asm_loads.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
+    old = ('asm volatile("global_load_dwordx4 %0, %2, %3\\n\\tglobal_load_dwordx4 %1, %2, %3 offset:1024" \\\n'
+           '             : "=&v"(a), "=&v"(b) : "v"(off), "s"(p) : "memory");')
+    got = [code for _, code in mod.asm_statements(old)]
+    assert len(got) == 1 and got[0].count('global_load_dwordx4') == 2
+    ok = 'asm volatile("s_mov_b32 m0, %0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m), "v"(v), "s"(r), "s"(o) : "memory");'
+    inst = [i for _, code in mod.asm_statements(ok) for i in code.split('\n')]
+    assert any('lds' in i for i in inst)
