@@ -17,11 +17,12 @@ reports those blocks' own median.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying
   roofline      for the dominant kernels, the fp32-MFMA Convolution launches (Winograd forms, pointwise, implicit GEMM):
-                `achieved` = ALGORITHMIC flops (2*N*K*C*kh*kw*oh*ow) of a step's launches / their device time, measured
-                with hipEvents on the compute stream inside the timed blocks; `frac_executed` = the flops the matrix
-                cores actually EXECUTE (Winograd families scaled by 16/36, 36/144, 36/100) over the same time, which is
-                what compares with the MFMA peak; `per_kernel` = the same per kernel family with its own bound
-                min(MFMA peak, arithmetic intensity x HBM peak);
+                `achieved` / `frac` = the flops the matrix cores EXECUTE per launch (Winograd families: 16/36, 36/144, 36/100 of the
+                algorithmic count, padded patches included) / the launches' device time, measured with hipEvents on the compute
+                stream inside the timed blocks, against the 157.3 TFLOP/s fp32 MFMA peak; `achieved_algorithmic` /
+                `frac_algorithmic` = SURVEY 8(d)'s algorithmic flops (2*N*K*C*kh*kw*oh*ow) over the same time (how fast the layers
+                get done; may exceed 1); `per_kernel` = per kernel family with its own bound min(MFMA peak, arithmetic intensity x
+                HBM peak); `traffic` / `traffic_by_kernel` = HBM bytes per launch from the committed PMC passes;
   cpu_baseline  the oracle (CPU restatement of the reference's 'special' path) timed on this host, N=1 per
                 image like the reference, on a bounded sample of the same workload;
   single_request_images_per_sec   one synchronous infer() at a time (SURVEY 8(d): B / wall time of one infer, median);
@@ -115,6 +116,12 @@ def mfma_ceiling(device):
     """What THIS box sustains on v_mfma_f32_32x32x2_f32 with nothing else in the instruction stream (pvhip_mfma_ceiling_f32: one
     wave per SIMD, operands in registers, random data, a 2-3 ms kernel), the shader clock it holds meanwhile, and the same with a
     VALU-only wave beside every MFMA wave.  157.3 TFLOP/s is the rate at 2.4 GHz; the chip lowers its clock under matrix load."""
+    # a probe of the DIAGNOSTIC build (libpvhip_diag.so, include/pvhip_diag.h), loaded beside the product library for this measurement only
+    try:
+        device.diag_library()
+    except Exception as exc:       # noqa: BLE001 -- informational: the line then says it has no such figure
+        print('bench.py: roofline.sustained not measured: {}'.format(exc), file=sys.stderr)
+        return None
     # the clock ramps up over the first milliseconds after idle: best of four back-to-back runs
     tf, ghz = max(device.mfma_ceiling_f32(False, 20000) for _ in range(4))
     tf_v, ghz_v = max(device.mfma_ceiling_f32(True, 20000) for _ in range(2))
@@ -350,8 +357,9 @@ def main():
         ex.compute_streams, ex.stream_base = saved
     ex.device_timing_runs = False
     ex.compute_streams = 1
-    if informational:
-        # the per-layer breakdown, one hipEvent bracket per launch, on one stream, untimed
+    if informational or (world > 1 and not args.no_node_timing):
+        # the per-layer breakdown, one hipEvent bracket per launch, on one stream, untimed.  In a multi-rank run EVERY rank makes these
+        # three passes (their Result gathers are collectives); rank 0's times go into the line (`roofline.per_kernel`, `per_op`)
         ex.device_timing = KERNEL_NODES
         for _ in range(3):
             ex.infer({in_name: x_dev})
@@ -519,12 +527,15 @@ def main():
                 avg_launch_ms = conv['ms'] / n_launch                # hipEvents on the compute stream, timed steps
                 tf = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
                 tf_exec = conv['exec'] / (conv['ms'] * 1e-3) / 1e12
-                traffic, traffic_src = None, None
+                traffic, traffic_src, traffic_by_kernel = None, None, None
                 for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_traffic.json')), reverse=True):
                     try:
                         doc = json.load(open(path))
                         k = doc['kernels']['convolution_kernels']
                         traffic = k['read_bytes_per_launch'] + k['write_bytes_per_launch']
+                        traffic_by_kernel = {name: {'launches_per_step': v.get('launches_per_step'), 'bytes_per_launch': v['read_bytes_per_launch'] + v['write_bytes_per_launch'],
+                                                    'algorithmic_bytes_per_launch': v.get('algorithmic_bytes_per_launch')}
+                                             for name, v in doc.get('convolution_kernels_by_family', {}).items()}
                         traffic_src = 'static: {} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_bench.sh, tree {}; ' \
                                       'not re-measured in this run)'.format(os.path.relpath(path, REPO), doc.get('tree', 'unknown'))
                         break
@@ -540,14 +551,15 @@ def main():
                                        'TFLOPs_executed': round(agg['exec'] / (agg['ms'] * 1e-3) / 1e12, 1),
                                        'bound_TFLOPs': round(bound_tf, 1),
                                        'frac_executed_of_bound': round(agg['exec'] / (agg['ms'] * 1e-3) / 1e12 / bound_tf, 3)}
-                roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': tf / PEAK_MFMA_F32_TFLOPS,
-                        'frac_executed': tf_exec / PEAK_MFMA_F32_TFLOPS, 'achieved_executed': tf_exec,
-                        'frac_note': '`achieved` / `frac` count ALGORITHMIC flops (2*N*K*C*kh*kw*oh*ow: SURVEY 8(d)); the Winograd families execute 16/36 '
-                                     '(F(2x2,3x3)), 36/144 (F(4x4,3x3)) or 36/100 (F(2x2,5x5)) of them on the matrix cores, so `frac` can exceed what the MFMA pipe '
-                                     'does: `frac_executed` is executed flops / peak, the figure that compares with matrix-core utilisation',
-                        'sustained': dict(sustained, frac_executed_of_sustained=round(tf_exec / sustained['TFLOPs'], 3)) if sustained else None,
-                        'traffic': traffic, 'traffic_source': traffic_src,
+                roof = {'bound': 'mfma', 'achieved': tf_exec, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': tf_exec / PEAK_MFMA_F32_TFLOPS,
+                        'achieved_algorithmic': tf, 'frac_algorithmic': tf / PEAK_MFMA_F32_TFLOPS,
+                        'frac_note': '`achieved` / `frac` count the flops the matrix cores EXECUTE per launch (a roofline fraction: never above 1); '
+                                     '`achieved_algorithmic` / `frac_algorithmic` count SURVEY 8(d)\'s algorithmic flops (2*N*K*C*kh*kw*oh*ow), of which the '
+                                     'Winograd families execute 16/36 (F(2x2,3x3)), 36/144 (F(4x4,3x3)) or 36/100 (F(2x2,5x5)), padded patches included -- '
+                                     'that figure says how fast the layers are done, not how busy the MFMA pipe is, and may exceed 1',
+                        'sustained': dict(sustained, frac_of_sustained=round(tf_exec / sustained['TFLOPs'], 3)) if sustained else None,
+                        'traffic': traffic, 'traffic_source': traffic_src, 'traffic_by_kernel': traffic_by_kernel or None,
                         'kernel': 'all Convolution launches of a step: conv_wino4_kernel (F(4x4,3x3), F(2x2,5x5)) + conv_wino_kernel (F(2x2,3x3)) + conv_pw_kernel '
                                   '(1x1; the 1x1 / 3x3_reduce / 5x5_reduce convolutions of an inception module are one launch) + conv_pool1x1_kernel (MaxPool + pool_proj) '
                                   '+ conv_igemm_dma_kernel (conv1, the 7x7-sized 5x5): {} launches per step for the 57 Convolution nodes, bias+ReLU fused'.format(n_launch),

@@ -162,13 +162,6 @@ int pvhip_transpose_f32(const float* x, float* y, int rank, const int64_t* in_sh
 int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int k,
                      int trans_a, int trans_b);
 
-/* Measurement utility, no reference counterpart: TFLOP/s this device SUSTAINS on v_mfma_f32_32x32x2_f32 alone (one wave per
- * SIMD, operands in registers, random data) and the shader clock it holds meanwhile (s_memtime / s_memrealtime) -- the chip
- * lowers its clock under matrix load, so this is the ceiling bench.py quotes beside the 157.3 TFLOP/s of 2.4 GHz.
- * mode 1: a second wave per SIMD issues v_fma_f32 only (fp32 matrix and vector instructions of a SIMD do not overlap);
- * mode 2: the v_mfma_f32_16x16x4_f32 shape (same flops per cycle; measured: the same sustained rate).  The clock ramps up over
- * the first milliseconds after idle: call it a few times and take the best.                                                 */
-int pvhip_mfma_ceiling_f32(int mode, int iters, double* tflops, double* clock_ghz);
 
 /* Convolution.py:57-87 im2col + kernel_Convolution_im2col ("special"), as an implicit GEMM:
  *   y[n,k,oy,ox] = sum_{c,r,s} xpad[n,c,oy*sh+r,ox*sw+s] * w[k,c,r,s]      (dilation ignored, as :72-87 does)

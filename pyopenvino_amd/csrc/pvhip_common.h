@@ -27,13 +27,15 @@ State& state();
 struct Settings {
     int generation = 0;          // bumped by every (re)load: host-side plan caches key on it
     // ---- product switches
-    int  conv_kernel    = 0;     // PVHIP_CONV_KERNEL: 0 = LDS-DMA kernels (default), 1 = "lds" (register-staged), 2 = "wave"
+    int  conv_kernel    = 0;     // PVHIP_CONV_KERNEL (diagnostic build only): 0 = LDS-DMA kernels (default), 1 = "lds" (register-staged), 2 = "wave"
     bool conv_winograd  = true;  // PVHIP_CONV_WINOGRAD=0: direct kernels for the 3x3 / 5x5 layers
     int  conv_winograd4 = 1;     // PVHIP_CONV_WINOGRAD4: 0 off, 1 by size rule, 2 ("force") any size
     int  conv_winograd5 = 1;     // PVHIP_CONV_WINOGRAD5: likewise for F(2x2,5x5)
     bool conv_pointwise = true;  // PVHIP_CONV_POINTWISE=0: 1x1 layers on the general LDS-DMA kernel
     int  fuse_poolconv  = 1;     // PVHIP_FUSE_POOLCONV: 0 off, 1 rows of whole 16- or 8-byte groups, 4 only 16-byte groups (A/B runs)
     bool pool3          = true;  // PVHIP_POOL3=0: the one-shot MaxPool kernel for 3x3 windows too
+    int  stream_nt      = 1;     // PVHIP_STREAM_NT: nontemporal loads / stores in the streaming kernels: 0 never, 1 from 64 MiB moved on, 2 always
+    int  stream_wg      = 16;    // PVHIP_STREAM_WG: workgroups per CU of the grid-stride streaming kernels
     // ---- tuning runs (scripts/): defaults are what the product uses
     int  tile_bm = 0, tile_bn = 0;         // PVHIP_CONV_TILE=BMxBN
     int  wtile_m = 2, wtile_n = 1;         // PVHIP_CONV_WTILE=TMxTN (wave kernel, units of 32)

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+#ifdef PVHIP_DIAG   // predecessor kernel, kept for A/B runs in the diagnostic build only (PVHIP_CONV_KERNEL=lds)
 // ---------------------------------------------------------------------------------------------------
 // (r,s)-major variant of the LDS-tiled kernel, used whenever C is a multiple of the stage depth (16).
 //
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
         }
     }
 }
+#endif  // PVHIP_DIAG
 
 // ---------------------------------------------------------------------------------------------------
 // LDS-DMA variant of the (r,s)-major kernel: both tiles go global -> LDS with `buffer_load ... lds`, no
@@ -744,6 +746,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     }
 }
 
+#ifdef PVHIP_DIAG   // alternative kernel, kept for A/B runs and ablations in the diagnostic build only (PVHIP_CONV_KERNEL=wave)
 // ---------------------------------------------------------------------------------------------------
 // Wave-direct variant: no LDS staging of operands and no barriers in the reduction loop.
 //
@@ -882,6 +885,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
     }
 }
 
+#endif  // PVHIP_DIAG
+
 // Is the (r,s)-major reduction order (conv_igemm_rs_kernel) used for this weight shape?
 inline bool rs_major(int c, int kh, int kw) { return c % kBK == 0 && kh * kw < 64; }
 
@@ -932,9 +937,14 @@ __global__ __launch_bounds__(kBlock) void conv_pack_kernel(const float* __restri
 
 inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
-// The LDS-DMA kernel is the default for (r,s)-major shapes; PVHIP_CONV_KERNEL=lds selects the register-staged
-// conv_igemm_rs_kernel instead (kept as a tested variant and for A/B measurements).
+// The LDS-DMA kernel serves every window of fewer than 64 taps; conv_igemm_kernel (register-staged, compare path) is the one general
+// fallback for larger windows.  The diagnostic build also carries the predecessors: PVHIP_CONV_KERNEL=lds selects the register-staged
+// conv_igemm_rs_kernel / conv_igemm_kernel<.., true> for A/B measurements (scripts/tune_conv.py, tests/diag_variants.py).
+#ifdef PVHIP_DIAG
 inline bool dma_enabled() { return settings().conv_kernel != 1; }
+#else
+inline bool dma_enabled() { return true; }
+#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
@@ -948,7 +958,9 @@ void launch_conv(const ConvArgs& a, int n_ptiles) {
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
         else
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
-    } else if (rs_major(a.C, a.kh, a.kw)) {
+    }
+#ifdef PVHIP_DIAG
+    else if (rs_major(a.C, a.kh, a.kw)) {
         const bool pointwise = a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
                                a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && settings().conv_pw16;   // 16-byte gather measured slower: opt-in
         const size_t dyn = (size_t)settings().conv_lds_pad_kb * 1024;
@@ -962,7 +974,8 @@ void launch_conv(const ConvArgs& a, int n_ptiles) {
     else if (a.kh * a.kw < 64)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0,
                            state().stream, a);
-    else
+#endif
+    else   // windows of 64 taps and more: the general fallback (the in-bounds test is a compare per element instead of a window-bit mask)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock),
                            0, state().stream, a);
 }
@@ -1081,6 +1094,7 @@ static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int 
         return PVHIP_OK;
     }
 
+#ifdef PVHIP_DIAG
     // ---- wave-direct kernel (PVHIP_CONV_KERNEL=wave, PVHIP_CONV_WTILE=TMxTN in units of 32)
     const size_t tab_bytes = (size_t)(a.kred_pad + kTabSpare) * sizeof(int2);
     if (settings().conv_kernel == 2 && tab_bytes <= 60 * 1024 && !rs_major(c, kh, kw)) {
@@ -1122,22 +1136,29 @@ static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int 
         return PVHIP_OK;
     }
 
+#endif  // PVHIP_DIAG
+
     // ---- tile selection (calibrated with scripts/tune_conv.py on the GoogLeNet shapes at batch 256):
     // 128-pixel tiles; 64 output channels per tile when that wastes less than half a tile and still
     // leaves >= 4 workgroups per CU, else 32.  PVHIP_CONV_TILE=BMxBN overrides (tuning runs only).
     int bm = (k_out % 64 == 0 || k_out % 64 > 32) ? 64 : 32, bn = 128;
     if (bm == 64 && (long)((a.P + 127) / 128) * ((k_out + 63) / 64) < 4 * kNumCU) bm = 32;
     if (kh == 1 && kw == 1) bm = 32;      // 1x1 layers: the smaller tile wins on every GoogLeNet shape (more workgroups per CU)
+#ifdef PVHIP_DIAG
     if (settings().tile_bm > 0) { bm = settings().tile_bm; bn = settings().tile_bn; }      // PVHIP_CONV_TILE: tuning runs only
+#endif
     a.n_mtiles       = (k_out + bm - 1) / bm;
     const int n_ptiles = (a.P + bn - 1) / bn;
 
+#ifdef PVHIP_DIAG
     if (bm == 128 && bn == 256) launch_conv<128, 256, 2, 2>(a, n_ptiles);
     else if (bm == 128 && bn == 128 && dma_enabled()) launch_conv<128, 128, 1, 4>(a, n_ptiles);
     else if (bm == 128 && bn == 128) launch_conv<128, 128, 2, 2>(a, n_ptiles);
     else if (bm == 64 && bn == 256) launch_conv<64, 256, 1, 4>(a, n_ptiles);
-    else if (bm == 64 && bn == 128) launch_conv<64, 128, 1, 4>(a, n_ptiles);
     else if (bm == 32 && bn == 256) launch_conv<32, 256, 1, 4>(a, n_ptiles);
+    else
+#endif
+    if (bm == 64) launch_conv<64, 128, 1, 4>(a, n_ptiles);
     else launch_conv<32, 128, 1, 4>(a, n_ptiles);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;

@@ -137,6 +137,7 @@ int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int
 
 }  // extern "C"
 
+#ifdef PVHIP_DIAG   // diagnostic build only (include/pvhip_diag.h): not in the product library
 // ---------------------------------------------------------------------------------------------------------------------------
 // Measurement utility (bench.py's roofline.sustained): what THIS device sustains on v_mfma_f32_32x32x2_f32 with nothing else in
 // the instruction stream -- operands in registers, random data (all-zero operands let the chip hold a higher clock), every SIMD
@@ -230,3 +231,4 @@ extern "C" int pvhip_mfma_ceiling_f32(int mode, int iters, double* tflops, doubl
     (void)hipFree(clocks);
     return PVHIP_OK;
 }
+#endif  // PVHIP_DIAG

@@ -5,6 +5,14 @@ using namespace pvhip;
 
 namespace {
 
+// Global accesses of the LRN / pooling streams are NONTEMPORAL: every element is read once and written once, and on this chip a 16-byte
+// stream with nt loads and stores runs at 6.0-6.4 TB/s against 5.1-5.4 plain (profiles/r03_stream_sweep.md).  One switch for A/B builds.
+constexpr bool kStreamNT = true;
+template <class T>
+__device__ __forceinline__ T ldnt(const T* p) { return kStreamNT ? __builtin_nontemporal_load(p) : *p; }
+template <class T>
+__device__ __forceinline__ void stnt(T* p, T v) { if (kStreamNT) __builtin_nontemporal_store(v, p); else *p = v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void lrn_window_kernel(const float* __restr
             const float d_ = bias + alpha * s_[v];                                             \
             o_[v]          = lrn_div(ext[(j_) + HALF][v], d_, beta, beta_mode);                \
         }                                                                                      \
-        yv[(size_t)(ch_) * cstride] = o_;                                                      \
+        stnt(yv + (size_t)(ch_) * cstride, o_);                                                      \
     }
 
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -101,12 +109,12 @@ __global__ __launch_bounds__(kBlock) void lrn_window_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 2 * HALF; ++j) ext[j] = (vec_t)(0.0f);
 #pragma unroll
-        for (int j = 0; j < T; ++j) ext[2 * HALF + j] = xv[(size_t)j * cstride];
+        for (int j = 0; j < T; ++j) ext[2 * HALF + j] = ldnt(xv + (size_t)j * cstride);
         // chunks 0 .. n_chunks-2: prefetch the next chunk, emit what this one completes
         for (int k = 0; k + 1 < n_chunks; ++k) {
             const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
 #pragma unroll
-            for (int j = 0; j < T; ++j) nxt[j] = xn[(size_t)j * cstride];
+            for (int j = 0; j < T; ++j) nxt[j] = ldnt(xn + (size_t)j * cstride);
             if (k == 0) {
 #pragma unroll
                 for (int j = HALF; j < T; ++j) PV_LRN_OUT(j, j - HALF)
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
                     anynan = anynan | __builtin_isunordered(v0, v1) | (v2 != v2);
                 }
                 if (zpad[i]) m = fmaxf(m, 0.0f);
-                *yo = anynan ? NAN : m;
+                stnt(yo, anynan ? NAN : m);
             }
         }
         __syncthreads();
@@ -263,11 +271,11 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
 #pragma unroll
     for (int j = 0; j < 2 * HALF; ++j) ext[j] = (vec_t)(0.0f);
 #pragma unroll
-    for (int j = 0; j < T; ++j) ext[2 * HALF + j] = xv[(size_t)j * cstride];
+    for (int j = 0; j < T; ++j) ext[2 * HALF + j] = ldnt(xv + (size_t)j * cstride);
     for (int k = 0; k + 1 < n_chunks; ++k) {
         const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
 #pragma unroll
-        for (int j = 0; j < T; ++j) nxt[j] = xn[(size_t)j * cstride];
+        for (int j = 0; j < T; ++j) nxt[j] = ldnt(xn + (size_t)j * cstride);
         if (k == 0) {
 #pragma unroll
             for (int j = HALF; j < T; ++j) PV_LRN_TO_LDS(j, j - HALF)
@@ -376,18 +384,18 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_kernel(LrnPoolArgs a, F
             float s_ = win[i_][0] * win[i_][0];                                                \
             _Pragma("unroll") for (int q = 1; q < SIZE; ++q) s_ = s_ + win[i_][q] * win[i_][q]; \
             const float d_ = a.bias + a.alpha * s_;                                            \
-            yimg[(size_t)((ch_) - HALF) * ohw + outo[i_]] = lrn_div(win[i_][HALF], d_, a.beta, beta_mode); \
+            stnt(yimg + (size_t)((ch_) - HALF) * ohw + outo[i_], lrn_div(win[i_][HALF], d_, a.beta, beta_mode)); \
         }                                                                                      \
     }
 
     vec_t cur[T], nxt[T];
 #pragma unroll
-    for (int j = 0; j < T; ++j) cur[j] = xv[(size_t)j * cstride];
+    for (int j = 0; j < T; ++j) cur[j] = ldnt(xv + (size_t)j * cstride);
     for (int k = 0; k < n_chunks; ++k) {
         if (k + 1 < n_chunks) {
             const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
 #pragma unroll
-            for (int j = 0; j < T; ++j) nxt[j] = xn[(size_t)j * cstride];
+            for (int j = 0; j < T; ++j) nxt[j] = ldnt(xn + (size_t)j * cstride);
         }
         if (active) {
 #pragma unroll

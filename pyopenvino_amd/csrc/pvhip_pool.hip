@@ -194,12 +194,31 @@ struct Pool3Args {
 
 typedef __attribute__((address_space(3))) void* pool_lds_ptr_t;
 
+// NT: nontemporal -- the input of a pooling launch is read once (halo rows twice) and its output written once; on this chip a 16-byte
+// stream with nt loads and stores runs at 6.0-6.4 TB/s against 5.1-5.4 plain (profiles/r03_stream_sweep.md).
+template <bool NT>
 __device__ __forceinline__ void pool_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned lds = (unsigned)(unsigned long)(pool_lds_ptr_t)dst;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    if (NT)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                     :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
 #endif
+}
+typedef float pool_f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void pool_st4(float* dst, const float* src_lds) {
+    const pool_f4v v = *reinterpret_cast<const pool_f4v*>(src_lds);
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<pool_f4v*>(dst));
+    else *reinterpret_cast<pool_f4v*>(dst) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void pool_st1(float* dst, float v) {
+    if (NT) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
 }
 __device__ __forceinline__ void pool_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -207,7 +226,7 @@ struct Pool3Divs {
     FastDiv bands, sow, ow;
 };
 
-template <int ST, bool STAGE>
+template <int ST, bool STAGE, bool NT>
 __global__ __launch_bounds__(kBlock) void maxpool3x3_cols_kernel(Pool3Args a, Pool3Divs dv) {
     extern __shared__ __attribute__((aligned(1024))) float lds3[];
     float* const outb = lds3 + 2 * a.in_floats;
@@ -228,12 +247,12 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_cols_kernel(Pool3Args a, Po
             const_cast<float*>(a.x + src), 0, (int)(left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left), 0x00020000);
         if (a.dense) {
             const int pieces = (gn * hw + 255) >> 8;
-            for (int q = wave; q < pieces; q += 4) pool_dma_b128(r, dst + q * 256, lane16, (unsigned)q * 1024u);
+            for (int q = wave; q < pieces; q += 4) pool_dma_b128<NT>(r, dst + q * 256, lane16, (unsigned)q * 1024u);
         } else {
             const int ppp = ((iy_hi - iy_lo) * a.w + 255) >> 8;               // pieces per plane
             for (int p = 0; p < gn; ++p)
                 for (int q = wave; q < ppp; q += 4)
-                    pool_dma_b128(r, dst + p * a.plane_l + q * 256, lane16, (unsigned)(p * hw) * 4u + (unsigned)q * 1024u);
+                    pool_dma_b128<NT>(r, dst + p * a.plane_l + q * 256, lane16, (unsigned)(p * hw) * 4u + (unsigned)q * 1024u);
         }
     };
 
@@ -298,10 +317,10 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_cols_kernel(Pool3Args a, Po
                 float* const yd = a.y + (size_t)g0 * ohw;
                 if (a.vec_out) {
                     const int n4 = n_out >> 2;
-                    for (int i = tid; i < n4; i += kBlock) reinterpret_cast<float4*>(yd)[i] = reinterpret_cast<const float4*>(outb)[i];
-                    for (int i = (n4 << 2) + tid; i < n_out; i += kBlock) yd[i] = outb[i];
+                    for (int i = tid; i < n4; i += kBlock) pool_st4<NT>(yd + 4 * i, outb + 4 * i);
+                    for (int i = (n4 << 2) + tid; i < n_out; i += kBlock) pool_st1<NT>(yd + i, outb[i]);
                 } else {
-                    for (int i = tid; i < n_out; i += kBlock) yd[i] = outb[i];
+                    for (int i = tid; i < n_out; i += kBlock) pool_st1<NT>(yd + i, outb[i]);
                 }
             } else {
                 const int run = rows_t * a.ow;
@@ -310,10 +329,10 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_cols_kernel(Pool3Args a, Po
                     const float* const so = outb + p * a.out_plane_l;
                     if (a.vec_out) {
                         const int n4 = run >> 2;
-                        for (int i = tid; i < n4; i += kBlock) reinterpret_cast<float4*>(yd)[i] = reinterpret_cast<const float4*>(so)[i];
-                        for (int i = (n4 << 2) + tid; i < run; i += kBlock) yd[i] = so[i];
+                        for (int i = tid; i < n4; i += kBlock) pool_st4<NT>(yd + 4 * i, so + 4 * i);
+                        for (int i = (n4 << 2) + tid; i < run; i += kBlock) pool_st1<NT>(yd + i, so[i]);
                     } else {
-                        for (int i = tid; i < run; i += kBlock) yd[i] = so[i];
+                        for (int i = tid; i < run; i += kBlock) pool_st1<NT>(yd + i, so[i]);
                     }
                 }
             }
@@ -660,13 +679,17 @@ int pvhip_maxpool2d_f32(const float* x, float* y, int n, int c, int h, int w, in
         if (plan_pool3(x, y, n * c, h, w, oh, ow, sh, pad_top, pad_left, a.hp, a.wp, pl3)) {
             Pool3Divs dv3{make_fastdiv((unsigned)pl3.a.n_bands), make_fastdiv((unsigned)(pl3.a.S * ow)), make_fastdiv((unsigned)ow)};
             const dim3 g3(pl3.grid), b3(kBlock);
-            if (sh == 1) {
-                if (pl3.stage) hipLaunchKernelGGL((maxpool3x3_cols_kernel<1, true>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
-                else           hipLaunchKernelGGL((maxpool3x3_cols_kernel<1, false>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
-            } else {
-                if (pl3.stage) hipLaunchKernelGGL((maxpool3x3_cols_kernel<2, true>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
-                else           hipLaunchKernelGGL((maxpool3x3_cols_kernel<2, false>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);
-            }
+            // nontemporal accesses from the size on where the tensors cannot stay in L2 for the consumer anyway (PVHIP_STREAM_NT)
+            const int  ntm = settings().stream_nt;
+            const bool nt  = ntm == 2 || (ntm == 1 && (size_t)n * c * ((size_t)h * w + (size_t)oh * ow) * 4 >= ((size_t)64 << 20));
+#define PV_P3(ST_, STAGE_)                                                                                            \
+    {                                                                                                                 \
+        if (nt) hipLaunchKernelGGL((maxpool3x3_cols_kernel<ST_, STAGE_, true>), g3, b3, pl3.lds, state().stream, pl3.a, dv3);  \
+        else    hipLaunchKernelGGL((maxpool3x3_cols_kernel<ST_, STAGE_, false>), g3, b3, pl3.lds, state().stream, pl3.a, dv3); \
+    }
+            if (sh == 1) { if (pl3.stage) PV_P3(1, true) else PV_P3(1, false) }
+            else         { if (pl3.stage) PV_P3(2, true) else PV_P3(2, false) }
+#undef PV_P3
             PVHIP_LAUNCH_CHECK();
             return PVHIP_OK;
         }

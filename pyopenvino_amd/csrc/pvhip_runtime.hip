@@ -32,21 +32,18 @@ void load_settings() {
     auto is0   = [&](const char* name) { const char* e = env(name); return e != nullptr && e[0] == '0'; };
     auto num   = [&](const char* name, int dflt) { const char* e = env(name); return e != nullptr ? atoi(e) : dflt; };
     auto tri   = [&](const char* name) { const char* e = env(name); return e == nullptr ? 1 : (e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1)); };
-    if (const char* e = env("PVHIP_CONV_KERNEL")) s.conv_kernel = strcmp(e, "lds") == 0 ? 1 : (strcmp(e, "wave") == 0 ? 2 : 0);
     s.conv_winograd  = !is0("PVHIP_CONV_WINOGRAD");
     s.conv_winograd4 = tri("PVHIP_CONV_WINOGRAD4");
     s.conv_winograd5 = tri("PVHIP_CONV_WINOGRAD5");
     s.conv_pointwise = !is0("PVHIP_CONV_POINTWISE");
     if (const char* e = env("PVHIP_FUSE_POOLCONV")) s.fuse_poolconv = e[0] == '0' ? 0 : (e[0] == '4' ? 4 : 1);
     s.pool3 = !(env("PVHIP_POOL3") != nullptr && num("PVHIP_POOL3", 1) == 0);
-    if (const char* e = env("PVHIP_CONV_TILE")) {
-        int bm = 0, bn = 0;
-        if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 32 || bm == 64 || bm == 128) && (bn == 128 || bn == 256)) { s.tile_bm = bm; s.tile_bn = bn; }
-    }
-    if (const char* e = env("PVHIP_CONV_WTILE")) sscanf(e, "%dx%d", &s.wtile_m, &s.wtile_n);
+    s.stream_nt = num("PVHIP_STREAM_NT", 1);
+    s.stream_wg = num("PVHIP_STREAM_WG", 16);
+    if (s.stream_wg < 1) s.stream_wg = 1;
+    if (s.stream_wg > 64) s.stream_wg = 64;
     s.conv_lds_pad_kb = num("PVHIP_CONV_LDS_PAD_KB", 0);
     s.conv_nopw = env("PVHIP_CONV_NOPW") != nullptr;
-    s.conv_pw16 = env("PVHIP_CONV_PW") != nullptr;
     { const int v = num("PVHIP_CONV_MULTI_BM", 32); s.multi_bm = (v == 64 || v == 128) ? v : 32; }
     s.pw_stagger_pct = num("PVHIP_PW_STAGGER", 0);
     s.pw_tn = num("PVHIP_PW_TN", 0);
@@ -65,6 +62,14 @@ void load_settings() {
     s.wino_balance = num("PVHIP_WINO_BALANCE", 1) != 0;
     s.wino_ragged = num("PVHIP_WINO_RAGGED", 1) != 0;
 #ifdef PVHIP_DIAG
+    // the predecessor convolution kernels and their tile overrides exist in the diagnostic build only
+    if (const char* e = env("PVHIP_CONV_KERNEL")) s.conv_kernel = strcmp(e, "lds") == 0 ? 1 : (strcmp(e, "wave") == 0 ? 2 : 0);
+    if (const char* e = env("PVHIP_CONV_TILE")) {
+        int bm = 0, bn = 0;
+        if (sscanf(e, "%dx%d", &bm, &bn) == 2 && (bm == 32 || bm == 64 || bm == 128) && (bn == 128 || bn == 256)) { s.tile_bm = bm; s.tile_bn = bn; }
+    }
+    if (const char* e = env("PVHIP_CONV_WTILE")) sscanf(e, "%dx%d", &s.wtile_m, &s.wtile_n);
+    s.conv_pw16 = env("PVHIP_CONV_PW") != nullptr;
     s.conv_ablate  = num("PVHIP_CONV_ABLATE", 0);
     s.wino4_ablate = num("PVHIP_WINO4_ABLATE", 0);
     s.pw_ablate    = num("PVHIP_PW_ABLATE", 0);

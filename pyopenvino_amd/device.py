@@ -11,6 +11,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpvhip.so')
+DIAG_LIB_PATH = os.path.join(_HERE, 'libpvhip_diag.so')      # diagnostic build (make diag): include/pvhip_diag.h
+# PVHIP_LIBRARY=<path>: load another build of the library instead (A/B runs against a previous commit's build; the test file of the
+# diagnostic build's extra kernels, tests/diag_variants.py, runs with the diagnostic library).  Never a CPU substitute: same C ABI.
+if os.environ.get('PVHIP_LIBRARY'):
+    LIB_PATH = os.path.abspath(os.environ['PVHIP_LIBRARY'])
 
 MAX_RANK = 6
 MAX_CONCAT = 16
@@ -70,7 +75,6 @@ SIGNATURES = {
     'pvhip_concat_f32': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _i64p, _fp, _c.c_int64]),
     'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
-    'pvhip_mfma_ceiling_f32': (_c.c_int, [_c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
     'pvhip_conv2d_pack_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
     'pvhip_conv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
@@ -190,12 +194,39 @@ def synchronize():
     call('pvhip_sync')
 
 
+_diag_lib = None
+
+
+def diag_library():
+    """The diagnostic build as a SECOND library handle (its own state: initialised on the same device), for measurement probes that are
+    not part of the product library (include/pvhip_diag.h).  Harness only (bench.py, scripts/): nothing in the product path calls it."""
+    global _diag_lib
+    if _diag_lib is None:
+        if os.path.abspath(LIB_PATH) == os.path.abspath(DIAG_LIB_PATH):
+            _diag_lib = load_library()
+        else:
+            if not os.path.isfile(DIAG_LIB_PATH):
+                raise PvhipError('diagnostic build {} is missing -- run `make -C pyopenvino_amd/csrc diag`'.format(DIAG_LIB_PATH))
+            ensure_init()
+            lib = ctypes.CDLL(DIAG_LIB_PATH)
+            lib.pvhip_last_error.restype = _c.c_char_p
+            if lib.pvhip_init(int(_initialised_device)) != 0:
+                raise PvhipError('diagnostic build: pvhip_init failed: {}'.format(lib.pvhip_last_error().decode(errors='replace')))
+            _diag_lib = lib
+        _diag_lib.pvhip_mfma_ceiling_f32.restype = _c.c_int
+        _diag_lib.pvhip_mfma_ceiling_f32.argtypes = [_c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]
+    return _diag_lib
+
+
 def mfma_ceiling_f32(with_valu_partner: bool = False, iters: int = 20000):
     """(TFLOP/s, shader clock in GHz) this device sustains on v_mfma_f32_32x32x2_f32 alone -- or with a VALU-only wave beside
-    every MFMA wave (include/pvhip.h: pvhip_mfma_ceiling_f32).  A measurement utility for bench.py's roofline."""
+    every MFMA wave (include/pvhip_diag.h: pvhip_mfma_ceiling_f32, DIAGNOSTIC build).  A measurement utility for bench.py's roofline."""
     ensure_init()
+    lib = diag_library()
     tf, ghz = _c.c_double(0.0), _c.c_double(0.0)
-    call('pvhip_mfma_ceiling_f32', 1 if with_valu_partner else 0, int(iters), _c.byref(tf), _c.byref(ghz))
+    rc = lib.pvhip_mfma_ceiling_f32(1 if with_valu_partner else 0, int(iters), _c.byref(tf), _c.byref(ghz))
+    if rc != 0:
+        raise PvhipError('pvhip_mfma_ceiling_f32 failed ({}): {}'.format(rc, lib.pvhip_last_error().decode(errors='replace')))
     return float(tf.value), float(ghz.value)
 
 

@@ -18,6 +18,15 @@ def is_conv(name):
     return 'conv_igemm' in name or 'conv_wino' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name
 
 
+def conv_family(name):
+    """Which convolution kernel: the split of `convolution_kernels` (profiles/<tag>_traffic.json: convolution_kernels_by_family)."""
+    for key, fam in (('conv_wino4_kernel', 'conv_wino4_kernel'), ('conv_wino_kernel', 'conv_wino_kernel'), ('conv_pw_kernel', 'conv_pw_kernel'),
+                     ('conv_pool1x1_kernel', 'conv_pool1x1_kernel'), ('conv_igemm_dma_kernel', 'conv_igemm_dma_kernel'), ('conv_igemm', 'conv_igemm_other')):
+        if key in name:
+            return fam
+    return None
+
+
 def find(root, pattern):
     hits = glob.glob(os.path.join(root, '**', pattern), recursive=True)
     return max(hits, key=os.path.getmtime) if hits else None      # gpurun MERGES into gpurun_out/: an older run's files may still be there
@@ -102,6 +111,10 @@ def main():
             agg = per_kernel.setdefault(fam, [0.0, 0])
             agg[0] += float(r['Counter_Value'])
             agg[1] += 1
+            if fam == 'convolution_kernels':       # ... and split by kernel
+                agg = per_kernel.setdefault('conv:' + conv_family(r['Kernel_Name']), [0.0, 0])
+                agg[0] += float(r['Counter_Value'])
+                agg[1] += 1
         traffic[counter] = {k: {'sum_kb': v[0], 'launches': v[1]} for k, v in per_kernel.items()}
     if traffic.get('FETCH_SIZE') and traffic.get('WRITE_SIZE'):
         out = {'tag': tag, 'tree': os.environ.get('PVHIP_TREE', 'unknown'), 'note': 'KB counters from separate --pmc passes; read side doubled (gfx950 FETCH_SIZE reports half of a wide '
@@ -113,16 +126,23 @@ def main():
                 continue
             rd = 2.0 * f['sum_kb'] * 1024.0 / f['launches']
             wr = w['sum_kb'] * 1024.0 / max(1, w['launches'])
-            out['kernels'][fam] = {'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr, 'launches_sampled': f['launches']}
+            if fam.startswith('conv:'):
+                passes = max(1.0, traffic['FETCH_SIZE']['convolution_kernels']['launches'] / float(per_pass))
+                out.setdefault('convolution_kernels_by_family', {})[fam[5:]] = {
+                    'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr, 'launches_sampled': f['launches'], 'launches_per_step': round(f['launches'] / passes, 2)}
+            else:
+                out['kernels'][fam] = {'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr, 'launches_sampled': f['launches']}
             md.append('| `{}` | {} | {:.2f} | {:.2f} | {:.2f} |'.format(fam, f['launches'], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
         with open(os.path.join(prof, tag + '_traffic.json'), 'w') as fo:
             json.dump(out, fo, indent=1)
     sq = find(os.path.join(raw, 'pmc_SQ'), '*counter_collection.csv')
     if sq:
-        agg = {}
+        agg, fam_agg = {}, {}
         for r in csv.DictReader(open(sq)):
             if is_conv(r['Kernel_Name']):
                 agg[r['Counter_Name']] = agg.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+                fa = fam_agg.setdefault(conv_family(r['Kernel_Name']), {})
+                fa[r['Counter_Name']] = fa.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
         if agg.get('GRBM_GUI_ACTIVE'):
             cyc = agg['GRBM_GUI_ACTIVE'] / 8.0
             md += ['', '## convolution kernels (conv_wino4 + conv_wino + conv_pw + conv_igemm_dma + conv_pool1x1), SQ counters summed over their launches', '']
@@ -142,6 +162,12 @@ def main():
                            '(bench.py: roofline.sustained)'.format(ghz)]
             for k in sorted(agg):
                 md.append('- {} = {:.4g}'.format(k, agg[k]))
+            md += ['', '| kernel | MFMA pipe busy, % of SIMD-cycles | CUs holding a wave, % | share of the convolution cycles, % |', '|---|---|---|---|']
+            for fam, fa in sorted(fam_agg.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0.0)):
+                c = fa.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+                if c:
+                    md.append('| `{}` | {:.1f} | {:.1f} | {:.1f} |'.format(fam, 100.0 * fa.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / c,
+                                                                     100.0 * fa.get('SQ_BUSY_CU_CYCLES', 0.0) / 256.0 / c, 100.0 * c / cyc))
     md += forked_md
     with open(os.path.join(prof, tag + '_summary.md'), 'w') as f:
         f.write('\n'.join(md) + '\n')

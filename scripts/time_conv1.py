@@ -4,7 +4,8 @@ import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-from pyopenvino_amd import device as dev, synth
+from pyopenvino_amd import device as dev
+dev.LIB_PATH = dev.DIAG_LIB_PATH      # PVHIP_CONV_KERNEL / _TILE / _WTILE variants exist in the diagnostic build only (make diag), synth
 from pyopenvino_amd.op_plugins import Convolution
 dev.init(0)
 n, c, h, w, k, ks = 256, 3, 224, 224, 64, 7

@@ -26,6 +26,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     m = re.search(r'#define\s+PVHIP_ABI_VERSION\s+(\d+)', header)
     assert lib.pvhip_abi_version() == int(m.group(1)) >= 9
     assert isinstance(lib.pvhip_last_error(), bytes)
+    # the diagnostic build exports all of that plus what include/pvhip_diag.h declares -- and the product library none of the latter
+    diag_header = open(os.path.join(REPO, 'include', 'pvhip_diag.h')).read()
+    diag_only = set(re.findall(r'\b(pvhip_[a-z0-9_]+)\s*\(', re.sub(r'/\*.*?\*/', '', diag_header, flags=re.S)))
+    assert diag_only and not (diag_only & declared) and not (diag_only & exported), diag_only & exported
+    if os.path.isfile(device.DIAG_LIB_PATH):
+        nm = subprocess.run(['nm', '-D', '--defined-only', device.DIAG_LIB_PATH], capture_output=True, text=True, check=True).stdout
+        assert (declared | diag_only) <= set(re.findall(r' T (pvhip_[a-z0-9_]+)', nm))
 
 
 def test_header_argument_counts_match_ctypes_signatures():
