@@ -141,6 +141,35 @@ inline int lrn_beta_mode(float beta, float bias) {
     return 0;
 }
 
+// Output stores of the convolution epilogues: ORDINARY stores.  Nontemporal ones (kConvStoreNT = true) were measured in round 3, on the
+// idea that the 4 MB a round of tiles writes per XCD evicts the input patches and weight fragments its workgroups re-read from the 4 MB
+// L2 they share (profiles/r03a: the six-point Winograd kernel fetches 3.5x its input from HBM): -5 % images/s, the Winograd
+// F(4x4,3x3) launches 2.05 -> 2.38 ms, the pointwise sibling launches +2 %, conv1 unchanged -- a lane's 16-byte pieces of different
+// rows are merged into whole lines by L2 when they are ordinary stores and go to memory one by one when they are not.  The switch stays
+// for A/B builds.
+constexpr bool kConvStoreNT = false;
+typedef float pv_f4v __attribute__((ext_vector_type(4)));
+typedef float pv_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void conv_store1(float* p, float v) {
+    if (kConvStoreNT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+__device__ __forceinline__ void conv_store2(float* p, float a, float b) {
+    pv_f2v v; v.x = a; v.y = b;
+    if (kConvStoreNT) __builtin_nontemporal_store(v, reinterpret_cast<pv_f2v*>(p));
+    else *reinterpret_cast<pv_f2v*>(p) = v;
+}
+__device__ __forceinline__ void conv_store4(float* p, float a, float b, float c, float d) {
+    pv_f4v v; v.x = a; v.y = b; v.z = c; v.w = d;
+    if (kConvStoreNT) __builtin_nontemporal_store(v, reinterpret_cast<pv_f4v*>(p));
+    else *reinterpret_cast<pv_f4v*>(p) = v;
+}
+template <class V>
+__device__ __forceinline__ void conv_storev(V* p, V v) {       // V: a float ext_vector_type
+    if (kConvStoreNT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // Global -> LDS loads (LDS-DMA), written as asm statements on purpose: hipcc treats the builtin form as a store to all
 // of LDS and puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialise the loads of stage t+1 with the
 // MFMAs of stage t.  The asm loads are invisible to its counters; a kernel waits for them itself (lds_dma_wait_all, or a

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_kernel(ConvArgs a) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + a.bias[ko];
                     v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                    yp[(size_t)ko * OHW] = v;
+                    conv_store1(yp + (size_t)ko * OHW, v);
                 }
             }
         }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + bv[r];
                     v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                    yp[(size_t)dr * OHW] = v;
+                    conv_store1(yp + (size_t)dr * OHW, v);
                 }
             }
         }
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
                 float v = acc[i][r];
                 if (a.bias != nullptr) v = v + bv[r];
                 v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                yp[(size_t)dr * OHW] = v;
+                conv_store1(yp + (size_t)dr * OHW, v);
             }
         }
     }
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_wave_kernel(ConvArgs a) {
                     float v = acc[i][j][r];
                     if (a.bias != nullptr) v = v + a.bias[ko];
                     v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                    yp[(size_t)ko * OHW] = v;
+                    conv_store1(yp + (size_t)ko * OHW, v);
                 }
             }
         }

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
                     float v = acc[i][r];
                     if (a.bias != nullptr) v = v + bv[r];
                     v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                    yp[(size_t)dr * HW] = v;
+                    conv_store1(yp + (size_t)dr * HW, v);
                 }
             }
         }

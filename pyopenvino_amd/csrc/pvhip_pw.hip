@@ -99,7 +99,7 @@ __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[
                 bvec_t v;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) v[j] = act_apply(acc[j][r] + bv[r], ab);
-                *reinterpret_cast<bvec_t*>(yp + (size_t)dr * a.HW) = v;
+                conv_storev(reinterpret_cast<bvec_t*>(yp + (size_t)dr * a.HW), v);
             }
         }
     } else {
@@ -113,7 +113,7 @@ __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
                 if (row0 + dr < klim) {
-                    yp[(size_t)dr * a.HW] = act_apply(acc[j][r] + bv[r], ab);
+                    conv_store1(yp + (size_t)dr * a.HW, act_apply(acc[j][r] + bv[r], ab));
                 }
             }
         }

@@ -339,10 +339,10 @@ __global__ __launch_bounds__(WAVES * kWave, (WAVES == 8 || MT * NTL == 1) ? 4 : 
                         ov[c2] = v;
                     }
                     if (pair_stores) {
-                        *reinterpret_cast<float2*>(yp + (size_t)r2 * OW) = make_float2(ov[0], ov[1]);
+                        conv_store2(yp + (size_t)r2 * OW, ov[0], ov[1]);
                     } else {
-                        yp[(size_t)r2 * OW] = ov[0];
-                        if (ox + 1 < OW) yp[(size_t)r2 * OW + 1] = ov[1];
+                        conv_store1(yp + (size_t)r2 * OW, ov[0]);
+                        if (ox + 1 < OW) conv_store1(yp + (size_t)r2 * OW + 1, ov[1]);
                     }
                 }
             }
@@ -707,15 +707,15 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                         if (RAGGED) {            /* only what exists; pairs where the rows are 8-byte aligned (even width) */ \
                             if (r2 < rows_ok) {                                                                  \
                                 _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {                            \
-                                    if (even_w && c2 + 1 < cols_ok) *reinterpret_cast<float2*>(yp + (size_t)r2 * OW + c2) = make_float2(ov[c2], ov[c2 + 1]); \
+                                    if (even_w && c2 + 1 < cols_ok) conv_store2(yp + (size_t)r2 * OW + c2, ov[c2], ov[c2 + 1]); \
                                     else {                                                                       \
-                                        if (c2 < cols_ok) yp[(size_t)r2 * OW + c2] = ov[c2];                     \
-                                        if (c2 + 1 < cols_ok) yp[(size_t)r2 * OW + c2 + 1] = ov[c2 + 1];         \
+                                        if (c2 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2, ov[c2]);                 \
+                                        if (c2 + 1 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2 + 1, ov[c2 + 1]);         \
                                     }                                                                            \
                                 }                                                                                \
                             }                                                                                    \
-                        } else if (M == 4) *reinterpret_cast<float4*>(yp + (size_t)r2 * OW) = make_float4(ov[0], ov[1], ov[2], ov[3]); \
-                        else        *reinterpret_cast<float2*>(yp + (size_t)r2 * OW) = make_float2(ov[0], ov[1]); \
+                        } else if (M == 4) conv_store4(yp + (size_t)r2 * OW, ov[0], ov[1], ov[2], ov[3]); \
+                        else        conv_store2(yp + (size_t)r2 * OW, ov[0], ov[1]); \
                     }                                                                                            \
                 }                                                                                                \
             }                                                                                                    \
