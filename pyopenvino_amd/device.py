@@ -167,10 +167,15 @@ def init(device: int = None) -> int:
     return device
 
 
+settings_serial = 0      # bumped by every reload: host-side plans that bake kernel choices in (a captured hipGraph) key on it
+
+
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
+    global settings_serial
     call('pvhip_settings_reload')
+    settings_serial += 1
 
 
 def ensure_init():

@@ -443,6 +443,7 @@ class Executable_Network:
         self.plan_fusion()
 
     def plan_fusion(self):
+        self._plan_serial = self.__dict__.get('_plan_serial', 0) + 1      # a captured pass is a pass of ONE plan
         """Peephole over the scheduled graph (SURVEY 8(f)-1): a Convolution whose only consumer is an Add of a
         per-output-channel Const (1,K,1,1), optionally followed by a ReLU as the Add's only consumer, is run
         as ONE launch: the Convolution plugin receives the bias tensor / relu flag on its node dict and
@@ -907,7 +908,7 @@ class Executable_Network:
             raise ValueError('capture_graph needs device-resident inputs (DeviceTensor): their addresses go into the graph')
         self.release_graph()
         for _ in range(max(1, warm)):           # the pool learns every block size of the pass: a capture must not hipMalloc
-            self.infer(inputs)
+            self._infer_eager(inputs)
         by_name = {G.nodes[n]['name']: n for n in G.nodes}
         for node_name, val in inputs.items():
             G.nodes[by_name[node_name]]['param'] = val
@@ -948,6 +949,7 @@ class Executable_Network:
         keep += [G.nodes[nid]['result'] for nid, _ in results]
         self._graph = {'handle': handle.value, 'inputs': dict(inputs), 'keep': keep,
                        'results': {name: G.nodes[nid]['result'] for nid, name in results}}
+        self._graph['by_hand'] = not self.__dict__.get('_auto_graph_busy')     # a recording made by hand is never replaced by infer()
         device.select_stream(0)
 
     def dump_node_args(self, task, node, inputs):
@@ -996,6 +998,8 @@ class Executable_Network:
 
     def release_graph(self):
         g = self.__dict__.pop('_graph', None)
+        if '_auto_graph' in self.__dict__:
+            self._auto_graph.update(captured=False, seen=0)
         if g is not None:
             from . import device
             import ctypes
@@ -1092,7 +1096,61 @@ class Executable_Network:
             out[name] = ports[next(iter(ports))]['data']
         return out
 
+    # ---- replay instead of dispatch.  A forward pass is ~100 plugin calls = 0.8-0.9 ms of Python + ctypes per pass; with inputs that
+    # are resident on the device -- the SAME tensors from call to call -- the pass is the same list of launches on the same addresses
+    # every time, so after AUTO_GRAPH_AFTER identical eager passes infer() records it into a hipGraph once (capture_graph) and replays it from then on with one call
+    # (infer_graph: bit-identical, tests/test_hip_models.py).  Anything that makes a pass differ -- other input tensors, another stream
+    # plan or fusion plan, re-read PVHIP_* settings, hooks that look at single nodes (verbose, expected_result, pickle_node_args,
+    # device_timing), a sharded batch -- runs eagerly, and a changed key drops the recording.  PVHIP_AUTO_GRAPH=0 turns it off.
+    AUTO_GRAPH_AFTER = 2
+
+    def _auto_graph_key(self, inputs, verbose):
+        from . import device
+        if verbose or os.environ.get('PVHIP_AUTO_GRAPH', '1') == '0' or self.__dict__.get('_auto_graph_busy'):
+            return None
+        if self.expected_result is not None or self.pickle_node_args or self.device_timing is not None or self.defer_sync:
+            return None
+        if self.comm is not None and getattr(self.comm, 'world', 1) > 1:
+            return None
+        if not inputs or not all(isinstance(v, device.DeviceTensor) for v in inputs.values()):
+            return None
+        registry = self.ienet.ie.plugins.plugins
+        if not all(getattr(sys.modules.get(m.__package__), 'DEVICE_STREAMS', False) for m in registry.values()):
+            return None
+        # (the recording reads the inputs where they lie: another tensor is another recording, never a copy into the caller's tensor)
+        return (tuple(sorted((k, tuple(v.shape), v.ptr) for k, v in inputs.items())), self.compute_streams, self.stream_base,
+                self.__dict__.get('_plan_serial', 0), self.fuse_epilogues, device.settings_serial, self.kernel_type)
+
     def infer(self, inputs: dict, verbose: bool = False) -> dict:
+        key = self._auto_graph_key(inputs, verbose)
+        state = self.__dict__.setdefault('_auto_graph', {'key': None, 'seen': 0, 'failed': False})
+        g = self.__dict__.get('_graph')
+        if key is None or state['failed'] or (g is not None and g.get('by_hand')):
+            return self._infer_eager(inputs, verbose)
+        if state['key'] != key:
+            if state['key'] is not None and self.__dict__.get('_graph') is not None and state.get('captured'):
+                self.release_graph()
+            state.update(key=key, seen=0, captured=False)
+        if state.get('captured') and self.__dict__.get('_graph') is not None:
+            self.last_node_times = []
+            return self.infer_graph(inputs)
+        state['seen'] += 1
+        if state['seen'] <= self.AUTO_GRAPH_AFTER:
+            return self._infer_eager(inputs, verbose)
+        self._auto_graph_busy = True
+        try:
+            self.capture_graph(inputs, warm=1)
+            state['captured'] = True
+        except Exception as exc:           # noqa: BLE001 -- replay is an optimisation: say why it is off, keep computing
+            state['failed'] = True
+            print('pyopenvino_amd: hipGraph replay of infer() disabled for this network ({}: {})'.format(type(exc).__name__, exc), file=sys.stderr)
+            return self._infer_eager(inputs, verbose)
+        finally:
+            self._auto_graph_busy = False
+        self.last_node_times = []
+        return self.infer_graph(inputs)
+
+    def _infer_eager(self, inputs: dict, verbose: bool = False) -> dict:
         G = self.ienet.G
         by_name = {G.nodes[n]['name']: n for n in G.nodes}
         for node_name, val in inputs.items():

@@ -468,3 +468,38 @@ def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp
     assert helpers.rel_err(logits32, z['logits']) <= 3e-3
     assert_close(logits16, logits32, 5e-3, 'f16 MFMA vs fp32 arithmetic, GoogLeNet FP16 IR', elementwise=False)
     assert np.abs(prob16.sum(axis=1) - 1).max() <= 1e-4
+
+
+def test_infer_replays_a_hipgraph_by_itself_for_device_resident_inputs(hip, monkeypatch):
+    """infer() with inputs that live on the device dispatches eagerly AUTO_GRAPH_AFTER times, then records the pass into a hipGraph and
+    replays it (one call instead of ~100 dispatches): the same bits every time; a host array, another stream plan or PVHIP_AUTO_GRAPH=0
+    go (back) to eager dispatch (the recording reads the inputs where they lie and never writes into a caller's tensor), and node hooks (device_timing) are honoured by running eagerly."""
+    from pyopenvino_amd import device, synth
+    _, net, ex = build_network(HIP, 'googlenet-v1', weights=synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), 1234), batch=4)
+    x_host = np.concatenate([synth.uniform_pixels(500 + i, (1, 3, 224, 224)) for i in range(4)], 0)
+    x = device.DeviceTensor.from_numpy(x_host)
+    name, out = net.inputs[0]['name'], net.outputs[0]['name']
+    first = np.asarray(ex.infer({name: x})[out])
+    assert ex.__dict__.get('_graph') is None
+    got = [np.asarray(ex.infer({name: x})[out]) for _ in range(4)]
+    assert ex.__dict__.get('_graph') is not None and ex._auto_graph['captured']
+    for g in got:
+        helpers.assert_bit_exact(g, first, 'replayed pass')
+    x2 = device.DeviceTensor.from_numpy(x_host[::-1].copy())                # another tensor: another recording, the first tensor is not touched
+    helpers.assert_bit_exact(np.asarray(ex.infer({name: x2})[out]), first[::-1].copy(), 'another input tensor')
+    assert np.array_equal(np.asarray(x), x_host) and not ex._auto_graph['captured']
+    helpers.assert_bit_exact(np.asarray(ex.infer({name: x_host})[out]), first, 'host input: eager')
+    ex.device_timing = {'Convolution'}
+    helpers.assert_bit_exact(np.asarray(ex.infer({name: x})[out]), first, 'node hooks: eager')
+    assert len(ex.device_times_ms()) > 0
+    ex.device_timing = None
+    ex.compute_streams = 1                                                 # another stream plan: the recording is dropped and made again
+    for _ in range(4):
+        helpers.assert_bit_exact(np.asarray(ex.infer({name: x})[out]), first, 'after a change of plan')
+    assert ex._auto_graph['captured']
+    monkeypatch.setenv('PVHIP_AUTO_GRAPH', '0')
+    ex.release_graph()
+    for _ in range(4):
+        helpers.assert_bit_exact(np.asarray(ex.infer({name: x})[out]), first, 'PVHIP_AUTO_GRAPH=0')
+    assert ex.__dict__.get('_graph') is None
+    assert_close(first[:2], np.load(os.path.join(GOLDEN, 'googlenet_rows8.npz'))['out'][:2], helpers.REL_TOL, 'rows vs the reference')
