@@ -504,8 +504,25 @@ int pvhip_graph_end_capture(void** graph_exec) {
         delete ge;
     };
     hipGraph_t g = nullptr;
+    // a capture that something invalidated on the way (a synchronisation, work on a stream that never joined it) must not reach
+    // hipGraphInstantiate: say so instead
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    const hipError_t qe = hipStreamIsCapturing(state().stream, &cst);
+    if (getenv("PVHIP_GRAPH_VERBOSE") != nullptr) fprintf(stderr, "pvhip_graph_end_capture: hipStreamIsCapturing -> %d, status %d\n", (int)qe, (int)cst);
     hipError_t e = hipStreamEndCapture(state().stream, &g);
-    if (e != hipSuccess) { release(); (void)hipGetLastError(); return fail(PVHIP_EHIP, "hipStreamEndCapture -> %s", hipGetErrorString(e)); }
+    if (getenv("PVHIP_GRAPH_VERBOSE") != nullptr) fprintf(stderr, "pvhip_graph_end_capture: hipStreamEndCapture -> %d, graph %p\n", (int)e, (void*)g);
+    if (e == hipSuccess && (g == nullptr || cst != hipStreamCaptureStatusActive)) e = hipErrorStreamCaptureInvalidated;
+    if (e != hipSuccess) {
+        if (g != nullptr) (void)hipGraphDestroy(g);
+        release();
+        (void)hipGetLastError();
+        return fail(PVHIP_EHIP, "hipStreamEndCapture -> %s (capture status %d)", hipGetErrorString(e), (int)cst);
+    }
+    if (getenv("PVHIP_GRAPH_VERBOSE") != nullptr) {
+        size_t n_nodes = 0;
+        (void)hipGraphGetNodes(g, nullptr, &n_nodes);
+        fprintf(stderr, "pvhip_graph_end_capture: %zu nodes\n", n_nodes);
+    }
     e = hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) { release(); return fail(PVHIP_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(e)); }

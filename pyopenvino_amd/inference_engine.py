@@ -898,10 +898,22 @@ class Executable_Network:
                 device.pool_epoch_end(epoch)
 
     # ---- hipGraph replay of a whole pass (what the reference's run_tasks loop, :259-292, becomes: one launch call)
-    def capture_graph(self, inputs: dict, warm: int = 2):
-        """Record one forward pass -- all its launches, on the base stream and on the streams the inception arms fork onto -- into a
-        hipGraph, for inputs that are resident on the device.  `infer_graph()` then replays it with ONE call instead of ~100
-        dispatches.  The graph holds the addresses of every tensor of the pass: they are kept alive with it (`release_graph`)."""
+    def capture_graph(self, inputs: dict, warm: int = 2, streams=1):
+        """Record one forward pass into a hipGraph, for inputs that are resident on the device.  `infer_graph()` then replays it with
+        ONE call instead of ~100 dispatches.  The graph holds the addresses of every tensor of the pass: they are kept alive with it
+        (`release_graph`).  `streams` = 1 (default): the pass is recorded on one compute stream, a linear chain of launches -- with the
+        persistent-grid kernels of this build that replays as fast as the forked form (googlenet-v1 batch 256: 44.5 k images/s either
+        way, scripts/time_replay.py).  `streams='plan'`: recorded as the stream plan forks it (`compute_streams`); hipStreamEndCapture of
+        ROCm 7.2 CRASHES (inside the runtime, not catchable) for some plans that use three or four streams -- the unfused GoogLeNet, the
+        FP16 one, the SSD IR (scripts/repro_capture.py) -- while the fused GoogLeNet plan records fine: use it only for a plan that has
+        been tried."""
+        if streams != 'plan':
+            saved_streams = self.compute_streams
+            self.compute_streams = max(1, int(streams))
+            try:
+                return self.capture_graph(inputs, warm=warm, streams='plan')
+            finally:
+                self.compute_streams = saved_streams
         from . import device
         G = self.ienet.G
         if not all(isinstance(v, device.DeviceTensor) for v in inputs.values()):
@@ -1116,6 +1128,11 @@ class Executable_Network:
             return None
         registry = self.ienet.ie.plugins.plugins
         if not all(getattr(sys.modules.get(m.__package__), 'DEVICE_STREAMS', False) for m in registry.values()):
+            return None
+        if '_graph_safe' not in self.__dict__:      # every layer type of this network says its compute() can be recorded
+            G = self.ienet.G                        # (a foreign plugin set does not: its pass stays eager)
+            self._graph_safe = all(getattr(registry.get(G.nodes[n]['type']), 'GRAPH_CAPTURE_SAFE', False) for n in G.nodes)
+        if not self._graph_safe:
             return None
         # (the recording reads the inputs where they lie: another tensor is another recording, never a copy into the caller's tensor)
         return (tuple(sorted((k, tuple(v.shape), v.ptr) for k, v in inputs.items())), self.compute_streams, self.stream_base,

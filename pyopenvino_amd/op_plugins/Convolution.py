@@ -26,6 +26,10 @@ SUPPORTS_SIBLINGS = True
 SUPPORTS_POOLED_INPUT = True
 
 
+# A pass made of such nodes can be recorded into a hipGraph (Executable_Network.infer does so by itself for device-resident inputs):
+# nothing in compute() synchronises with the host or reads a tensor back once the constants are cached.
+GRAPH_CAPTURE_SAFE = True
+
 def name():
     print('Convolution')
 

@@ -12,6 +12,10 @@ from .. import device as dev
 SUPPORTS_FUSED_EPILOGUE = True
 
 
+# A pass made of such nodes can be recorded into a hipGraph on ONE stream (Executable_Network.infer does so by itself for
+# device-resident inputs; the whole SSD IR was tried: scripts/repro_capture.py).
+GRAPH_CAPTURE_SAFE = True
+
 def name():
     print('GroupConvolution')
 

@@ -12,6 +12,10 @@ from . import MaxPool
 SUPPORTS_FUSED_POOL = True
 
 
+# A pass made of such nodes can be recorded into a hipGraph (Executable_Network.infer does so by itself for device-resident inputs):
+# nothing in compute() synchronises with the host or reads a tensor back once the constants are cached.
+GRAPH_CAPTURE_SAFE = True
+
 def _pool_geometry(pool_node: dict, h: int, w: int):
     attrs = pool_node['data']
     strides = common_def.string_to_tuple(attrs['strides'])

@@ -12,6 +12,10 @@ from .. import device as dev
 SUPPORTS_FUSED_LRN = True
 
 
+# A pass made of such nodes can be recorded into a hipGraph (Executable_Network.infer does so by itself for device-resident inputs):
+# nothing in compute() synchronises with the host or reads a tensor back once the constants are cached.
+GRAPH_CAPTURE_SAFE = True
+
 def _geometry(node: dict, h: int, w: int):
     attrs = node['data']
     strides = common_def.string_to_tuple(attrs['strides'])

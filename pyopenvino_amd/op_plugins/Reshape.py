@@ -7,6 +7,10 @@ from .. import common_def
 from .. import device as dev
 
 
+# A pass made of such nodes can be recorded into a hipGraph (Executable_Network.infer does so by itself for device-resident inputs):
+# nothing in compute() synchronises with the host or reads a tensor back once the constants are cached.
+GRAPH_CAPTURE_SAFE = True
+
 def name():
     print('Reshape')
 

@@ -5,6 +5,10 @@ import numpy as np
 from .. import common_def
 
 
+# A pass made of such nodes can be recorded into a hipGraph on ONE stream (Executable_Network.infer does so by itself for
+# device-resident inputs; the whole SSD IR was tried: scripts/repro_capture.py).
+GRAPH_CAPTURE_SAFE = True
+
 def name():
     print('ShapeOf')
 

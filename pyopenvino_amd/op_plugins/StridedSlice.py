@@ -7,6 +7,10 @@ from .. import common_def
 from .. import device as dev
 
 
+# A pass made of such nodes can be recorded into a hipGraph on ONE stream (Executable_Network.infer does so by itself for
+# device-resident inputs; the whole SSD IR was tried: scripts/repro_capture.py).
+GRAPH_CAPTURE_SAFE = True
+
 def name():
     print('StridedSlice')
 

@@ -402,7 +402,7 @@ def test_hipgraph_replay_of_a_forward_pass_is_bit_identical(hip, model, shape, s
     want1 = infer_one(ex, net, d1)
     want2 = infer_one(ex, net, d2)
     assert not np.array_equal(want1, want2)
-    ex.capture_graph({name: hip.DeviceTensor.from_numpy(x1)})      # the graph's own input tensor: new inputs are copied into it
+    ex.capture_graph({name: hip.DeviceTensor.from_numpy(x1)}, streams='plan' if streams > 1 else 1)      # the graph's own input tensor: new inputs are copied into it
     helpers.assert_bit_exact(ex.infer_graph()[out_name], want1, 'replay')
     helpers.assert_bit_exact(ex.infer_graph({name: d2})[out_name], want2, 'replay with new input')
     helpers.assert_bit_exact(infer_one(ex, net, d1), want1, 'eager pass after a capture')
@@ -503,3 +503,30 @@ def test_infer_replays_a_hipgraph_by_itself_for_device_resident_inputs(hip, monk
         helpers.assert_bit_exact(np.asarray(ex.infer({name: x})[out]), first, 'PVHIP_AUTO_GRAPH=0')
     assert ex.__dict__.get('_graph') is None
     assert_close(first[:2], np.load(os.path.join(GOLDEN, 'googlenet_rows8.npz'))['out'][:2], helpers.REL_TOL, 'rows vs the reference')
+
+
+def test_the_ssd_ir_and_the_fp16_googlenet_replay_too(hip, tmp_path):
+    """infer() records on ONE stream (hipStreamEndCapture crashed for the forked plans of these two networks): the whole SSD IR --
+    DetectionOutput with its workspace, the folded prior boxes -- and GoogLeNet as an FP16 IR on the f16 kernels replay with the bits
+    of their eager passes."""
+    from pyopenvino_amd import IECore, device, synth
+    xml = os.path.join(helpers.MODELS, 'ssd_mobilenet_v1_coco.xml')
+    _, net, ex = build_network(HIP, 'ssd_mobilenet_v1_coco', weights=synth.synth_weights(xml, 1234), batch=2)
+    x = device.DeviceTensor.from_numpy(synth.uniform_pixels(700, (2, 3, 300, 300)))
+    name, out = net.inputs[0]['name'], net.outputs[0]['name']
+    first = np.asarray(ex.infer({name: x})[out])
+    for _ in range(4):
+        assert np.array_equal(np.asarray(ex.infer({name: x})[out]), first)
+    assert ex.__dict__.get('_graph') is not None and ex._auto_graph['captured']
+    gx = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    xml16, blob16 = synth.fp16_ir(gx, synth.synth_weights(gx, 1234), str(tmp_path))
+    ie = IECore(plugin_package=HIP)
+    net16 = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+    net16.set_batch(4)
+    ex16 = ie.load_network(net16)
+    x16 = device.DeviceTensor.from_numpy(synth.uniform_pixels(31, (4, 3, 224, 224)))
+    n16, o16 = net16.inputs[0]['name'], net16.outputs[0]['name']
+    first16 = np.asarray(ex16.infer({n16: x16})[o16])
+    for _ in range(4):
+        helpers.assert_bit_exact(np.asarray(ex16.infer({n16: x16})[o16]), first16, 'FP16 GoogLeNet replay')
+    assert ex16._auto_graph['captured']
