@@ -149,6 +149,7 @@ def copy_ceiling(device):
         e1.synchronize()
         out[name] = round(8.0 * n / (e0.elapsed_ms(e1) / 10 * 1e-3) / 1e9, 1)
     out['tensor_MB'] = round(4.0 * n / 1e6, 1)
+    out['relu_stream_frac_hbm_peak'] = round(out['relu_stream'] / PEAK_HBM_GBS, 4)      # ReLU.py:9-12 on an 822 MB tensor against the 8 TB/s spec
     return out
 
 
@@ -351,11 +352,17 @@ def main():
         # the per-layer breakdown, one hipEvent bracket per launch, on one stream, untimed.  In a multi-rank run EVERY rank makes these
         # three passes (their Result gathers are collectives); rank 0's times go into the line (`roofline.per_kernel`, `per_op`)
         ex.device_timing = KERNEL_NODES
+        spacer = (device.DeviceTensor.empty((256 * 64 * 112 * 112,)), device.DeviceTensor.empty((256 * 64 * 112 * 112,)))
         for _ in range(3):
+            # a ~0.3 ms streaming launch in front of the pass: the bracket of the pass's FIRST launch (data/mean) would otherwise begin on
+            # an idle GPU and time the host's dispatch latency and the clock ramp with it (it read 0.10-0.25 ms for a 0.05 ms kernel)
+            device.select_stream(0)
+            device.call('pvhip_relu_f32', ctypes.c_void_p(spacer[0].ptr), ctypes.c_void_p(spacer[1].ptr), spacer[0].size)
             ex.infer({in_name: x_dev})
             for nid, typ, name, ms in ex.device_times_ms():
                 per_node.setdefault(nid, [typ, name, 0.0])[2] += ms / 3.0
         ex.device_timing = None
+        spacer = None
     ex.compute_streams = n_streams
 
     out = pipelined(args.warmup) if n_req > 1 else None

@@ -148,24 +148,47 @@ inline int lrn_beta_mode(float beta, float bias) {
 // rows are merged into whole lines by L2 when they are ordinary stores and go to memory one by one when they are not.  The switch stays
 // for A/B builds.
 constexpr bool kConvStoreNT = false;
+// kConvStoreSC1: write-through stores that do not keep their line in the XCD's L2 (`sc1`; MI355X guide, "stores of each flavour"), the
+// other way to keep a round's output from evicting inputs and weights.  Measured too: -3.5 % images/s (Winograd 1.90 -> 2.16 ms, the
+// others +2..4 %).  The output rows of these layers are 224 / 112 / 56 / 28 bytes long: a 128-byte line holds pieces of several rows
+// that different store instructions write, and only ordinary stores are merged in L2 before they leave it.  asm statements (a store
+// has no destination register: nothing for hipcc to copy early); off.
+constexpr bool kConvStoreSC1 = false;
 typedef float pv_f4v __attribute__((ext_vector_type(4)));
 typedef float pv_f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void conv_store1(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kConvStoreSC1) { asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); return; }
+#endif
     if (kConvStoreNT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 __device__ __forceinline__ void conv_store2(float* p, float a, float b) {
     pv_f2v v; v.x = a; v.y = b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kConvStoreSC1) { asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); return; }
+#endif
     if (kConvStoreNT) __builtin_nontemporal_store(v, reinterpret_cast<pv_f2v*>(p));
     else *reinterpret_cast<pv_f2v*>(p) = v;
 }
 __device__ __forceinline__ void conv_store4(float* p, float a, float b, float c, float d) {
     pv_f4v v; v.x = a; v.y = b; v.z = c; v.w = d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kConvStoreSC1) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); return; }
+#endif
     if (kConvStoreNT) __builtin_nontemporal_store(v, reinterpret_cast<pv_f4v*>(p));
     else *reinterpret_cast<pv_f4v*>(p) = v;
 }
 template <class V>
-__device__ __forceinline__ void conv_storev(V* p, V v) {       // V: a float ext_vector_type
+__device__ __forceinline__ void conv_storev(V* p, V v) {       // V: a float ext_vector_type of 1, 2 or 4
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kConvStoreSC1) {
+        if constexpr (sizeof(V) == 4) { const float f_ = v[0]; asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(f_) : "memory"); }
+        else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+        return;
+    }
+#endif
     if (kConvStoreNT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }

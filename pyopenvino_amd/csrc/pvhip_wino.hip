@@ -789,6 +789,12 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             if (ABL == 1) {                                                                                      \
                 v_[r] = __builtin_bit_cast(float, rowo[r] + soff);                                               \
                 e_[r] = 0.0f;                                                                                    \
+            } else if (ABL == 6) {          /* no edge loads: what do the six almost empty load instructions of a gather cost? */ \
+                w4_load(v_[r], xr, rowo[r], soff);                                                               \
+                e_[r] = EdgT{};                                                                                  \
+            } else if (ABL == 7) {          /* no patch loads, only the edge loads */                            \
+                v_[r] = __builtin_bit_cast(float, rowo[r] + soff);                                               \
+                w4_load(e_[r], xr, eo[r], soff);                                                                 \
             } else {                                                                                             \
                 w4_load(v_[r], xr, rowo[r], soff);                                                               \
                 w4_load(e_[r], xr, eo[r], soff);                                                                 \
@@ -1124,6 +1130,8 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
         case 3: hipLaunchKernelGGL((conv_wino4_kernel<4, 3>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         case 4: hipLaunchKernelGGL((conv_wino4_kernel<4, 4>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         case 5: hipLaunchKernelGGL((conv_wino4_kernel<4, 5>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        case 6: hipLaunchKernelGGL((conv_wino4_kernel<4, 6>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        case 7: hipLaunchKernelGGL((conv_wino4_kernel<4, 7>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         default: break;
     }
 #endif
