@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   11
+#define PVHIP_ABI_VERSION   12
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
