@@ -905,7 +905,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         const float* const vbs = &sm.V0[0][0][0] + ((row * 6) * kCB + lh) * NT + l31;      // this lane's B operand of MFMA (j = 0, kk = 0) in V0
         for (int tile = L; tile < n_tiles; tile += G) {
             const unsigned long long h0 = PVW4_NOW();
-            const unsigned u_base = (unsigned)((tile % a.n_kb) * (a.n_stages + 1)) * u_stage_bytes;
+            const unsigned u_base = (ABL == 8) ? 0u : (unsigned)((tile % a.n_kb) * (a.n_stages + 1)) * u_stage_bytes;      // ABL 8: every workgroup the weights of channel block 0 (how much do the U loads of two workgroups that share a CU, but no weights, cost?)
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -1132,6 +1132,7 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
         case 5: hipLaunchKernelGGL((conv_wino4_kernel<4, 5>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         case 6: hipLaunchKernelGGL((conv_wino4_kernel<4, 6>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         case 7: hipLaunchKernelGGL((conv_wino4_kernel<4, 7>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
+        case 8: hipLaunchKernelGGL((conv_wino4_kernel<4, 8>), grid, dim3(512), 0, state().stream, a); return PVHIP_OK;
         default: break;
     }
 #endif
