@@ -130,7 +130,9 @@ __device__ __forceinline__ float lrn_pow_f(float d, float beta, int beta_mode) {
 // an LRN element; a few ulp from the exact quotient, far inside the 1e-4 of the path).  It is chosen on the host only
 // when bias keeps d in the normal range, where those instructions are accurate.
 __device__ __forceinline__ float lrn_div(float x, float d, float beta, int beta_mode) {
-    if (beta_mode == 4) return x * (__builtin_amdgcn_rsqf(d) * __builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf(d)));
+    // d^-0.75 = 2^(-0.75 log2 d): TWO transcendental issues (v_log_f32, v_exp_f32; ~1 ulp each: 3e-7 relative for d up to 100) where
+    // rsq(d) * rsq(sqrt(d)) took three -- they are quarter-rate, and the LRN + MaxPool launch is vector-ALU-bound beside its stream
+    if (beta_mode == 4) return x * __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(d));
     return x / lrn_pow_f(d, beta, beta_mode);
 }
 
