@@ -60,6 +60,9 @@ struct Settings {
 const Settings& settings();
 void            load_settings();
 
+// MatMul.py:9-17 on the split-K fp32-MFMA kernel (pvhip_matmul.hip); round_f16: both operands rounded to fp16 first (FP16 IRs).
+int matmul_impl(const float* a, const float* b, float* c, int m, int n, int k, int trans_a, int trans_b, int round_f16);
+
 // Records a formatted message for pvhip_last_error() and returns `code`.
 int fail(int code, const char* fmt, ...);
 

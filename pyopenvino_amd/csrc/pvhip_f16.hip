@@ -16,7 +16,8 @@
 //                     conflict-free ds_read_b128; the weight tile [64][32 + 8] comes from a panel packed once in that
 //                     layout.  Register-staged double buffering: the gathers of stage t+1 are in flight under the MFMAs
 //                     of stage t.
-//   matmul_f16_kernel C[M,N] = op(A) . op(B) through element strides, 64 x 64 tiles, same LDS images.
+//   pvhip_matmul_f16  MatMul of an FP16 IR: fp16-rounded operands on the split-K fp32-MFMA kernel of pvhip_matmul.hip (exact products,
+//                     fp32 accumulation: the arithmetic of the f16 instruction; the FC layers are launch-size bound).
 #include <hip/hip_fp16.h>
 
 #include "pvhip_common.h"
@@ -195,59 +196,6 @@ __global__ __launch_bounds__(kBlock) void conv_f16_pack_kernel(const float* __re
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-struct MatMulF16Args {
-    const float* a;
-    const float* b;
-    float*       c;
-    int  M, N, K;
-    long sam, sak;   // A(m,k) = a[m*sam + k*sak]
-    long sbk, sbn;   // B(k,n) = b[k*sbk + n*sbn]
-};
-
-__global__ __launch_bounds__(kBlock) void matmul_f16_kernel(MatMulF16Args p) {
-    __shared__ __attribute__((aligned(16))) _Float16 As[64][kLd];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[64][kLd];
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const bool a_k_fast = (p.sak == 1), b_k_fast = (p.sbk == 1);       // consecutive lanes walk the contiguous global axis
-    floatx16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int k0 = 0; k0 < p.K; k0 += kBK) {
-#pragma unroll
-        for (int j = 0; j < (64 * kBK) / kBlock; ++j) {
-            const int e = tid + j * kBlock;
-            int m, k;
-            if (a_k_fast) { m = e / kBK; k = e % kBK; } else { k = e / 64; m = e % 64; }
-            const int gm = m0 + m, gk = k0 + k;
-            As[m][k] = (_Float16)((gm < p.M && gk < p.K) ? p.a[(long)gm * p.sam + (long)gk * p.sak] : 0.0f);
-            int n, k2;
-            if (b_k_fast) { n = e / kBK; k2 = e % kBK; } else { k2 = e / 64; n = e % 64; }
-            const int gn = n0 + n, gk2 = k0 + k2;
-            Bs[n][k2] = (_Float16)((gn < p.N && gk2 < p.K) ? p.b[(long)gk2 * p.sbk + (long)gn * p.sbn] : 0.0f);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const half8 af = *reinterpret_cast<const half8*>(&As[wm * 32 + l31][st * 16 + lh * 8]);
-            const half8 bf = *reinterpret_cast<const half8*>(&Bs[wn * 32 + l31][st * 16 + lh * 8]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int gn = n0 + wn * 32 + l31;
-    if (gn < p.N) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (gm < p.M) p.c[(size_t)gm * p.N + gn] = acc[r];
-        }
-    }
-}
-
 inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 }  // namespace
@@ -307,20 +255,10 @@ int pvhip_conv2d_f16(const float* x, const float* wpack, float* y, int n, int c,
 }
 
 int pvhip_matmul_f16(const float* a, const float* b, float* c, int m, int n, int k, int trans_a, int trans_b) {
-    PVHIP_REQUIRE_INIT();
-    PVHIP_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
-    if ((size_t)m * n == 0) return PVHIP_OK;
-    PVHIP_CHECK_ARG(c != nullptr && (k == 0 || (a != nullptr && b != nullptr)));
-    if (k == 0) return pvhip_memset(c, 0, (size_t)m * n * sizeof(float));
-    MatMulF16Args p;
-    p.a = a; p.b = b; p.c = c; p.M = m; p.N = n; p.K = k;
-    if (trans_a) { p.sam = 1; p.sak = m; } else { p.sam = k; p.sak = 1; }   // stored [K,M] / [M,K]
-    if (trans_b) { p.sbk = 1; p.sbn = k; } else { p.sbk = n; p.sbn = 1; }   // stored [N,K] / [K,N]
-    dim3 grid((n + 63) / 64, (m + 63) / 64, 1);
-    if (grid.y > 65535) return fail(PVHIP_EUNSUPPORTED, "pvhip_matmul_f16: M=%d too large for the tile grid", m);
-    hipLaunchKernelGGL(matmul_f16_kernel, grid, dim3(kBlock), 0, state().stream, p);
-    PVHIP_LAUNCH_CHECK();
-    return PVHIP_OK;
+    // fp16-rounded operands on the split-K kernel of pvhip_matmul.hip (see matmul_kernel<true>): the FC layers of the IRs are launch-size
+    // bound, and a product of two fp16 values is exact in fp32 -- the arithmetic of the f16 MFMA, six times faster than the tile kernel
+    // of round 2 (v_mfma_f32_32x32x16_f16, 64x64 tiles, no split) at (256, 1024) x (1000, 1024)^T: 0.027 against 0.175 ms.
+    return pvhip::matmul_impl(a, b, c, m, n, k, trans_a, trans_b, 1);
 }
 
 }  // extern "C"

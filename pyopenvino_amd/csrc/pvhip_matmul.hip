@@ -22,6 +22,11 @@ struct MatMulArgs {
     long         sbk, sbn;  // B(k,n) = b[k*sbk + n*sbn]
 };
 
+// kF16 (the MatMul of an FP16 IR, pvhip_matmul_f16): both operands are rounded to fp16 (round to nearest even, v_cvt_f16_f32) while they
+// are staged, then multiplied on the fp32 matrix cores: a product of two fp16 values is exact in fp32, so this is the arithmetic of
+// v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulation) in another summation order -- on the kernel that splits the reduction
+// over workgroups, which is what the launch-size-bound FC layers need (0.027 ms against 0.175 ms for the f16 tile kernel).
+template <bool kF16>
 __global__ __launch_bounds__(kBlock) void matmul_kernel(MatMulArgs p) {
     __shared__ float As[kTK][kTM + 1];
     __shared__ float Bs[kTK][kTN + 1];
@@ -47,15 +52,19 @@ __global__ __launch_bounds__(kBlock) void matmul_kernel(MatMulArgs p) {
             int       m, k;
             if (a_k_fast) { m = e / kTK; k = e % kTK; } else { k = e / kTM; m = e % kTM; }
             const int gm = m0 + m, gk = k0 + k;
-            As[k][m] = (gm < p.M && gk < k_end) ? p.a[(long)gm * p.sam + (long)gk * p.sak] : 0.0f;
+            float av = (gm < p.M && gk < k_end) ? p.a[(long)gm * p.sam + (long)gk * p.sak] : 0.0f;
+            if (kF16) av = (float)(_Float16)av;
+            As[k][m] = av;
         }
 #pragma unroll
         for (int j = 0; j < (kTN * kTK) / kBlock; ++j) {
             const int e = tid + j * kBlock;
             int       n, k;
             if (b_n_fast) { k = e / kTN; n = e % kTN; } else { n = e / kTK; k = e % kTK; }
-            const int gn = n0 + n, gk = k0 + k;
-            Bs[k][n] = (gn < p.N && gk < k_end) ? p.b[(long)gk * p.sbk + (long)gn * p.sbn] : 0.0f;
+            const int gn = n0 + n, gk2 = k0 + k;
+            float bv = (gn < p.N && gk2 < k_end) ? p.b[(long)gk2 * p.sbk + (long)gn * p.sbn] : 0.0f;
+            if (kF16) bv = (float)(_Float16)bv;
+            Bs[k][n] = bv;
         }
         __syncthreads();
 #pragma unroll
@@ -90,9 +99,9 @@ __global__ __launch_bounds__(kBlock) void matmul_reduce_kernel(const float* __re
 
 }  // namespace
 
-extern "C" {
+namespace pvhip {
 
-int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int k, int trans_a, int trans_b) {
+int matmul_impl(const float* a, const float* b, float* c, int m, int n, int k, int trans_a, int trans_b, int round_f16) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(m >= 0 && n >= 0 && k >= 0);
     if ((size_t)m * n == 0) return PVHIP_OK;
@@ -103,7 +112,7 @@ int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int
     if (trans_a) { p.sam = 1; p.sak = m; } else { p.sam = k; p.sak = 1; }   // stored [K,M] / [M,K]
     if (trans_b) { p.sbk = 1; p.sbn = k; } else { p.sbk = n; p.sbn = 1; }   // stored [N,K] / [K,N]
     dim3 grid((n + kTN - 1) / kTN, (m + kTM - 1) / kTM, 1);
-    if (grid.y > 65535) return fail(PVHIP_EUNSUPPORTED, "pvhip_matmul_f32: M=%d too large for the tile grid", m);
+    if (grid.y > 65535) return fail(PVHIP_EUNSUPPORTED, "pvhip_matmul: M=%d too large for the tile grid", m);
     // Split the reduction over workgroups when the output has too few tiles to fill the chip (the FC layers
     // of the IRs: 64 tiles at batch 256); partial tiles go to a workspace and are summed in split order.
     const long tiles  = (long)grid.x * grid.y;
@@ -118,7 +127,8 @@ int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int
     splits    = (k + p.k_chunk - 1) / p.k_chunk;
     if (splits <= 1) {
         p.k_chunk = (k + kTK - 1) / kTK * kTK;
-        hipLaunchKernelGGL(matmul_kernel, grid, dim3(kBlock), 0, state().stream, p);
+        if (round_f16) hipLaunchKernelGGL(matmul_kernel<true>, grid, dim3(kBlock), 0, state().stream, p);
+        else           hipLaunchKernelGGL(matmul_kernel<false>, grid, dim3(kBlock), 0, state().stream, p);
         PVHIP_LAUNCH_CHECK();
         return PVHIP_OK;
     }
@@ -127,12 +137,21 @@ int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int
     if (rc) return rc;
     p.c    = static_cast<float*>(ws);
     grid.z = splits;
-    hipLaunchKernelGGL(matmul_kernel, grid, dim3(kBlock), 0, state().stream, p);
+    if (round_f16) hipLaunchKernelGGL(matmul_kernel<true>, grid, dim3(kBlock), 0, state().stream, p);
+    else           hipLaunchKernelGGL(matmul_kernel<false>, grid, dim3(kBlock), 0, state().stream, p);
     hipLaunchKernelGGL(matmul_reduce_kernel, dim3(grid_for((size_t)m * n)), dim3(kBlock), 0, state().stream,
                        static_cast<const float*>(ws), c, (size_t)m * n, splits);
     (void)pvhip_free(ws);   // stream-ordered: the pool hands the block out again only to later work on this stream
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
+}
+
+}  // namespace pvhip
+
+extern "C" {
+
+int pvhip_matmul_f32(const float* a, const float* b, float* c, int m, int n, int k, int trans_a, int trans_b) {
+    return pvhip::matmul_impl(a, b, c, m, n, k, trans_a, trans_b, 0);
 }
 
 }  // extern "C"
