@@ -45,7 +45,24 @@ struct WinoArgs {
     int   y_ctotal, y_coff;
     int   balance;          // conv_wino4_kernel: producers placed by SIMD (see the kernel)
     int   n_tiles;          // conv_wino4_kernel: channel blocks x patch blocks, walked by a persistent grid
+    // conv_wino4_kernel: patch index -> (image, patch row, patch column) by multiply-high and shift (w4_magic): the divisors are
+    // wave-uniform, but hipcc's own division keeps their reciprocals in VECTOR registers across the main loop -- spilled there
+    unsigned tpi_mul, tpi_sh, tx_mul, tx_sh;
 };
+
+// n / d for 0 <= n < 2^31 and the (mul, sh) of w4_magic(d): exact (mul = ceil(2^(31+s) / d), s = ceil(log2 d): the error term
+// n * (mul * d - 2^(31+s)) stays below 2^(31+s)); mul = 0 stands for d = 1
+__device__ __forceinline__ int w4_div(int n, unsigned mul, unsigned sh) {
+    return mul != 0u ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
+}
+static void w4_magic(unsigned d, unsigned& mul, unsigned& sh) {
+    mul = 0u; sh = 0u;
+    if (d <= 1u) return;
+    unsigned s_ = 0;
+    while ((1u << s_) < d) ++s_;
+    mul = (unsigned)(((1ull << (31 + s_)) + d - 1) / d);
+    sh  = s_ - 1;
+}
 
 // U = G g G^T for one (k, c):  G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]
 __global__ __launch_bounds__(kBlock) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int K, int C,
@@ -611,14 +628,14 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0,
-                                                                        a.bias != nullptr ? a.K * 4 : 0, 0x00020000);
+    typedef const __attribute__((address_space(4))) float* const_float_p;      // constant address space: scalar loads
+    const const_float_p bias_c = (const_float_p)(unsigned long)a.bias;
     constexpr unsigned u_stage_bytes = (unsigned)kXi4 * kCB * KB * 4u;
     const unsigned u_lane = (unsigned)lane * 16u;
 
     // the A operands of this consumer's twelve MFMAs of a stage: group g_ = MFMAs 4 g_ .. 4 g_ + 3
-#define PVW4_LOAD_U(ua_, s_, g_)                                                                                  \
-    w4_load(ua_[g_], ur, u_lane + (unsigned)(row * 3 + (g_)) * 1024u, u_base + (unsigned)(s_) * u_stage_bytes)
+#define PVW4_LOAD_U(ua_, so_, g_)      /* so_: byte offset of the stage image (channel block and stage) in the panel */             \
+    w4_load(ua_[g_], ur, u_lane + (unsigned)(row * 3 + (g_)) * 1024u, (so_))
 
     // ---- roles.  Two workgroups share a CU, and waves w and w + 4 of a workgroup share a SIMD: with fixed roles (producers = waves
     // 6, 7) two SIMDs carry four consumers (48 MFMAs per stage of both workgroups) and two carry two consumers and two producers (24).
@@ -655,24 +672,30 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     {                                                                                                            \
         _Pragma("unroll") for (int rr = 0; rr < CH / 2; ++rr) {                                                  \
             const int r  = pass * (CH / 2) + rr;                          /* accumulator register */              \
-            const int kl = (rr & 3) + 8 * (rr >> 2) + 4 * lh;             /* channel inside the pass: 0 .. CH-1 */ \
+            const int kl = (rr & 3) + 8 * (rr >> 2) + 4 * lh_e;           /* channel inside the pass: 0 .. CH-1 */ \
             float so[4];                                                                                         \
             if (M == 4) wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1], so[2], so[3]); \
             else        wino2_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1]); \
             exv_t sv;                                                                                            \
             _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) sv[c2] = so[c2];                                    \
-            *reinterpret_cast<exv_t*>(Ex + ((row * CH + kl) * 32 + l31) * M) = sv;                               \
+            *reinterpret_cast<exv_t*>(Ex + ((row * CH + kl) * 32 + tl) * M) = sv;                                \
         }                                                                                                        \
     }
 #define PVW4_EPI_NOWRITE(pass) {}
 #define PVW4_EPILOGUE(WRITE_, tile_)                                                                             \
     {                                                                                                            \
         const int kb_e = (tile_) % a.n_kb, tb_e = (tile_) / a.n_kb;                                              \
-        const int tl = tid & 31;                                                  /* 512 threads = 16 channels x 32 patches per sweep */ \
+        /* The lane id is made HERE, by an asm hipcc can neither hoist nor merge: every per-thread value of the epilogue is then   */ \
+        /* computed per tile.  Derived from threadIdx they are loop invariants, hipcc keeps them across the main loop, has no      */ \
+        /* registers for them there (128), spills them -- and a reload from scratch is a VECTOR MEMORY load: its wait is            */ \
+        /* vmcnt(0), i.e. for every store of the previous pass to be acknowledged and every gather in flight to land.              */ \
+        int lane_e;                                                                                              \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));            \
+        const int tl = lane_e & 31, lh_e = lane_e >> 5;                            /* 512 threads = 16 channels x 32 patches per sweep */ \
         const int t  = tb_e * NT + tl;                                                                           \
         const int tc = t < a.T ? t : 0;                                                                          \
-        const int n_ = tc / TPI, rem_ = tc - n_ * TPI;                                                           \
-        const int ty_ = rem_ / a.TX, tx_ = rem_ - ty_ * a.TX;                                                    \
+        const int n_ = w4_div(tc, a.tpi_mul, a.tpi_sh), rem_ = tc - n_ * TPI;                                    \
+        const int ty_ = w4_div(rem_, a.tx_mul, a.tx_sh), tx_ = rem_ - ty_ * a.TX;                                \
         float* __restrict__ const yp0 = a.y + (((size_t)n_ * a.y_ctotal + a.y_coff) * OH + M * ty_) * OW + M * tx_; \
         const int  rows_ok = min(M, OH - M * ty_), cols_ok = min(M, OW - M * tx_);                               \
         const bool even_w = (OW & 1) == 0;                                                                       \
@@ -682,10 +705,18 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
             WRITE_(pass);                                                                                        \
             __syncthreads();                                                                                     \
             _Pragma("unroll") for (int sweep = 0; sweep < CH / 16; ++sweep) {                                    \
-                const int kl = (tid >> 5) + 16 * sweep;                                                          \
+                const int kl = 2 * wid + lh_e + 16 * sweep;                      /* = (tid >> 5) + 16 * sweep */   \
                 const int kg = kb_e * KB + pass * CH + kl;                                                       \
+                /* the bias by SCALAR loads (the wave's two channels are wave-uniform): a vector load here made every pass wait */ \
+                /* for vmcnt(0) -- behind the previous pass's stores and the producers' gathers in flight (stores count in vmcnt) */ \
+                float bs0 = 0.0f, bs1 = 0.0f;                                                                    \
+                if (a.bias != nullptr) {                                                                         \
+                    const int kgs = kb_e * KB + pass * CH + 2 * wid + 16 * sweep;                                \
+                    bs0 = bias_c[min(kgs, a.K - 1)];                                                             \
+                    bs1 = bias_c[min(kgs + 1, a.K - 1)];                                                         \
+                }                                                                                                \
                 if (t < a.T && kg < a.K) {                                                                       \
-                    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)kg * 4u, 0, 0)); \
+                    const float bv = lh_e ? bs1 : bs0;                                                           \
                     float* __restrict__ yp = yp0 + (size_t)kg * (OH * OW);                                       \
                     exv_t ev[6];                                                                                 \
                     _Pragma("unroll") for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(Ex + ((i * CH + kl) * 32 + tl) * M); \
@@ -748,8 +779,9 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     {                                                                                                            \
         const int  t    = ((tile_) / a.n_kb) * NT + l31;                                                         \
         const bool live = (tile_) < n_tiles && t < a.T;                                                          \
-        const int  n = live ? t / TPI : 0, rem = live ? t - n * TPI : 0;                                         \
-        const int  ty = rem / a.TX, tx = rem - ty * a.TX;                                                        \
+        const int  tq = live ? t : 0;                                                                            \
+        const int  n = w4_div(tq, a.tpi_mul, a.tpi_sh), rem = tq - n * TPI;                                      \
+        const int  ty = w4_div(rem, a.tx_mul, a.tx_sh), tx = rem - ty * a.TX;                                    \
         const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + M * tx) * 4u;                              \
         zl_ = tx == 0;                                                                                           \
         zh_ = tx == a.TX - 1;                                                                                    \
@@ -903,23 +935,30 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         floatx16 acc[6];
         static_assert(offsetof(Stage, V1) == offsetof(Stage, V0) + sizeof(float) * kXi4 * kCB * NT, "V1 follows V0");
         const float* const vbs = &sm.V0[0][0][0] + ((row * 6) * kCB + lh) * NT + l31;      // this lane's B operand of MFMA (j = 0, kk = 0) in V0
+        // ABL 8: every workgroup the weights of channel block 0 (how much do the U loads of two workgroups that share a CU, but no weights, cost?)
+#define PVW4_U_BASE(tile_) ((ABL == 8) ? 0u : (unsigned)(((tile_) % a.n_kb) * (a.n_stages + 1)) * u_stage_bytes)
+        w4_float4v ua[3];
+        {
+            const unsigned u_first = PVW4_U_BASE(L);
+            PVW4_LOAD_U(ua, u_first, 0);
+            PVW4_LOAD_U(ua, u_first, 1);
+            PVW4_LOAD_U(ua, u_first, 2);
+        }
         for (int tile = L; tile < n_tiles; tile += G) {
             const unsigned long long h0 = PVW4_NOW();
-            const unsigned u_base = (ABL == 8) ? 0u : (unsigned)((tile % a.n_kb) * (a.n_stages + 1)) * u_stage_bytes;      // ABL 8: every workgroup the weights of channel block 0 (how much do the U loads of two workgroups that share a CU, but no weights, cost?)
+            // The last stage of a tile loads stage 0 of the NEXT tile's weights: they arrive during the epilogue.  Loaded after it, the
+            // first wait for them would also be a wait for the epilogue's stores (stores count in vmcnt and the counter retires in order).
+            const unsigned u_base = PVW4_U_BASE(tile), u_next = PVW4_U_BASE(tile + G);
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-            w4_float4v ua[3];
-            PVW4_LOAD_U(ua, 0, 0);
-            PVW4_LOAD_U(ua, 0, 1);
-            PVW4_LOAD_U(ua, 0, 2);
             __syncthreads();
             t_head += PVW4_NOW() - h0;
             for (int s = 0; s < n_eff; ++s) {
                 const unsigned long long t0 = PVW4_NOW();
                 const float* vb = vbs + (s & 1) * (kXi4 * kCB * NT);         // V1 follows V0: every read below is this address + a constant
-                const int    sn = s + 1 < n_eff ? s + 1 : s;          // the last stage reloads its own image (unused)
+                const unsigned so_n = s + 1 < n_eff ? u_base + (unsigned)(s + 1) * u_stage_bytes : u_next;
                 // B operands one group (four MFMAs) ahead, A operands of a group reloaded for the next stage as soon as its MFMAs are
                 // issued: the sched_barriers keep hipcc from sinking the loads to the end of the stage (it did)
                 float bfr[2][4];
@@ -942,7 +981,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                         else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[j], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ABL != 4) PVW4_LOAD_U(ua, sn, g);
+                    if (ABL != 4) PVW4_LOAD_U(ua, so_n, g);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef PVW4_READ_B
@@ -958,6 +997,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         }
     }
 #undef PVW4_LOAD_U
+#undef PVW4_U_BASE
 #undef PVW4_EPILOGUE
 #undef PVW4_EPI_WRITE
 #undef PVW4_EPI_NOWRITE
@@ -1024,6 +1064,7 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
     a.balance = 0; a.n_tiles = 0;
+    a.tpi_mul = a.tpi_sh = a.tx_mul = a.tx_sh = 0u;
 #ifdef PVHIP_DIAG
     if (settings().wino4_ablate == 5) a.balance = 5;          // diagnostic build: s_memtime stamps (scripts/stamps_wino.py)
 #endif
@@ -1110,6 +1151,8 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     const long n_tb = ((long)a.T + 31) / 32;
     if (n_tb * a.n_kb > 0x3fffffffL) return fail(PVHIP_EUNSUPPORTED, "wino4_conv: too many tiles");
     a.n_tiles = (int)(n_tb * a.n_kb);
+    w4_magic((unsigned)(a.TY * a.TX), a.tpi_mul, a.tpi_sh);
+    w4_magic((unsigned)a.TX, a.tx_mul, a.tx_sh);
     // persistent: two workgroups per CU (72 KB of LDS each), each walking tiles L, L + G, ...
     const dim3 grid((unsigned)(a.n_tiles < 2 * kNumCU ? a.n_tiles : 2 * kNumCU));
     if (m == 2) {
