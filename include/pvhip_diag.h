@@ -32,6 +32,8 @@ int pvhip_diag_pw_stamps(unsigned long long* out);
  * ticket counter is reset), and its s_memtime stamps (64 counters; cleared).                                                        */
 int pvhip_diag_wino4_hw(unsigned* out);
 int pvhip_diag_wino4_stamps(unsigned long long* out);
+/* the same run's epilogue phases: [wave 0..7][write 0, barrier, read + store 0, barrier, write 1, barrier, read + store 1, barrier]  */
+int pvhip_diag_wino4_epilogue(unsigned long long* out);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,7 @@ __device__ __forceinline__ void wino_dma_b128(__amdgpu_buffer_rsrc_t r, float* d
 // consumers: 0 MFMA segment (LDS reads + MFMA issue), 1 wait for the U DMA, 2 barrier;  producers: 0 gather issue, 1 wait for the older
 // gather, 2 transform + LDS writes, 3 barrier.
 __device__ unsigned long long g_w4_stamps[8][8];
+__device__ unsigned long long g_w4_epi[8][8];      // ABL = 5: the epilogue's phases (write 0, barrier, read + store 0, barrier, write 1, barrier, read + store 1, barrier)
 __device__ unsigned g_w4_hw[64][8][2];          // ABL = 5: HW_REG_LDS_ALLOC / HW_REG_HW_ID of the waves of the first 64 workgroups
 __device__ unsigned g_w4_hw_ticket;
 #define PVW4_NOW() ((ABL == 5) ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
@@ -701,9 +702,16 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         const bool even_w = (OW & 1) == 0;                                                                       \
         (void)rows_ok; (void)cols_ok; (void)even_w;                                                              \
         _Pragma("unroll") for (int pass = 0; pass < PASSES; ++pass) {                                            \
+            const unsigned long long p0_ = PVW4_NOW();                                                           \
             if (pass == 1) __syncthreads();                                                                      \
+            const unsigned long long p1_ = PVW4_NOW();                                                           \
             WRITE_(pass);                                                                                        \
+            const unsigned long long p2_ = PVW4_NOW();                                                           \
             __syncthreads();                                                                                     \
+            const unsigned long long p3_ = PVW4_NOW();                                                           \
+            if (pass == 1) ep[3] += p1_ - p0_;                                                                   \
+            ep[pass * 4 + 0] += p2_ - p1_;                                                                       \
+            ep[pass * 4 + 1] += p3_ - p2_;                                                                       \
             _Pragma("unroll") for (int sweep = 0; sweep < CH / 16; ++sweep) {                                    \
                 const int kl = 2 * wid + lh_e + 16 * sweep;                      /* = (tid >> 5) + 16 * sweep */   \
                 const int kg = kb_e * KB + pass * CH + kl;                                                       \
@@ -750,11 +758,14 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                     }                                                                                            \
                 }                                                                                                \
             }                                                                                                    \
+            ep[pass * 4 + 2] += PVW4_NOW() - p3_;                                                                \
         }                                                                                                        \
-        __syncthreads();      /* the exchange area is read out: V1 may be written again */                                  \
+        { const unsigned long long q0_ = PVW4_NOW(); __syncthreads(); ep[7] += PVW4_NOW() - q0_; } /* the exchange area is read out: V1 may be written again */ \
     }
 
     unsigned long long st[4] = {0ull, 0ull, 0ull, 0ull};      // ABL = 5 only
+    unsigned long long ep[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    (void)ep;
     unsigned long long t_epi = 0ull, t_head = 0ull;
     (void)t_epi; (void)t_head;
     if (producer) {
@@ -1012,6 +1023,8 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         atomicAdd(&g_w4_stamps[who][6], t_head);
         atomicAdd(&g_w4_stamps[who][3], producer ? 0ull : (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_entry));   // consumers: life in 10 ns ticks               // consumers: tile heads (zero, U(0), first barrier); producers: before the first tile
         atomicAdd(&g_w4_stamps[who][7], 1ull);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_w4_epi[who][i], ep[i]);
     }
 #endif
 }
@@ -1193,6 +1206,13 @@ extern "C" int pvhip_diag_wino4_hw(unsigned* out) {          // 64 x 8 x 2 words
     if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_hw), 64 * 8 * 2 * sizeof(unsigned)) != hipSuccess) return PVHIP_EHIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_hw_ticket), &zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+extern "C" int pvhip_diag_wino4_epilogue(unsigned long long* out) {      // 8 waves x 8 phases, read and cleared
+    unsigned long long zero[64] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_epi), sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_epi), zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
     return PVHIP_OK;
 }
 extern "C" int pvhip_diag_wino4_stamps(unsigned long long* out) {

@@ -16,6 +16,7 @@ dev.init(0)
 lib = ctypes.CDLL(dev.LIB_PATH)
 lib.pvhip_diag_wino4_stamps.argtypes = [ctypes.c_void_p]
 lib.pvhip_diag_wino4_hw.argtypes = [ctypes.c_void_p]
+lib.pvhip_diag_wino4_epilogue.argtypes = [ctypes.c_void_p]
 only = sys.argv[1] if len(sys.argv) > 1 else ''
 for name, xs, k in LAYERS:
     if only not in name:
@@ -35,6 +36,7 @@ for name, xs, k in LAYERS:
         dev.synchronize()
         out = (ctypes.c_ulonglong * 64)()
         lib.pvhip_diag_wino4_stamps(out)          # clear
+        lib.pvhip_diag_wino4_epilogue(out)
         e0 = dev.Event().record()
         for _ in range(5):
             run()
@@ -42,6 +44,8 @@ for name, xs, k in LAYERS:
         ms = e0.elapsed_ms(e1) / 5
         lib.pvhip_diag_wino4_stamps(out)
         st = np.array(list(out), dtype=np.float64).reshape(8, 8)
+        lib.pvhip_diag_wino4_epilogue(out)
+        epi_ph = np.array(list(out), dtype=np.float64).reshape(8, 8)
         print('{} ablate={}: {:.3f} ms'.format(name, abl, ms), flush=True)
         if abl == '5' and os.environ.get('HW'):
             hw = (ctypes.c_uint * (64 * 8 * 2))()
@@ -69,3 +73,10 @@ for name, xs, k in LAYERS:
                 else:
                     print('  producer {}: per stage (all but the last two of a tile)  gather issue {:4.0f}  gather wait {:4.0f}  transform+store {:5.0f}  barrier {:5.0f} | before the first tile {:6.0f}  epilogues per tile {:6.0f} | life {:8.0f}'.format(
                         wv - 6, per[0] * stages / max(1, stages - 2), per[1] * stages / max(1, stages - 2), per[2] * stages / max(1, stages - 2), per[3] * stages / max(1, stages - 2), head, epi / per_wg, life))
+            print('  epilogue phases, cycles per tile: write 0 | barrier | read + store 0 | barrier | write 1 | barrier | read + store 1 | barrier')
+            for wv in range(8):
+                cnt = st[wv, 7]
+                if cnt == 0:
+                    continue
+                print('    {} {}: '.format('consumer' if wv < 6 else 'producer', wv if wv < 6 else wv - 6) +
+                      ' | '.join('{:5.0f}'.format(v) for v in epi_ph[wv] / cnt / per_wg))
