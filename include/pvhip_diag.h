@@ -25,6 +25,11 @@ int pvhip_mfma_ceiling_f32(int mode, int iters, double* tflops, double* clock_gh
  * adjacent words of the lane; nt != 0: nontemporal loads and stores; blocks x threads as given.                                  */
 int pvhip_diag_stream_f32(const float* x, float* y, unsigned long long n, int relu, int unroll, int nt, int layout, int blocks, int threads);
 
+/* scripts/issue_mix.py: MFMA streams (mfma: 0 none, 1 fp32 32x32x2, 2 bf16 32x32x16) and / or a packed-fp32 vector stream (valu != 0),
+ * in every wave (split = 0) or the MFMAs on waves 0-3 and the vector stream on waves 4-7 of each 8-wave workgroup (split = 1: one of each
+ * per SIMD); iters iterations of 8 fp32 / 16 bf16 MFMAs and 64 packed FMAs; out: blocks * 512 floats.                                 */
+int pvhip_diag_issue_mix(float* out, int mfma, int valu, int split, int iters, int blocks);
+
 /* scripts/time_pw.py --ablate 8: read and clear the cycle accounts of conv_pw_kernel<.., .., 8> (PVHIP_PW_ABLATE=8); out = 8 counters. */
 int pvhip_diag_pw_stamps(unsigned long long* out);
 

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                 const int kg = kb_e * KB + pass * CH + kl;                                                       \
                 /* the bias by SCALAR loads (the wave's two channels are wave-uniform): a vector load here made every pass wait */ \
                 /* for vmcnt(0) -- behind the previous pass's stores and the producers' gathers in flight (stores count in vmcnt) */ \
-                float bs0 = 0.0f, bs1 = 0.0f;                                                                    \
+                float bs0 = -0.0f, bs1 = -0.0f;                  /* no bias: v + -0.0 == v for every v, -0.0 included */ \
                 if (a.bias != nullptr) {                                                                         \
                     const int kgs = kb_e * KB + pass * CH + 2 * wid + 16 * sweep;                                \
                     bs0 = bias_c[min(kgs, a.K - 1)];                                                             \
@@ -735,14 +735,22 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                         else        wino2_at(ev[0][c2], ev[1][c2], ev[2][c2], ev[3][c2], ev[4][c2], ev[5][c2], col[0], col[1]); \
                         _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) yv[r2][c2] = col[r2];                   \
                     }                                                                                            \
+                    /* bias and activation on all M x M values, the bounds behind WAVE-UNIFORM branches: act_apply's two compare-and- */ \
+                    /* selects per value were 64 of the ~210 vector instructions of this block (plus 16 selects for "bias or not"),   */ \
+                    /* and every vector instruction here competes with the other workgroup's MFMAs for the SIMD's issue slots          */ \
+                    _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2)                                             \
+                        _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = yv[r2][c2] + bv;           \
+                    if (a.act != 0) {                                                                            \
+                        _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2)                                         \
+                            _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] < ab.lo) ? ab.lo : yv[r2][c2]; \
+                    }                                                                                            \
+                    if (a.act == 2) {                                                                            \
+                        _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2)                                         \
+                            _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] > ab.hi) ? ab.hi : yv[r2][c2]; \
+                    }                                                                                            \
                     _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) {                                           \
                         float ov[M];                                                                             \
-                        _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) {                                       \
-                            float v = yv[r2][c2];                                                                \
-                            if (a.bias != nullptr) v = v + bv;                                                   \
-                            v = act_apply(v, ab);                                                                \
-                            ov[c2] = v;                                                                          \
-                        }                                                                                        \
+                        _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) ov[c2] = yv[r2][c2];                    \
                         if (RAGGED) {            /* only what exists; pairs where the rows are 8-byte aligned (even width) */ \
                             if (r2 < rows_ok) {                                                                  \
                                 _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {                            \
