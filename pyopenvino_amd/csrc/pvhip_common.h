@@ -115,6 +115,25 @@ __device__ __forceinline__ float act_apply(float v, const ActBounds& b) {
     v = (v > b.hi) ? b.hi : v;
     return v;
 }
+// The same for N accumulator values of one lane, behind WAVE-UNIFORM branches (the activation and the bias pointer are launch
+// constants): per value act_apply is two compares and two selects and "bias or not" one more select -- five vector instructions
+// of which a ReLU layer with a bias needs two, and every vector instruction of a convolution kernel is matrix time lost
+// (profiles/r03_issue_mix.md).  The operations that remain are the same ones on the same values: the same bits.
+template <int N>
+__device__ __forceinline__ void bias_act_n(float (&v)[N], const float (&b)[N], bool has_bias, int act, const ActBounds& ab) {
+    if (has_bias) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = v[i] + b[i];
+    }
+    if (act != 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = (v[i] < ab.lo) ? ab.lo : v[i];
+    }
+    if (act == 2) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = (v[i] > ab.hi) ? ab.hi : v[i];
+    }
+}
 
 // (bias + alpha * sum)^beta of the LRN kernels.  beta_mode: 1 -> d^0.75 as sqrt(d)*sqrt(sqrt(d)) (two correctly
 // rounded roots), 2 -> d^0.5, 3 -> d, 0 -> powf.

@@ -498,15 +498,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_rs_kernel(ConvArgs a) {
             const int n   = gp / OHW;
             const int rem = gp - n * OHW;
             float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff + row0) * OHW + rem;
+            float vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vv[r] = acc[i][j][r];
+            bias_act_n<16>(vv, bv, a.bias != nullptr, a.relu, act_bounds(a.relu, a.act_lo, a.act_hi));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
-                if (row0 + dr < a.K) {
-                    float v = acc[i][j][r];
-                    if (a.bias != nullptr) v = v + bv[r];
-                    v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                    conv_store1(yp + (size_t)dr * OHW, v);
-                }
+                if (row0 + dr < a.K) conv_store1(yp + (size_t)dr * OHW, vv[r]);
             }
         }
     }
@@ -733,15 +732,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
             klim  = ka->seg[sg].m_begin + ka->seg[sg].k;
         }
         float* __restrict__ yp = yb + ((size_t)n * yct + ycoff + row0) * OHW + rem;
+        float vv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = acc[i][r];
+        bias_act_n<16>(vv, bv, a.bias != nullptr, a.relu, act_bounds(a.relu, a.act_lo, a.act_hi));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < klim) {
-                float v = acc[i][r];
-                if (a.bias != nullptr) v = v + bv[r];
-                v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                conv_store1(yp + (size_t)dr * OHW, v);
-            }
+            if (row0 + dr < klim) conv_store1(yp + (size_t)dr * OHW, vv[r]);
         }
     }
 }

@@ -235,15 +235,14 @@ __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
             if (gp >= a.P) continue;
             const int n = gp / HW, rem = gp - n * HW;
             float* __restrict__ yp = a.y + ((size_t)n * a.y_ctotal + a.y_coff + row0) * HW + rem;
+            float vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vv[r] = acc[i][r];
+            bias_act_n<16>(vv, bv, a.bias != nullptr, a.relu, act_bounds(a.relu, a.act_lo, a.act_hi));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
-                if (row0 + dr < a.K) {
-                    float v = acc[i][r];
-                    if (a.bias != nullptr) v = v + bv[r];
-                    v = act_apply(v, act_bounds(a.relu, a.act_lo, a.act_hi));
-                    conv_store1(yp + (size_t)dr * HW, v);
-                }
+                if (row0 + dr < a.K) conv_store1(yp + (size_t)dr * HW, vv[r]);
             }
         }
     }

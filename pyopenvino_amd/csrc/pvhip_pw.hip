@@ -83,9 +83,17 @@ __device__ __forceinline__ void pw_mfma_stage(const float* bs, const float4v (&f
 
 // Bias / activation / store of a wave's TN accumulators: register r of accumulator j is channel row0 + (r&3) + 8*(r>>2) of
 // pixel gp0 + j; with whole 4-pixel groups (kVec) the TN pixels of a lane are one TN*4-byte store.
-template <int TN, bool kVec>
-__device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[4], const float (&bv)[16], float* __restrict__ yb, int yct,
-                                         int ycoff, int klim, int row0, int gp0) {
+// ACT: 0 none, 1 a lower bound (ReLU), 2 both bounds (Clamp) -- act_apply without the compare-and-select pairs that do nothing for the
+// launch's activation (pw_store picks the instantiation behind a wave-uniform branch: two of the five vector instructions per value).
+template <int ACT>
+__device__ __forceinline__ float pw_act(float v, const ActBounds& b) {
+    if (ACT >= 1) v = (v < b.lo) ? b.lo : v;
+    if (ACT == 2) v = (v > b.hi) ? b.hi : v;
+    return v;
+}
+template <int TN, bool kVec, int ACT>
+__device__ __forceinline__ void pw_store_act(const PwArgs& a, const floatx16 (&acc)[4], const float (&bv)[16], float* __restrict__ yb, int yct,
+                                             int ycoff, int klim, int row0, int gp0) {
     typedef float bvec_t __attribute__((ext_vector_type(TN)));
     const ActBounds ab = act_bounds(a.act, a.lo, a.hi);          // bv[] holds -0.0 where there is no bias
     if (kVec) {
@@ -98,7 +106,7 @@ __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[
             if (row0 + dr < klim) {
                 bvec_t v;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) v[j] = act_apply(acc[j][r] + bv[r], ab);
+                for (int j = 0; j < TN; ++j) v[j] = pw_act<ACT>(acc[j][r] + bv[r], ab);
                 conv_storev(reinterpret_cast<bvec_t*>(yp + (size_t)dr * a.HW), v);
             }
         }
@@ -113,11 +121,18 @@ __device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
                 if (row0 + dr < klim) {
-                    conv_store1(yp + (size_t)dr * a.HW, act_apply(acc[j][r] + bv[r], ab));
+                    conv_store1(yp + (size_t)dr * a.HW, pw_act<ACT>(acc[j][r] + bv[r], ab));
                 }
             }
         }
     }
+}
+template <int TN, bool kVec>
+__device__ __forceinline__ void pw_store(const PwArgs& a, const floatx16 (&acc)[4], const float (&bv)[16], float* __restrict__ yb, int yct,
+                                         int ycoff, int klim, int row0, int gp0) {
+    if (a.act == 0) pw_store_act<TN, kVec, 0>(a, acc, bv, yb, yct, ycoff, klim, row0, gp0);
+    else if (a.act == 1) pw_store_act<TN, kVec, 1>(a, acc, bv, yb, yct, ycoff, klim, row0, gp0);
+    else pw_store_act<TN, kVec, 2>(a, acc, bv, yb, yct, ycoff, klim, row0, gp0);
 }
 
 // One workgroup = 4 waves, one per SIMD (with one wave per channel tile and 5-7 waves per workgroup, two waves of a workgroup
