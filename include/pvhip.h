@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   12
+#define PVHIP_ABI_VERSION   13
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -153,6 +153,13 @@ int pvhip_maxpool_lrn_f32(const float* x, float* y, int n, int c, int h, int w, 
  * dst[outer][sum(inner)] at its running offset.  srcs / inner are HOST arrays of n_src entries.  */
 #define PVHIP_MAX_CONCAT 16
 int pvhip_concat_f32(int n_src, const float* const* srcs, const int64_t* inner, float* dst, int64_t outer);
+/* The zero-padded image Convolution.py:64-66 builds before it slides its window, as a tensor: y (n, c, h + pad_top + pad_bottom,
+ * w + pad_left + pad_right) = x (n, c, h, w) with zeros around; channel_add (c floats, may be NULL) is added to every element of x on
+ * the way (Add.py:9-14 of a per-channel constant feeding the convolution: one pass instead of two).  The Convolution plugin pads the
+ * input of a layer whose channel count is not a multiple of 16 (GoogLeNet conv1) and convolves the result without padding: the
+ * kernel's gather then needs no window test (pvhip_conv2d_f32 picks that form whenever no window leaves the tensor).             */
+int pvhip_pad2d_f32(const float* x, float* y, int n, int c, int h, int w, int pad_top, int pad_left, int pad_bottom, int pad_right,
+                    const float* channel_add);
 /* Transpose.py:9-13 kernel_Transpose_numpy, materialised: y = x.transpose(perm), y contiguous.   */
 int pvhip_transpose_f32(const float* x, float* y, int rank, const int64_t* in_shape, const int64_t* perm);
 

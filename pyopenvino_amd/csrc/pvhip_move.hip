@@ -29,6 +29,25 @@ __global__ __launch_bounds__(kBlock) void concat_kernel(ConcatArgs a, T* __restr
     }
 }
 
+// Zero padding as a pass of its own (Convolution.py:64-66 builds the padded image the same way): y[plane][pt + iy][pl + ix] =
+// x[plane][iy][ix] (+ add[plane % c]), zeros around.  grid.y = plane; a thread walks the plane's OUTPUT elements, so the stores are
+// dense; two divisions by launch constants per element (multiply-high).
+__global__ __launch_bounds__(kBlock) void pad2d_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ add,
+                                                       int c, int h, int w, int pt, int pl, unsigned hp, unsigned wp, FastDiv d_wp) {
+    const unsigned plane = blockIdx.y;
+    const float* __restrict__ xp = x + (size_t)plane * h * w;
+    float* __restrict__       yp = y + (size_t)plane * hp * wp;
+    const float b = add != nullptr ? add[plane % (unsigned)c] : -0.0f;          // v + -0.0 == v for every v
+    const unsigned total = hp * wp, stride = gridDim.x * blockDim.x;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const unsigned oy = fdiv(e, d_wp), ox = e - oy * wp;
+        const int      iy = (int)oy - pt, ix = (int)ox - pl;
+        float v = 0.0f;
+        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) v = xp[(size_t)iy * w + ix] + b;
+        __builtin_nontemporal_store(v, yp + e);
+    }
+}
+
 struct PermArgs {
     int      rank;
     unsigned out_shape[PVHIP_MAX_RANK];
@@ -92,6 +111,23 @@ int pvhip_concat_f32(int n_src, const float* const* srcs, const int64_t* inner, 
                            reinterpret_cast<float4*>(dst));
     else
         hipLaunchKernelGGL(concat_kernel<float>, dim3(gx, n_src), dim3(kBlock), 0, state().stream, a, dst);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_pad2d_f32(const float* x, float* y, int n, int c, int h, int w, int pad_top, int pad_left, int pad_bottom, int pad_right,
+                    const float* channel_add) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 && pad_right >= 0);
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+    const unsigned long long hp = (unsigned long long)h + pad_top + pad_bottom, wp = (unsigned long long)w + pad_left + pad_right;
+    if (hp * wp >= (1ull << 31) || (unsigned long long)n * c > 65535ull)
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_pad2d_f32: plane of %llu x %llu elements or %llu planes: too large", hp, wp,
+                    (unsigned long long)n * c);
+    const int gx = (int)((hp * wp + (unsigned long long)kBlock * 4 - 1) / ((unsigned long long)kBlock * 4));      // four elements per thread
+    hipLaunchKernelGGL(pad2d_kernel, dim3(gx > 0 ? gx : 1, n * c), dim3(kBlock), 0, state().stream, x, y, channel_add, c, h, w, pad_top,
+                       pad_left, (unsigned)hp, (unsigned)wp, make_fastdiv((unsigned)wp));
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -73,6 +73,7 @@ SIGNATURES = {
     'pvhip_maxpool_lrn_supported': (_c.c_int, [_c.c_int] * 15 + [_c.c_float, _c.c_float]),
     'pvhip_maxpool_lrn_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 15 + [_c.c_float] * 3),
     'pvhip_concat_f32': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _i64p, _fp, _c.c_int64]),
+    'pvhip_pad2d_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 8 + [_fp]),
     'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
     'pvhip_matmul_f32': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_conv2d_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
@@ -170,11 +171,15 @@ def init(device: int = None) -> int:
 settings_serial = 0      # bumped by every reload: host-side plans that bake kernel choices in (a captured hipGraph) key on it
 
 
+conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'      # Convolution plugin: pad the input of a c-major layer in a pass of its own
+
+
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
-    global settings_serial
+    global settings_serial, conv_prepad
     call('pvhip_settings_reload')
+    conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     settings_serial += 1
 
 

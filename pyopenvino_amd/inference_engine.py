@@ -353,6 +353,7 @@ class Executable_Network:
         self._lrn_pool = {}             # LRN node id -> id of the MaxPool folded into it, or MaxPool id -> id of the LRN folded into it
         self._siblings = {}             # Convolution node id -> ids of the convolutions of the same input launched with it
         self._pool_conv = {}            # Convolution node id -> (MaxPool node folded into its input tile, id of the MaxPool's data input)
+        self._pre_add = {}              # Convolution node id -> (Add node folded into its padding pass, Const id, id of the Add's data input)
         self.fuse_siblings = os.environ.get('PVHIP_FUSE_SIBLINGS', '1') != '0'
         self._infer_serial = 0
         self._timed = []                # [(node id, type, name, start Event, stop Event)] of the last run_tasks
@@ -452,6 +453,7 @@ class Executable_Network:
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
         self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pool_conv = {}, set(), {}, {}, {}
+        self._pre_add = {}
         if not self.fuse_epilogues:
             return
         G = self.ienet.G
@@ -558,6 +560,23 @@ class Executable_Network:
                 if psrc is not None and conv_plugin.pooled_fusable(G.nodes[cid], G.nodes[src]):
                     self._pool_conv[cid] = (src, psrc)
                     self._fused_away.add(src)
+        # An Add of a per-INPUT-channel Const whose only consumer is a convolution that pads its input in a pass of its own (GoogLeNet:
+        # data/mean -> conv1): the padding pass adds the constant on the way and the Add is not dispatched (same fp32 add: same bits).
+        if not f16 and getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False):
+            for cid in G.nodes:
+                if G.nodes[cid]['type'] != 'Convolution' or cid in self._pool_conv:
+                    continue
+                src = next((p_ for p_ in G.pred[cid] if G.edges[(p_, cid)]['connection'][3] == 0), None)
+                if src is None or G.nodes[src]['type'] != 'Add' or src in self._fused_away or len(list(G.successors(src))) != 1:
+                    continue
+                preds = list(G.pred[src])
+                consts = [p_ for p_ in preds if G.nodes[p_]['type'] == 'Const']
+                others = [p_ for p_ in preds if G.nodes[p_]['type'] != 'Const']
+                if len(preds) != 2 or len(consts) != 1 or len(others) != 1:
+                    continue
+                if conv_plugin.pre_add_fusable(G.nodes[cid], G.nodes[src], G.nodes[consts[0]]):
+                    self._pre_add[cid] = (src, consts[0], others[0])
+                    self._fused_away.add(src)
         # Third peephole: fused convolution chains that read the SAME tensor with the same geometry and activation (the
         # 1x1, 3x3_reduce and 5x5_reduce arms of an inception module) are one launch of the first of them in schedule
         # order: the input is read once and every output-channel tile stores into the tensor of its own convolution
@@ -622,6 +641,7 @@ class Executable_Network:
                         owner[nid] = lead
 
         folded_adds = {pool_id: src_id for pool_id, src_id in self._pool_conv.values()}      # MaxPools folded into their consumer's fetch
+        folded_adds.update({add_id: src_id for add_id, _, src_id in self._pre_add.values()})  # Adds folded into a padding pass
 
         def producers(nid):
             if nid in folded_adds:           # an Add folded into its consumer's fetch: whoever wrote the Add's input
@@ -799,6 +819,15 @@ class Executable_Network:
                 node['_fuse_pool_in'] = G.nodes[pool_id]
             else:
                 node.pop('_fuse_pool_in', None)
+            pre_add = self._pre_add.get(task)
+            if pre_add is not None:          # the folded Add hands its data input on; its constant rides in the padding pass
+                add_id, const_id, src_id = pre_add
+                edge = G.edges[(src_id, add_id)]['connection']
+                out = G.nodes[add_id]['output']
+                out[next(iter(out))]['data'] = G.nodes[edge[0]]['output'][edge[1]]['data']
+                node['_pre_add'] = G.nodes[const_id]['output'][0]['data']
+            else:
+                node.pop('_pre_add', None)
             inputs = self.prepare_inputs_for_task(task) if 'input' in node else {}
             if node_type in ('Convolution', 'MatMul'):
                 node['_f16_mfma'] = bool(getattr(self.ienet, 'f16_mfma', False))
@@ -1089,8 +1118,8 @@ class Executable_Network:
                 chain = [cid, f['add']] + ([f['relu']] if f['relu'] is not None else [])
                 if all(c in needed for c in chain):
                     keep[cid] = dict(f, into=None)      # Concat elimination is not applied to sub-graphs
-            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pool_conv)
-            self._siblings, self._pool_conv = {}, {}      # sub-graph runs launch every convolution (MaxPool) on its own
+            saved = (self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pool_conv, self._pre_add)
+            self._siblings, self._pool_conv, self._pre_add = {}, {}, {}      # sub-graph runs launch every convolution (MaxPool, Add) on its own
             self._fusion = {c: f for c, f in keep.items()}
             self._fused_away = {n for f in self._fusion.values() for n in (f['add'], f['relu']) if n is not None}
             self._concat_direct = {}
@@ -1099,7 +1128,7 @@ class Executable_Network:
             try:
                 self.run_tasks(False)
             finally:
-                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pool_conv = saved
+                self._fusion, self._fused_away, self._concat_direct, self._lrn_pool, self._siblings, self._pool_conv, self._pre_add = saved
         finally:
             self.task_list = full
         out = {}

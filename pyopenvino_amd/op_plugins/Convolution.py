@@ -24,6 +24,10 @@ SUPPORTS_SIBLINGS = True
 # be handed over with the convolution: node['_fuse_pool_in'] = the MaxPool's node dict, inputs[0] = the MaxPool's own input.  The
 # kernel pools while it builds its input tile; the pooled tensor is never written.
 SUPPORTS_POOLED_INPUT = True
+# An Add of one fp32 constant per INPUT channel whose only consumer is a convolution that pads its input in a pass of its own (a layer
+# with C % 16 != 0 and padding: GoogLeNet's data/mean -> conv1) may be handed over with the convolution: node['_pre_add'] = the constant
+# (1, C, 1, 1), inputs[0] = the Add's own data input.  The padding pass adds it on the way (the same fp32 add: the same bits).
+SUPPORTS_PRE_ADD = True
 
 
 # A pass made of such nodes can be recorded into a hipGraph (Executable_Network.infer does so by itself for device-resident inputs):
@@ -67,6 +71,33 @@ def packed_weights_f16(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
     return wpack
 
 
+def prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16=False) -> bool:
+    """True for a padded layer that libpvhip runs on the c-major form of the LDS-DMA kernel (C % 16 != 0, not a Winograd or pointwise
+    layer): its gather tests every tap against the window unless no window leaves the tensor (PVHIP_CONV_PREPAD=0: never)."""
+    if f16 or not dev.conv_prepad or c % 16 == 0 or not (any(pads_begin) or any(pads_end)) or oh <= 0 or ow <= 0 or kh * kw >= 64:
+        return False
+    return int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) == 0
+
+
+def pre_add_fusable(node: dict, add_node: dict, const_node: dict) -> bool:
+    """True when this layer pads its input in a pass of its own (prepad_wanted) and the Add in front of it adds one fp32 constant per
+    input channel: the padding pass then does the Add (IR attributes and port dims; no device needed)."""
+    try:
+        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+        strides, pb, pe = (common_def.string_to_tuple(attrs[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+        if len(xd) != 4 or attrs['auto_pad'] != 'explicit':
+            return False
+        if tuple(const_node['data']['shape']) != (1, int(xd[1]), 1, 1) or const_node['data']['element_type'] != 'f32':
+            return False
+        add_out = add_node['output'][common_def.first_output_port(add_node)]['dims']
+        if tuple(add_out) != tuple(xd) or not all(tuple(p_['dims']) in (tuple(xd), (1, int(xd[1]), 1, 1)) for p_ in add_node['input'].values()):
+            return False
+        oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
+        return prepad_wanted(int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3]), oh, ow, strides, pb, pe)
+    except (KeyError, ValueError, AssertionError, IndexError, TypeError):
+        return False
+
+
 def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, f16=False):
     n, c, h, wd = x.shape
     kn, kc, kh, kw = w.shape
@@ -78,6 +109,18 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         # the strided slice of the padded image is shorter than (oh, ow): numpy refuses the assignment (:68)
         raise ValueError('could not broadcast input array: window exceeds the padded input '
                          '({}x{} padded, kernel {}x{}, stride {}, output {}x{})'.format(hp, wp, kh, kw, strides, oh, ow))
+    pre_add = node.get('_pre_add')            # plan_fusion: the per-channel Add in front of this layer rides in the padding pass
+    if pre_add is not None:
+        pre_add = dev.as_device(pre_add)
+        assert pre_add.size == c
+    if prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16) or pre_add is not None:
+        # The zero-padded image (Convolution.py:64-66) as a tensor of its own, convolved WITHOUT padding: the gather of a layer whose
+        # channel count is not a multiple of 16 (conv1: C = 3) then needs no window test -- zero vector instructions per gathered row
+        # instead of five, and vector instructions are matrix time lost.  The pass costs less than the tests did.
+        xp = dev.DeviceTensor.empty((n, c, hp, wp))
+        dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
+                 pads_end[0], pads_end[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
+        x, h, wd, pads_begin, pads_end = xp, hp, wp, (0, 0), (0, 0)
     wpack = packed_weights_f16(node, w, h, wd) if f16 else packed_weights(node, w, h, wd)
     act_code, act_lo, act_hi = 0, 0.0, 0.0
     if act is not None:

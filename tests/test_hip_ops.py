@@ -337,6 +337,58 @@ def test_conv_seeded_random_shapes(hip):
     assert families == {'wino', 'pw', 'rs', 'c'}, families
 
 
+def test_pad2d_matches_numpy_bit_exact(hip):
+    """pvhip_pad2d_f32 (the zero-padded image of Convolution.py:64-66 as a tensor, optionally with the per-channel Add in front of the
+    layer folded in) against np.pad of x (+ c): asymmetric pads, ragged widths, one plane, no padding at all."""
+    import ctypes
+    cases = [((2, 3, 9, 11), (3, 3, 3, 3)), ((1, 1, 1, 1), (0, 2, 1, 0)), ((3, 5, 7, 4), (0, 0, 0, 0)), ((2, 3, 224, 224), (3, 3, 3, 3)),
+             ((1, 4, 6, 5), (1, 0, 0, 2))]
+    for xs, (pt, pl, pb, pr) in cases:
+        x = rnd(sum(xs), xs, 30.0)
+        add = rnd(7, (1, xs[1], 1, 1), 100.0)
+        xd = hip.DeviceTensor.from_numpy(x)
+        for with_add in (False, True):
+            y = hip.DeviceTensor.empty((xs[0], xs[1], xs[2] + pt + pb, xs[3] + pl + pr))
+            ad = hip.DeviceTensor.from_numpy(add) if with_add else None
+            hip.call('pvhip_pad2d_f32', ctypes.c_void_p(xd.ptr), ctypes.c_void_p(y.ptr), xs[0], xs[1], xs[2], xs[3], pt, pl, pb, pr,
+                     ctypes.c_void_p(ad.ptr if ad is not None else 0))
+            want = np.pad((x + add) if with_add else x, ((0, 0), (0, 0), (pt, pb), (pl, pr)))
+            assert_bit_exact(np.asarray(y), want.astype(np.float32), 'pad2d {} pads {} add={}'.format(xs, (pt, pl, pb, pr), with_add))
+
+
+def test_conv_prepadded_input_is_bit_identical(hip, monkeypatch):
+    """A padded layer on the c-major kernel (C % 16 != 0) runs as a padding pass + the test-free gather; PVHIP_CONV_PREPAD=0 keeps the
+    window test in the gather.  Same taps, same order: the same bits -- also with the per-channel Add in front folded into the pass
+    (node['_pre_add']), against Add then Convolution as two launches."""
+    cases = [((2, 3, 33, 29), (20, 3, 7, 7), (2, 2), (3, 3), (3, 3)), ((3, 5, 9, 9), (70, 5, 3, 3), (1, 1), (1, 1), (1, 1)),
+             ((2, 3, 30, 30), (32, 3, 3, 3), (2, 2), (0, 0), (1, 1)), ((1, 1, 12, 12), (8, 1, 5, 5), (1, 1), (2, 2), (2, 2)),
+             ((70, 3, 30, 30), (16, 3, 7, 7), (2, 2), (3, 3), (3, 3))]
+    from pyopenvino_amd.op_plugins import Convolution
+    for xs, ws, st, pb, pe in cases:
+        x, w = rnd(sum(xs), xs, 20.0), rnd(sum(ws), ws, (2.0 / (ws[1] * ws[2] * ws[3])) ** 0.5)
+        c_add = rnd(11, (1, xs[1], 1, 1), 50.0)
+        bias = hip.DeviceTensor.from_numpy(rnd(5, (1, ws[0], 1, 1)))
+        outs = {}
+        for mode in ('0', '1'):
+            helpers.setenv(monkeypatch, 'PVHIP_CONV_PREPAD', mode)
+            hip.reload_settings()
+            node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+            node['_fuse_bias'], node['_fuse_act'] = bias, ('relu',)
+            outs[mode] = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w})))
+            if mode == '1':
+                oh, ow = outs[mode].shape[2:]
+                assert Convolution.prepad_wanted(xs[0], xs[1], xs[2], xs[3], ws[0], ws[2], ws[3], oh, ow, st, pb, pe), (xs, ws)
+                summed = first_out(hip_plugin('Add').compute(make_node('Add', [x, c_add]), {0: x, 1: c_add}))
+                two = np.asarray(first_out(hip_plugin('Convolution').compute(dict(node), {0: summed, 1: w})))
+                folded = dict(node)
+                folded['_pre_add'] = hip.DeviceTensor.from_numpy(c_add)
+                one = np.asarray(first_out(hip_plugin('Convolution').compute(folded, {0: x, 1: w})))
+                assert_bit_exact(one, two, 'Add folded into the padding pass {} * {}'.format(xs, ws))
+        assert_bit_exact(outs['1'], outs['0'], 'padding pass + test-free gather vs window test {} * {}'.format(xs, ws))
+    monkeypatch.delenv('PVHIP_CONV_PREPAD', raising=False)
+    hip.reload_settings()
+
+
 @pytest.mark.parametrize('kernel', ['default'])
 def test_conv_fused_bias_and_activation_bit_exact(hip, monkeypatch, kernel):
     """Fused epilogues (bias, then ReLU or Clamp) of both convolution kernels and of the depthwise kernel equal

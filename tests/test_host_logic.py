@@ -186,6 +186,19 @@ def test_bench_work_model_matches_survey_totals():
     assert abs(relu_bytes / 1e6 - 2 * 12.905) < 0.01
 
 
+def test_plan_folds_the_mean_add_into_conv1s_padding_pass():
+    """GoogLeNet: data/mean (Add of one constant per input channel) feeds only conv1, a padded layer with C = 3: the Add is not
+    dispatched, conv1 reads the Parameter and its padding pass adds the constant.  Unfused plans and the FP16 form keep the Add."""
+    _, net, ex = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=True)
+    G = net.G
+    assert len(ex._pre_add) == 1
+    (cid, (aid, kid, sid)), = ex._pre_add.items()
+    assert G.nodes[cid]['name'].startswith('conv1/7x7_s2') and G.nodes[aid]['type'] == 'Add' and G.nodes[kid]['type'] == 'Const'
+    assert G.nodes[sid]['type'] == 'Parameter' and aid in ex._fused_away
+    _, _, ex2 = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=False)
+    assert ex2._pre_add == {}
+
+
 def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
     """plan_streams on GoogLeNet (fused, Concat-eliminated) and on the unfused graph: every producer a node reads from is either on the node's own stream or in its
     wait list (and records an event); the four arms of an inception module land on four different streams; a host plugin
