@@ -243,6 +243,18 @@ int    pvhip_conv2d_f16(const float* x, const float* wpack, float* y,
                         const float* bias, int act,
                         int out_channel_offset, int out_channels_total,
                         float act_lo, float act_hi);
+/* The second f16 kernel (ABI v13): layers whose channel count is a multiple of 16 (every GoogLeNet layer but conv1) on the LDS-DMA
+ * kernel of pvhip_conv2d_f32 -- the SAME fp32 tiles reach LDS by the same copies, wpack is the fp32 panel of pvhip_conv2d_pack_f32 --
+ * with a stage of 16 channels as ONE v_mfma_f32_32x32x16_f16 per 32-channel tile (operands rounded to fp16 as they are read from LDS,
+ * fp32 accumulation): 1/16 of the matrix-core cycles, no register-staged gather.  Same arithmetic as pvhip_conv2d_f16 in another
+ * summation order ((r,s)-major).  _supported: C % 16 == 0 and a window of fewer than 64 taps.                                    */
+int    pvhip_conv2d_f16_dma_supported(int c, int kh, int kw);
+int    pvhip_conv2d_f16_dma(const float* x, const float* wpack, float* y,
+                            int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
+                            int sh, int sw, int pad_top, int pad_left,
+                            const float* bias, int act,
+                            int out_channel_offset, int out_channels_total,
+                            float act_lo, float act_hi);
 int    pvhip_matmul_f16(const float* a, const float* b, float* c, int m, int n, int k,
                         int trans_a, int trans_b);
 

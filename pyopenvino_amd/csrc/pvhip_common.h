@@ -41,6 +41,7 @@ struct Settings {
     int  wtile_m = 2, wtile_n = 1;         // PVHIP_CONV_WTILE=TMxTN (wave kernel, units of 32)
     int  conv_lds_pad_kb = 0;              // PVHIP_CONV_LDS_PAD_KB: extra dynamic LDS caps workgroups per CU
     bool conv_nopw = false;                // PVHIP_CONV_NOPW: general kernel without its pointwise copy
+    int  f16_bm = 0;                       // PVHIP_CONV_F16_BM=32|64|128: channel tile of the f16 LDS-DMA form (tuning runs)
     bool conv_novalid = false;             // PVHIP_CONV_NOVALID: c-major gather with the window test even where no window leaves the tensor (A/B)
     bool conv_pw16 = false;                // PVHIP_CONV_PW: 16-byte gather of the register-staged kernel
     int  multi_bm = 32;                    // PVHIP_CONV_MULTI_BM

@@ -535,10 +535,15 @@ typedef const __attribute__((address_space(4))) int* const_int_p;
 // kValid (c-major only): no padding and every window inside the tensor -- no window test at all, the tap's offset rides in the scalar
 // offset of the load: ZERO vector instructions per gathered row instead of five (shift, and, compare, select, add), which were 45 of
 // conv1's 61 issue slots per 16 MFMAs.  Padded layers reach it through pvhip_pad2d_f32 (the Convolution plugin pads once per launch).
-template <int BM, bool kRS, bool kPW = false, bool kValid = false>   // kRS: (r,s)-major reduction order (C % 16 == 0); else c-major with the window-bit table
+// kF16 (FP16 IRs, (r,s)-major only): the SAME fp32 tiles in LDS, but a stage of 16 channels is ONE v_mfma_f32_32x32x16_f16 per 32-channel
+// tile: a lane reads its eight reduction rows of both operands, rounds them to fp16 (to nearest even; the constants of an FP16 IR are fp16
+// values already) and the matrix cores accumulate in fp32 -- 32 MFMA cycles per tile and stage instead of 512, after which the launch is
+// as fast as its LDS-DMA copies (Convolution.py:57-87 computed in numpy float16 by the reference, common_def.py:13-17).
+template <int BM, bool kRS, bool kPW = false, bool kValid = false, bool kF16 = false>   // kRS: (r,s)-major reduction order (C % 16 == 0); else c-major with the window-bit table
 __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     static_assert(!kPW || kRS, "the pointwise copy uses the (r,s)-major panel");
     static_assert(!kValid || !kRS, "the test-free gather is the c-major one");
+    static_assert(!kF16 || kRS, "the f16 form takes whole 16-channel stages");
     constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
     constexpr int A_PIECES = kBK * BM * 4 / 1024;          // 1-KiB wave-instructions per weight tile
     constexpr int A_PER_WAVE = (A_PIECES + 3) / 4;
@@ -681,6 +686,26 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+        if (kF16) {
+            typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+            PV3_ISSUE(buf ^ 1);     // stage kt+1 (past the end: the spare zero stages)
+            __builtin_amdgcn_sched_barrier(0);
+            half8 b8;               // MFMA operand layout: lane (column l31, half lh) holds reduction rows 8 lh .. 8 lh + 7
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b8[q] = (_Float16)Bs[buf][8 * lh + q][b_col];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                half8 a8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a8[q] = (_Float16)As[buf][8 * lh + q][l31 + i * 32];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            PV3_ADVANCE();
+            dma_wait_all();
+            __syncthreads();
+            continue;
+        }
         float af[2][TM], bf[2];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lh][l31 + i * 32];
@@ -954,12 +979,17 @@ inline bool dma_enabled() { return settings().conv_kernel != 1; }
 inline bool dma_enabled() { return true; }
 #endif
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool kF16 = false>
 void launch_conv(const ConvArgs& a, int n_ptiles) {
     if (BN == 128 && WAVES_M == 1 && dma_enabled() && (rs_major(a.C, a.kh, a.kw) || a.kh * a.kw < 64)) {
         const size_t dyn = (size_t)settings().conv_lds_pad_kb * 1024;     // tuning: extra dynamic LDS caps workgroups per CU
         const bool pw = rs_major(a.C, a.kh, a.kw) && a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
                         a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && !settings().conv_nopw;
+        if (kF16) {           // conv2d_impl sends only (r,s)-major layers here
+            if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, true, false, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
+            else    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, false, false, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
+            return;
+        }
         if (pw)
             hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
         else if (rs_major(a.C, a.kh, a.kw))
@@ -1039,7 +1069,7 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
 
 static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh,
                        int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
-                       int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+                       int out_channel_offset, int out_channels_total, float act_lo, float act_hi, bool f16 = false) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && k_out > 0 && kh > 0 && kw > 0 && oh >= 0 && ow >= 0);
     PVHIP_CHECK_ARG(sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0);
@@ -1074,6 +1104,20 @@ static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int 
 
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
 
+    if (f16) {      // pvhip_conv2d_f16_dma: every layer on the LDS-DMA kernel's f16 form (the matrix work is 16x cheaper: no Winograd, 64-channel tiles)
+        if (!rs_major(c, kh, kw) || !dma_enabled())
+            return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_dma: C %% 16 == 0 and a window of fewer than 64 taps required (C=%d, %dx%d)", c, kh, kw);
+        // the activation tile of a stage is re-read once per channel tile (through L2, which is what this form is bound by): wide tiles
+        int bm = k_out > 64 ? 128 : (k_out > 32 ? 64 : 32);
+        if (settings().f16_bm) bm = settings().f16_bm;          // PVHIP_CONV_F16_BM: tuning runs
+        a.n_mtiles = (k_out + bm - 1) / bm;
+        const int n_ptiles = (a.P + 127) / 128;
+        if (bm == 128)     launch_conv<128, 128, 1, 4, true>(a, n_ptiles);
+        else if (bm == 64) launch_conv<64, 128, 1, 4, true>(a, n_ptiles);
+        else               launch_conv<32, 128, 1, 4, true>(a, n_ptiles);
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
     // ---- 3x3 / stride 1 / same padding: Winograd F(2x2, 3x3), 2.25x fewer matrix-core operations (pvhip_wino.hip)
     if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
         const PwDest d{y, 0, k_out, a.y_ctotal, a.y_coff};
@@ -1179,6 +1223,15 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
                      int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
     return conv2d_impl(x, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
                        out_channels_total, act_lo, act_hi);
+}
+
+int pvhip_conv2d_f16_dma_supported(int c, int kh, int kw) { return (c > 0 && kh > 0 && kw > 0 && rs_major(c, kh, kw) && dma_enabled()) ? 1 : 0; }
+
+int pvhip_conv2d_f16_dma(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh, int kw,
+                         int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
+                         int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+    return conv2d_impl(x, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
+                       out_channels_total, act_lo, act_hi, true);
 }
 
 int pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left) {

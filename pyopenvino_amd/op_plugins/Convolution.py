@@ -121,7 +121,9 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
                  pads_end[0], pads_end[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
         x, h, wd, pads_begin, pads_end = xp, hp, wp, (0, 0), (0, 0)
-    wpack = packed_weights_f16(node, w, h, wd) if f16 else packed_weights(node, w, h, wd)
+    # FP16 IRs: layers with C % 16 == 0 run the f16 form of the LDS-DMA kernel on the fp32 panel (PVHIP_CONV_F16_DMA=0: the first f16 kernel)
+    f16_dma = f16 and dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
+    wpack = packed_weights_f16(node, w, h, wd) if (f16 and not f16_dma) else packed_weights(node, w, h, wd)
     act_code, act_lo, act_hi = 0, 0.0, 0.0
     if act is not None:
         act_code = 1 if act[0] == 'relu' else 2
@@ -137,7 +139,11 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         y = dev.ChannelSlice(target, coff, kn)
     tail = (n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
-    if f16:         # FP16 IR: fp16 operands on the f16 matrix cores, fp32 accumulation
+    if f16:
+        node['_hip_f16'] = 'lds-dma' if f16_dma else 'gather'      # which f16 kernel ran (tests)
+    if f16_dma:
+        dev.call('pvhip_conv2d_f16_dma', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
+    elif f16:       # FP16 IR: fp16 operands on the f16 matrix cores, fp32 accumulation
         dev.call('pvhip_conv2d_f16', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
     else:
         dev.call('pvhip_conv2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)

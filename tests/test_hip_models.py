@@ -372,7 +372,7 @@ def test_fp16_ir_on_the_f16_matrix_cores(hip, tmp_path):
         soft = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'SoftMax')
         logits = np.asarray(next(iter(net.G.nodes[next(iter(net.G.pred[soft]))]['output'].values()))['data'])
         outs[mode] = (prob, logits)
-        ran_f16 = ['_hip_wpack16' in net.G.nodes[n] for n in net.G.nodes if net.G.nodes[n]['type'] == 'Convolution']
+        ran_f16 = ['_hip_f16' in net.G.nodes[n] for n in net.G.nodes if net.G.nodes[n]['type'] == 'Convolution']
         assert all(ran_f16) if not mode else not any(ran_f16)
     prob, logits = outs[False]
     assert np.isfinite(prob).all() and np.array_equal(prob.argmax(axis=1), z['logits'].argmax(axis=1))
@@ -458,7 +458,7 @@ def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp
     z = np.load(os.path.join(GOLDEN, 'googlenet_fp16_rows2.npz'))
     images = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
     prob16, logits16, net16 = _googlenet_fp16_logits(HIP, False, images, tmp_path)
-    assert net16.f16_mfma and all('_hip_wpack16' in net16.G.nodes[n] for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution')
+    assert net16.f16_mfma and all('_hip_f16' in net16.G.nodes[n] for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution')
     prob32, logits32, net32 = _googlenet_fp16_logits(HIP, True, images, tmp_path)
     assert not net32.f16_mfma
     err_ref, err_32 = helpers.rel_err(logits16, z['logits']), helpers.rel_err(logits16, logits32)

@@ -957,6 +957,48 @@ def test_conv_f16_mfma_vs_oracle_on_rounded_operands(hip):
     assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
 
 
+def test_conv_f16_dma_form_vs_oracle_and_first_f16_kernel(hip, monkeypatch):
+    """pvhip_conv2d_f16_dma (FP16 IRs, C % 16 == 0: the fp32 tiles of the LDS-DMA kernel, one v_mfma_f32_32x32x16_f16 per stage and
+    32-channel tile) against the oracle on fp16-ROUNDED operands (1e-5: only the fp32 summation order differs) and against the first
+    f16 kernel (PVHIP_CONV_F16_DMA=0: the same arithmetic in c-major order).  3x3 / 5x5 / 7x7 / 1x1 windows, strides, padding, the
+    pointwise copy (H*W % 4 == 0) and the gather (odd H*W), K_out below / between / above whole tiles, a pixel count that is not a
+    multiple of 128, bias + ReLU fused into a wider tensor."""
+    from pyopenvino_amd import device as dev
+    cases = [((2, 16, 12, 12), 40, 3, (1, 1), (1, 1), (1, 1)), ((3, 64, 14, 14), 96, 1, (1, 1), (0, 0), (0, 0)),
+             ((2, 32, 7, 7), 16, 1, (1, 1), (0, 0), (0, 0)), ((1, 48, 9, 11), 208, 3, (2, 2), (1, 1), (1, 1)),
+             ((2, 16, 13, 13), 33, 5, (1, 1), (2, 2), (2, 2)), ((5, 32, 6, 6), 70, 7, (1, 1), (3, 3), (3, 3)),
+             ((1, 160, 7, 7), 320, 3, (1, 1), (1, 1), (1, 1)), ((2, 16, 28, 28), 32, 5, (1, 1), (2, 2), (2, 2))]
+    for xs, k, kk, st, pb, pe in cases:
+        x, w = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5)
+        assert dev.call('pvhip_conv2d_f16_dma_supported', xs[1], kk, kk)
+        outs = {}
+        for mode in ('1', '0'):
+            helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_DMA', mode)
+            dev.reload_settings()
+            node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+            node['_f16_mfma'] = True
+            outs[mode] = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w})))
+            assert node['_hip_f16'] == ('lds-dma' if mode == '1' else 'gather')
+        want = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x, w], conv_data(st, pb, pe)), {0: f16r(x), 1: f16r(w)},
+                                                              kernel_type='special'))
+        assert_close(outs['1'], want, 1e-5, 'f16 LDS-DMA form {} k{} {}x{}'.format(xs, k, kk, kk))
+        assert_close(outs['1'], outs['0'], 1e-5, 'f16 LDS-DMA form vs the first f16 kernel {} k{}'.format(xs, k))
+    monkeypatch.delenv('PVHIP_CONV_F16_DMA', raising=False)
+    dev.reload_settings()
+    assert not dev.call('pvhip_conv2d_f16_dma_supported', 3, 7, 7) and not dev.call('pvhip_conv2d_f16_dma_supported', 16, 8, 8)
+    x, w, b = np.abs(rnd(1, (2, 32, 10, 6))), rnd(2, (40, 32, 3, 3), 0.1), rnd(3, (1, 40, 1, 1), 0.3)
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
+    node['_f16_mfma'] = True
+    wide = dev.DeviceTensor.from_numpy(np.full((2, 50, 10, 6), -1.0, dtype=np.float32))
+    fused = dict(node)
+    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
+    hip_plugin('Convolution').compute(fused, {0: x, 1: w})
+    got = np.asarray(wide)
+    unfused = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+    assert_bit_exact(got[:, 7:47], np.maximum(unfused + b, 0).astype(np.float32), 'f16 LDS-DMA form: fused epilogue')
+    assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
+
+
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
     """The reference's own FP16 node fixture (resources/node_args_6.pickle, replayed as test_node_sample.py:1-16 does; cropped)
     in float16 as the reference computes it: the f16-MFMA result is within fp16 tolerance of the reference's float16 output
