@@ -255,6 +255,20 @@ int    pvhip_conv2d_f16_dma(const float* x, const float* wpack, float* y,
                             const float* bias, int act,
                             int out_channel_offset, int out_channels_total,
                             float act_lo, float act_hi);
+/* The third f16 kernel (ABI v13): stride-1 "same" windows (1x1; 3x3 / pad 1; 5x5 / pad 2) with C % 16 == 0 and rows short enough that
+ * a 128-pixel tile and its halo are one 1-KiB span per channel (128 + 2 * pad * (w + 1) + 3 <= 256 floats: every GoogLeNet layer but
+ * conv1).  A workgroup copies ONE span per channel and stage into LDS and serves every tap and up to 128 output channels from it (no
+ * copy per tap, none per channel tile); the weights are fp16 MFMA fragments packed once by _span_pack (wf: _span_pack_elems FLOATS).
+ * Operands rounded to fp16 as they are read, fp32 accumulation; arguments as pvhip_conv2d_f32.                                     */
+int    pvhip_conv2d_f16_span_supported(int c, int h, int w, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
+size_t pvhip_conv2d_f16_span_pack_elems(int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_f16_span_pack(const float* w_oihw, float* wf, int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_f16_span(const float* x, const float* wf, float* y,
+                             int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
+                             int sh, int sw, int pad_top, int pad_left,
+                             const float* bias, int act,
+                             int out_channel_offset, int out_channels_total,
+                             float act_lo, float act_hi);
 int    pvhip_matmul_f16(const float* a, const float* b, float* c, int m, int n, int k,
                         int trans_a, int trans_b);
 

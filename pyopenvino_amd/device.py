@@ -83,6 +83,10 @@ SIGNATURES = {
     'pvhip_conv2d_f16_pack': (_c.c_int, [_fp, _fp] + [_c.c_int] * 6),
     'pvhip_conv2d_f16': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_f16_dma_supported': (_c.c_int, [_c.c_int] * 3),
+    'pvhip_conv2d_f16_span_supported': (_c.c_int, [_c.c_int] * 11),
+    'pvhip_conv2d_f16_span_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
+    'pvhip_conv2d_f16_span_pack': (_c.c_int, [_fp, _fp] + [_c.c_int] * 4),
+    'pvhip_conv2d_f16_span': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_f16_dma': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_matmul_f16': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
@@ -101,7 +105,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -175,15 +179,17 @@ settings_serial = 0      # bumped by every reload: host-side plans that bake ker
 
 conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'      # Convolution plugin: pad the input of a c-major layer in a pass of its own
 conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'    # Convolution plugin, FP16 IRs: the f16 form of the LDS-DMA kernel where it applies
+conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)  # ... and the span kernel before it: 1 = 3x3 / 5x5 layers, 2 = 1x1 too (slower there), 0 = never
 
 
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
-    global settings_serial, conv_prepad, conv_f16_dma
+    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span
     call('pvhip_settings_reload')
     conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'
+    conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)
     settings_serial += 1
 
 

@@ -71,6 +71,18 @@ def packed_weights_f16(node: dict, w, h: int, wd: int) -> 'dev.DeviceTensor':
     return wpack
 
 
+def packed_weights_f16_span(node: dict, w) -> 'dev.DeviceTensor':
+    """fp16 MFMA fragments of the span kernel (FP16 IRs, stride-1 "same" windows), cached on the node like packed_weights."""
+    cached = node.get('_hip_wspan')
+    if cached is not None and cached[0] is w._block and cached[1] == w.shape:
+        return cached[2]
+    k, c, kh, kw = w.shape
+    wpack = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_f16_span_pack_elems', k, c, kh, kw)),))
+    dev.call('pvhip_conv2d_f16_span_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wpack.ptr), k, c, kh, kw)
+    node['_hip_wspan'] = (w._block, w.shape, wpack)
+    return wpack
+
+
 def prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16=False) -> bool:
     """True for a padded layer that libpvhip runs on the c-major form of the LDS-DMA kernel (C % 16 != 0, not a Winograd or pointwise
     layer): its gather tests every tap against the window unless no window leaves the tensor (PVHIP_CONV_PREPAD=0: never)."""
@@ -122,8 +134,13 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
                  pads_end[0], pads_end[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
         x, h, wd, pads_begin, pads_end = xp, hp, wp, (0, 0), (0, 0)
     # FP16 IRs: layers with C % 16 == 0 run the f16 form of the LDS-DMA kernel on the fp32 panel (PVHIP_CONV_F16_DMA=0: the first f16 kernel)
-    f16_dma = f16 and dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
-    wpack = packed_weights_f16(node, w, h, wd) if (f16 and not f16_dma) else packed_weights(node, w, h, wd)
+    f16_span = f16 and dev.conv_f16_span >= (2 if kh == 1 else 1) and bool(dev.call('pvhip_conv2d_f16_span_supported', c, h, wd, kh, kw, strides[0], strides[1],
+                                                            pads_begin[0], pads_begin[1], oh, ow))
+    f16_dma = f16 and not f16_span and dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
+    if f16_span:
+        wpack = packed_weights_f16_span(node, w)
+    else:
+        wpack = packed_weights_f16(node, w, h, wd) if (f16 and not f16_dma) else packed_weights(node, w, h, wd)
     act_code, act_lo, act_hi = 0, 0.0, 0.0
     if act is not None:
         act_code = 1 if act[0] == 'relu' else 2
@@ -140,8 +157,10 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     tail = (n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1],
             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
     if f16:
-        node['_hip_f16'] = 'lds-dma' if f16_dma else 'gather'      # which f16 kernel ran (tests)
-    if f16_dma:
+        node['_hip_f16'] = 'span' if f16_span else ('lds-dma' if f16_dma else 'gather')      # which f16 kernel ran (tests)
+    if f16_span:
+        dev.call('pvhip_conv2d_f16_span', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
+    elif f16_dma:
         dev.call('pvhip_conv2d_f16_dma', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
     elif f16:       # FP16 IR: fp16 operands on the f16 matrix cores, fp32 accumulation
         dev.call('pvhip_conv2d_f16', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)

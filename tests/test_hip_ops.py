@@ -972,6 +972,7 @@ def test_conv_f16_dma_form_vs_oracle_and_first_f16_kernel(hip, monkeypatch):
         x, w = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5)
         assert dev.call('pvhip_conv2d_f16_dma_supported', xs[1], kk, kk)
         outs = {}
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_SPAN', '0')
         for mode in ('1', '0'):
             helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_DMA', mode)
             dev.reload_settings()
@@ -996,6 +997,54 @@ def test_conv_f16_dma_form_vs_oracle_and_first_f16_kernel(hip, monkeypatch):
     got = np.asarray(wide)
     unfused = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
     assert_bit_exact(got[:, 7:47], np.maximum(unfused + b, 0).astype(np.float32), 'f16 LDS-DMA form: fused epilogue')
+    assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
+    monkeypatch.delenv('PVHIP_CONV_F16_SPAN', raising=False)
+    dev.reload_settings()
+
+
+def test_conv_f16_span_kernel_vs_oracle_and_the_other_f16_kernels(hip, monkeypatch):
+    """pvhip_conv2d_f16_span (FP16 IRs: stride-1 "same" 1x1 / 3x3 / 5x5 windows, C % 16 == 0: one LDS span per channel and stage serves
+    every tap and up to 256 output channels) against the oracle on fp16-ROUNDED operands (1e-5) and against the LDS-DMA form
+    (PVHIP_CONV_F16_SPAN=0).  GoogLeNet's extents (56, 28, 14, 7), H*W that is not a multiple of 4 (dword copies) or of 128 (a tile's
+    tail), several tiles per image, output channels below / between / above whole tiles and above one channel group (> 256), one
+    and several stages, odd and even stage counts; bias + ReLU fused into a wider tensor."""
+    from pyopenvino_amd import device as dev
+    cases = [((2, 16, 12, 12), 40, 3), ((3, 64, 14, 14), 96, 1), ((2, 32, 7, 7), 16, 1), ((2, 48, 7, 7), 128, 5),
+             ((1, 64, 56, 56), 192, 3), ((2, 96, 28, 28), 128, 3), ((2, 16, 28, 28), 32, 5), ((1, 160, 14, 14), 320, 3),
+             ((2, 192, 7, 7), 384, 3), ((1, 16, 9, 5), 33, 3), ((1, 32, 14, 14), 208, 3), ((3, 16, 13, 13), 7, 5),
+             ((1, 32, 20, 61), 24, 3), ((2, 16, 3, 3), 300, 3)]
+    for xs, k, kk in cases:
+        pad = (kk - 1) // 2
+        x, w = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5)
+        assert dev.call('pvhip_conv2d_f16_span_supported', xs[1], xs[2], xs[3], kk, kk, 1, 1, pad, pad, xs[2], xs[3]), (xs, kk)
+        outs = {}
+        for mode in ('2', '0'):       # 2: the 1x1 layers too (by default they stay on the LDS-DMA form, which is faster there)
+            helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_SPAN', mode)
+            dev.reload_settings()
+            node = make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad)))
+            node['_f16_mfma'] = True
+            outs[mode] = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w})))
+            assert node['_hip_f16'] == ('span' if mode == '2' else 'lds-dma')
+        want = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad))),
+                                                              {0: f16r(x), 1: f16r(w)}, kernel_type='special'))
+        assert_close(outs['2'], want, 1e-5, 'f16 span kernel {} k{} {}x{}'.format(xs, k, kk, kk))
+        assert_close(outs['2'], outs['0'], 1e-5, 'f16 span kernel vs the LDS-DMA form {} k{}'.format(xs, k))
+    monkeypatch.delenv('PVHIP_CONV_F16_SPAN', raising=False)
+    dev.reload_settings()
+    for c, h, w_, kk, st, pad, oh, ow in [(3, 8, 8, 3, 1, 1, 8, 8), (16, 8, 8, 3, 2, 1, 4, 4), (16, 8, 8, 3, 1, 0, 6, 6), (16, 8, 8, 7, 1, 3, 8, 8),
+                                          (16, 8, 70, 3, 1, 1, 8, 70), (16, 8, 40, 5, 1, 2, 8, 40)]:
+        assert not dev.call('pvhip_conv2d_f16_span_supported', c, h, w_, kk, kk, st, st, pad, pad, oh, ow), (c, h, w_, kk, st, pad)
+    x, w, b = np.abs(rnd(1, (2, 32, 10, 6))), rnd(2, (40, 32, 3, 3), 0.1), rnd(3, (1, 40, 1, 1), 0.3)
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
+    node['_f16_mfma'] = True
+    wide = dev.DeviceTensor.from_numpy(np.full((2, 50, 10, 6), -1.0, dtype=np.float32))
+    fused = dict(node)
+    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
+    hip_plugin('Convolution').compute(fused, {0: x, 1: w})
+    assert fused['_hip_f16'] == 'span'
+    got = np.asarray(wide)
+    unfused = first_out(hip_plugin('Convolution').compute(dict(node), {0: x, 1: w}))
+    assert_bit_exact(got[:, 7:47], np.maximum(unfused + b, 0).astype(np.float32), 'f16 span kernel: fused epilogue')
     assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
 
 
