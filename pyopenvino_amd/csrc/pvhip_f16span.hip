@@ -80,6 +80,11 @@ __global__ __launch_bounds__(kBlock) void conv_f16_span_kernel(SpanArgs a) {
     __shared__ __attribute__((aligned(1024))) float    Bs[kSC][kRow];
     __shared__ __attribute__((aligned(16)))   _Float16 Hs[kImgPx][kPxH];
 
+#ifdef PVHIP_DIAG
+    const int abl = a.abl;      // scripts/time_f16_span.py: parts switched off (wrong results on purpose)
+#else
+    constexpr int abl = 0;
+#endif
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void conv_f16_span_kernel(SpanArgs a) {
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
             const int      row = 4 * wid + j;                                                                    \
             const unsigned vo  = voff0 + (unsigned)(((cs_) * kSC + row) * HW) * 4u;                              \
-            if (a.abl & 1) continue;                                                                             \
+            if (abl & 1) continue;                                                                             \
             if (VEC) span_dma_b128(xr, &Bs[row][0], vo);                                                         \
             else {                                                                                               \
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) span_dma_b32(xr, &Bs[row][64 * q], vo + 256u * q); \
@@ -162,14 +167,14 @@ __global__ __launch_bounds__(kBlock) void conv_f16_span_kernel(SpanArgs a) {
     {                                                                                                            \
         const unsigned so = (unsigned)((((mt * ncs + (cs_)) * TAPS + (tap_)) * a.tm) * 1024);                    \
         _Pragma("unroll") for (int j = 0; j < TPW; ++j)                                                          \
-            if (have[j] && !(a.abl & 16)) dst_[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane, so + (unsigned)(wid + 4 * j) * 1024u, 0)); \
+            if (have[j] && !(abl & 16)) dst_[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane, so + (unsigned)(wid + 4 * j) * 1024u, 0)); \
     }
 
     PVS_ISSUE(0);
     for (int cs = 0; cs < ncs; ++cs) {
         span_dma_wait<0>();
         __syncthreads();                       // the span of stage cs has landed; every read of the previous fp16 image is done
-        if (dst_px >= 0 && !(a.abl & 2)) {     // fp32 span column -> sixteen fp16 channels of one pixel
+        if (dst_px >= 0 && !(abl & 2)) {     // fp32 span column -> sixteen fp16 channels of one pixel
             half8 lo8, hi8;
 #pragma unroll
             for (int q = 0; q < 8; ++q) { lo8[q] = (_Float16)Bs[q][tid]; hi8[q] = (_Float16)Bs[8 + q][tid]; }
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void conv_f16_span_kernel(SpanArgs a) {
             for (int n = 0; n < 4; ++n) b8[n] = *reinterpret_cast<const half8*>(hs0 + pixaddr[n] + shift);
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
-                if (have[j] && !(a.abl & 4)) {
+                if (have[j] && !(abl & 4)) {
 #pragma unroll
                     for (int n = 0; n < 4; ++n) acc[j][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][j], b8[n], acc[j][n], 0, 0, 0);
                 }
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void conv_f16_span_kernel(SpanArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = row0 + (r & 3) + 8 * (r >> 2);
-                if (k < a.K && !(a.abl & 8)) conv_store1(yp + (size_t)k * HW, vv[r]);
+                if (k < a.K && !(abl & 8)) conv_store1(yp + (size_t)k * HW, vv[r]);
             }
         }
     }
