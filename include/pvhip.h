@@ -208,6 +208,11 @@ int    pvhip_conv2d_pooled_supported(int n, int c, int h, int w, int k_out);
 int    pvhip_conv2d_pooled_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out,
                                const float* bias, int act, int out_channel_offset, int out_channels_total,
                                float act_lo, float act_hi);
+/* The same pair for an FP16 IR read with fp16_as_fp32=False (ABI v13): the window maximum in fp32, then both operands rounded to fp16 as
+ * they are read from LDS, fp32 accumulation on v_mfma_f32_32x32x16_f16 -- what pvhip_maxpool2d_f32 followed by pvhip_conv2d_f16_dma does. */
+int    pvhip_conv2d_pooled_f16(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out,
+                               const float* bias, int act, int out_channel_offset, int out_channels_total,
+                               float act_lo, float act_hi);
 /* Several Convolution.py:149-176 calls that share their input (the 1x1, 3x3_reduce and 5x5_reduce arms of an inception
  * module) as ONE launch: the input is read once and the small arms ride in the big one's grid.  Only 1x1 / stride 1 /
  * unpadded convolutions with c % 16 == 0 (pvhip_conv2d_multi_supported; no device needed).  wpack is the panel of
@@ -229,6 +234,12 @@ int    pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, 
                               int oh, int ow, int sh, int sw, int pad_top, int pad_left,
                               const float* bias, int act, float act_lo, float act_hi,
                               int n_dest, const pvhip_conv_dest* dests);
+/* The same launch for an FP16 IR read with fp16_as_fp32=False (ABI v13): the f16 form of the LDS-DMA kernel (pvhip_conv2d_f16_dma) over
+ * the members' panel -- the module input is read once, operands rounded to fp16 as they are read from LDS, fp32 accumulation.          */
+int    pvhip_conv2d_multi_f16_dma(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw,
+                                  int oh, int ow, int sh, int sw, int pad_top, int pad_left,
+                                  const float* bias, int act, float act_lo, float act_hi,
+                                  int n_dest, const pvhip_conv_dest* dests);
 
 /* ---- FP16 IRs.  The reference runs an FP16 IR in numpy float16 (common_def.py:13-17; Convolution.py:57-87 and
  * MatMul.py:9-17 then multiply AND accumulate in float16).  These entries take the same fp32 device tensors as their _f32

@@ -1247,9 +1247,9 @@ int pvhip_conv2d_multi_supported(int c, int kh, int kw, int sh, int sw, int pad_
             rs_major(c, kh, kw)) ? 1 : 0;
 }
 
-int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw, int oh, int ow, int sh,
-                           int sw, int pad_top, int pad_left, const float* bias, int act, float act_lo, float act_hi, int n_dest,
-                           const pvhip_conv_dest* dests) {
+static int conv2d_multi_impl(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw, int oh, int ow, int sh,
+                             int sw, int pad_top, int pad_left, const float* bias, int act, float act_lo, float act_hi, int n_dest,
+                             const pvhip_conv_dest* dests, bool f16) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && oh >= 0 && ow >= 0 && dests != nullptr);
     if (!pvhip_conv2d_multi_supported(c, kh, kw, sh, sw, pad_top, pad_left, n_dest) || oh != h || ow != w)
@@ -1276,7 +1276,7 @@ int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_multi_f32: input exceeds 2^29 elements or an output 2^31");
     if (in_e == 0 || oh == 0 || ow == 0) return PVHIP_OK;
     PVHIP_CHECK_ARG(x != nullptr && wpack != nullptr);
-    if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
+    if (!f16 && pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) {
         PwDest pd[kMaxConvDests];
         for (int i = 0; i < n_dest; ++i) pd[i] = PwDest{a.seg[i].y, a.seg[i].m_begin, a.seg[i].k, a.seg[i].ctotal, a.seg[i].coff};
         const int kred_pad = round_up_int(c, kBK), kout_pad = round_up_int(k_panel, kKoutAlign);
@@ -1301,10 +1301,26 @@ int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int
     a.relu = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = a.seg[0].ctotal; a.y_coff = a.seg[0].coff;
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
-    const int bm = settings().multi_bm;       // PVHIP_CONV_MULTI_BM: tuning runs only
+    int bm = settings().multi_bm;             // PVHIP_CONV_MULTI_BM: tuning runs only
+    if (f16) bm = settings().f16_bm ? settings().f16_bm : (k_panel > 64 ? 128 : (k_panel > 32 ? 64 : 32));      // wide tiles: the input tile is re-read per channel tile
     a.n_mtiles = (k_panel + bm - 1) / bm;          // a 64-channel tile may straddle two ranges: the epilogue looks the range up per 32 channels
     const int n_ptiles = (a.P + 127) / 128;
     const bool pw = (h * w) % 4 == 0;
+    if (f16) {           // FP16 IRs: the f16 form of the same kernel (pvhip_conv2d_f16_dma), one launch for the module's 1x1 convolutions
+        const dim3 grid(a.n_mtiles * n_ptiles);
+        if (bm == 128) {
+            if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, true, true, false, true>), grid, dim3(kBlock), 0, state().stream, a);
+            else    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, true, false, false, true>), grid, dim3(kBlock), 0, state().stream, a);
+        } else if (bm == 64) {
+            if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<64, true, true, false, true>), grid, dim3(kBlock), 0, state().stream, a);
+            else    hipLaunchKernelGGL((conv_igemm_dma_kernel<64, true, false, false, true>), grid, dim3(kBlock), 0, state().stream, a);
+        } else {
+            if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, true, false, true>), grid, dim3(kBlock), 0, state().stream, a);
+            else    hipLaunchKernelGGL((conv_igemm_dma_kernel<32, true, false, false, true>), grid, dim3(kBlock), 0, state().stream, a);
+        }
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
     if (bm == 128) {
         if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<128, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
         else    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, true, false>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), 0, state().stream, a);
@@ -1317,6 +1333,18 @@ int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int
     }
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
+}
+
+int pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw, int oh, int ow, int sh,
+                           int sw, int pad_top, int pad_left, const float* bias, int act, float act_lo, float act_hi, int n_dest,
+                           const pvhip_conv_dest* dests) {
+    return conv2d_multi_impl(x, wpack, n, c, h, w, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, act, act_lo, act_hi, n_dest, dests, false);
+}
+
+int pvhip_conv2d_multi_f16_dma(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw, int oh, int ow, int sh,
+                               int sw, int pad_top, int pad_left, const float* bias, int act, float act_lo, float act_hi, int n_dest,
+                               const pvhip_conv_dest* dests) {
+    return conv2d_multi_impl(x, wpack, n, c, h, w, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, act, act_lo, act_hi, n_dest, dests, true);
 }
 
 }  // extern "C"

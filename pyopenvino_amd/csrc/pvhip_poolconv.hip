@@ -56,7 +56,9 @@ __device__ __forceinline__ void pc_load(pc_f2& d, __amdgpu_buffer_rsrc_t r, unsi
     d = __builtin_bit_cast(pc_f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 
-template <int BM, int VEC>
+// kF16 (FP16 IRs): the same tiles, a stage of 16 channels as ONE v_mfma_f32_32x32x16_f16 per 32-channel tile, both operands rounded to
+// fp16 as they are read from LDS (the maximum of the window is taken in fp32, then rounded: what MaxPool followed by pvhip_conv2d_f16_dma does)
+template <int BM, int VEC, bool kF16 = false>
 __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
     constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
     constexpr int CONSUMERS = 4, PRODUCERS = 4;
@@ -198,6 +200,23 @@ __global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
             const int buf = s & 1;
             PVP_LOAD_A(s + 1, buf ^ 1);          // past the end: the spare zero stages of the panel
             __builtin_amdgcn_sched_barrier(0);
+            if (kF16) {
+                typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+                half8 b8;               // MFMA operand layout: lane (column l31, half lh) holds reduction rows 8 lh .. 8 lh + 7
+#pragma unroll
+                for (int q = 0; q < 8; ++q) b8[q] = (_Float16)Bs[buf][8 * lh + q][b_col];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    half8 a8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a8[q] = (_Float16)As[buf][8 * lh + q][l31 + i * 32];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                continue;
+            }
             float af[2][TM], bf[2];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[0][i] = As[buf][lh][l31 + i * 32];
@@ -267,8 +286,8 @@ extern "C" {
 
 int pvhip_conv2d_pooled_supported(int n, int c, int h, int w, int k_out) { return pooled_supported(n, c, h, w, k_out) ? 1 : 0; }
 
-int pvhip_conv2d_pooled_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, const float* bias,
-                            int act, int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, const float* bias,
+                              int act, int out_channel_offset, int out_channels_total, float act_lo, float act_hi, bool f16) {
     PVHIP_REQUIRE_INIT();
     if (!pooled_supported(n, c, h, w, k_out))
         return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_pooled_f32: shape outside the fused kernel (ask pvhip_conv2d_pooled_supported first)");
@@ -295,8 +314,13 @@ int pvhip_conv2d_pooled_f32(const float* x, const float* wpack, float* y, int n,
     const bool v4 = w % 4 == 0;
 #define PVP_LAUNCH(BM_)                                                                                           \
     do {                                                                                                          \
-        if (v4) hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 4>), grid, block, 0, state().stream, a);             \
-        else    hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 2>), grid, block, 0, state().stream, a);             \
+        if (f16) {                                                                                                \
+            if (v4) hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 4, true>), grid, block, 0, state().stream, a);   \
+            else    hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 2, true>), grid, block, 0, state().stream, a);   \
+        } else {                                                                                                  \
+            if (v4) hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 4>), grid, block, 0, state().stream, a);         \
+            else    hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 2>), grid, block, 0, state().stream, a);         \
+        }                                                                                                         \
     } while (0)
     if (bm == 32) PVP_LAUNCH(32);
     else if (bm == 64) PVP_LAUNCH(64);
@@ -304,6 +328,16 @@ int pvhip_conv2d_pooled_f32(const float* x, const float* wpack, float* y, int n,
 #undef PVP_LAUNCH
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
+}
+
+int pvhip_conv2d_pooled_f32(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, const float* bias,
+                            int act, int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+    return conv2d_pooled_impl(x, wpack, y, n, c, h, w, k_out, bias, act, out_channel_offset, out_channels_total, act_lo, act_hi, false);
+}
+
+int pvhip_conv2d_pooled_f16(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, const float* bias,
+                            int act, int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
+    return conv2d_pooled_impl(x, wpack, y, n, c, h, w, k_out, bias, act, out_channel_offset, out_channels_total, act_lo, act_hi, true);
 }
 
 }  // extern "C"

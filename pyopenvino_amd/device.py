@@ -92,8 +92,10 @@ SIGNATURES = {
     'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),
     'pvhip_conv2d_pooled_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 5 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
+    'pvhip_conv2d_pooled_f16': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 5 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_multi_supported': (_c.c_int, [_c.c_int] * 8),
     'pvhip_conv2d_multi_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 12 + [_fp, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _c.c_void_p]),
+    'pvhip_conv2d_multi_f16_dma': (_c.c_int, [_fp, _fp] + [_c.c_int] * 12 + [_fp, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _c.c_void_p]),
     'pvhip_dwconv2d_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 12 + [_fp, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_detection_output_f32': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                               _c.c_float, _c.c_float, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),

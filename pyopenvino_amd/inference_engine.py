@@ -549,7 +549,7 @@ class Executable_Network:
         f16 = bool(getattr(self.ienet, 'f16_mfma', False))     # the f16-MFMA kernel fuses the epilogue and the Concat store only
         # A 3x3 / stride 1 / pad 1 MaxPool whose only consumer is a fused 1x1 convolution (pool -> pool_proj): the MaxPool is not
         # dispatched, the convolution reads the MaxPool's input and pools while it builds its input tile.
-        if not f16 and getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and os.environ.get('PVHIP_FUSE_POOLCONV', '1') != '0':
+        if (not f16 or os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0') and getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and os.environ.get('PVHIP_FUSE_POOLCONV', '1') != '0':
             for cid in list(self._fusion):
                 if G.nodes[cid]['type'] != 'Convolution':
                     continue
@@ -581,7 +581,7 @@ class Executable_Network:
         # 1x1, 3x3_reduce and 5x5_reduce arms of an inception module) are one launch of the first of them in schedule
         # order: the input is read once and every output-channel tile stores into the tensor of its own convolution
         # (Convolution.launch_siblings; each output has the bits of its own launch).
-        if not f16 and self.fuse_siblings and getattr(conv_plugin, 'SUPPORTS_SIBLINGS', False):
+        if (not f16 or os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0') and self.fuse_siblings and getattr(conv_plugin, 'SUPPORTS_SIBLINGS', False):
             position = {t: i for i, t in enumerate(self.task_list)}
             groups = {}
             for cid, f in self._fusion.items():

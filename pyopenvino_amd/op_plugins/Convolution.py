@@ -209,7 +209,7 @@ def pooled_fusable(node: dict, pool_node: dict) -> bool:
         return False
 
 
-def launch_pooled(node, x, w, bias=None, act=None, into=None):
+def launch_pooled(node, x, w, bias=None, act=None, into=None, f16=False):
     """conv1x1(maxpool3x3/s1/p1(x)) in one launch; arguments as launch()."""
     n, c, h, wd = x.shape
     kn = w.shape[0]
@@ -229,7 +229,9 @@ def launch_pooled(node, x, w, bias=None, act=None, into=None):
         ctotal = target.shape[1]
         assert target.shape[0] == n and tuple(target.shape[2:]) == (h, wd) and coff + kn <= ctotal
         y = dev.ChannelSlice(target, coff, kn)
-    dev.call('pvhip_conv2d_pooled_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), n, c, h, wd, kn,
+    if f16:
+        node['_hip_f16'] = 'MaxPool + 1x1'
+    dev.call('pvhip_conv2d_pooled_f16' if f16 else 'pvhip_conv2d_pooled_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), n, c, h, wd, kn,
              ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
     return y
 
@@ -285,7 +287,7 @@ def fused_panel(node: dict, ws, biases, h: int, wd: int):
     return packed
 
 
-def launch_siblings(node, x, members, strides, pads_begin, act):
+def launch_siblings(node, x, members, strides, pads_begin, act, f16=False):
     """members: [(weights, bias or None, into or None)], the node's own convolution first.  -> list of outputs."""
     n, c, h, wd = x.shape
     ws = [m[0] for m in members]
@@ -312,7 +314,11 @@ def launch_siblings(node, x, members, strides, pads_begin, act):
             outs.append(dev.ChannelSlice(target, coff, kn))
         keep.append(target)
         dests[i].y, dests[i].k, dests[i].channel_offset, dests[i].channels_total = target.ptr, kn, int(coff), int(ctotal)
-    dev.call('pvhip_conv2d_multi_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), n, c, h, wd, 1, 1, h, wd,
+    if f16:
+        node['_hip_f16'] = 'lds-dma, siblings'
+        for m in node.get('_siblings', []):
+            m['node']['_hip_f16'] = 'lds-dma, siblings'
+    dev.call('pvhip_conv2d_multi_f16_dma' if f16 else 'pvhip_conv2d_multi_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), n, c, h, wd, 1, 1, h, wd,
              strides[0], strides[1], pads_begin[0], pads_begin[1], ctypes.c_void_p(bias.ptr if bias is not None else 0),
              act_code, act_lo, act_hi, len(members), ctypes.cast(dests, ctypes.c_void_p))
     return outs
@@ -335,7 +341,17 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
     siblings = node.get('_siblings')
-    if node.get('_f16_mfma'):
+    if node.get('_f16_mfma') and siblings and dev.conv_f16_dma:
+        members = [(w, bias, node.get('_out_into'))]
+        for sib in siblings:
+            common_def.validate_inputs(sib['node'], sib['inputs'])
+            sb = sib.get('bias')
+            members.append((dev.as_device(sib['inputs'][1]), dev.as_device(sb) if sb is not None else None, sib.get('into')))
+        outs = launch_siblings(node, x, members, strides, pads_begin, node.get('_fuse_act'), f16=True)
+        y, node['_sibling_out'] = outs[0], outs[1:]
+    elif node.get('_f16_mfma') and node.get('_fuse_pool_in') is not None:
+        y = launch_pooled(node, x, w, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'), f16=True)
+    elif node.get('_f16_mfma'):
         y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'), f16=True)
     elif node.get('_fuse_pool_in') is not None:
         y = launch_pooled(node, x, w, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'))

@@ -1048,6 +1048,55 @@ def test_conv_f16_span_kernel_vs_oracle_and_the_other_f16_kernels(hip, monkeypat
     assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
 
 
+@pytest.mark.parametrize('xs,ks', [((3, 192, 28, 28), (64, 96, 16)), ((2, 512, 14, 14), (160, 112, 24)), ((5, 832, 7, 7), (384, 192, 48))])
+def test_f16_sibling_launch_and_pooled_launch_match_their_single_launches(hip, xs, ks):
+    """FP16 IRs: the 1x1 convolutions of an inception module as ONE launch of the f16 LDS-DMA form (pvhip_conv2d_multi_f16_dma) and
+    MaxPool + pool_proj as one launch (pvhip_conv2d_pooled_f16): the same operands rounded the same way, the same (r,s)-major order --
+    1e-5 from each member's own launch and from the oracle on fp16-rounded operands (the bits may differ: another channel tile)."""
+    from pyopenvino_amd import device as dev
+    plugin, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
+    x = rnd(11, xs)
+    data = conv_data((1, 1), (0, 0), (0, 0))
+    ws = [rnd(20 + i, (k, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5) for i, k in enumerate(ks)]
+    bs = [rnd(40 + i, (1, k, 1, 1), 0.1) for i, k in enumerate(ks)]
+    nodes = [make_node('Convolution', [x, w], data) for w in ws]
+    alone = []
+    for node, w, b in zip(nodes, ws, bs):
+        nd = dict(node)
+        nd['_f16_mfma'], nd['_fuse_bias'], nd['_fuse_act'] = True, dev.DeviceTensor.from_numpy(b), ('relu',)
+        alone.append(np.asarray(first_out(plugin.compute(nd, {0: x, 1: w}))))
+        want = np.maximum(first_out(oracle_plugin('Convolution').compute(node, {0: f16r(x), 1: f16r(w)}, kernel_type='special')) + b, 0)
+        assert_close(alone[-1], want, 1e-5, 'f16 conv {}'.format(w.shape))
+    wide = dev.DeviceTensor.from_numpy(np.full((xs[0], ks[0] + 7, xs[2], xs[3]), -1.0, dtype=np.float32))
+    lead = dict(nodes[0])
+    lead['_f16_mfma'], lead['_fuse_bias'], lead['_fuse_act'], lead['_out_into'] = True, dev.DeviceTensor.from_numpy(bs[0]), ('relu',), (wide, 3)
+    lead['_siblings'] = [{'node': n_, 'inputs': {0: x, 1: w}, 'bias': dev.DeviceTensor.from_numpy(b), 'into': None}
+                         for n_, w, b in zip(nodes[1:], ws[1:], bs[1:])]
+    plugin.compute(lead, {0: x, 1: ws[0]})
+    assert lead['_hip_f16'] == 'lds-dma, siblings'
+    got = [np.asarray(wide)[:, 3:3 + ks[0]]] + [np.asarray(t) for t in lead['_sibling_out']]
+    for g, a_, k in zip(got, alone, ks):
+        assert_close(np.ascontiguousarray(g), a_, 1e-5, 'f16 sibling with {} channels'.format(k))
+    rest = np.asarray(wide)
+    assert np.all(rest[:, :3] == -1.0) and np.all(rest[:, 3 + ks[0]:] == -1.0)
+    if xs[3] % 2 == 0:                       # MaxPool + pool_proj (even widths): against MaxPool, then the f16 convolution
+        k = ks[2] if ks[2] <= 128 else 64
+        w, b = ws[2][:k], bs[2][:, :k]
+        pnode = make_node('MaxPool', [x], pool_data((3, 3), (1, 1), (1, 1), (1, 1), 'ceil'))
+        pnode['output'][1]['dims'] = tuple(xs)
+        cnode = make_node('Convolution', [x, w], data)
+        assert plugin.pooled_fusable(cnode, pnode)
+        pooled = pool.compute(pnode, {0: x})[1]
+        two = dict(cnode)
+        two['_f16_mfma'], two['_fuse_bias'], two['_fuse_act'] = True, dev.DeviceTensor.from_numpy(b), ('relu',)
+        want = np.asarray(first_out(plugin.compute(two, {0: pooled, 1: w})))
+        one = dict(two)
+        one['_fuse_pool_in'] = pnode
+        got1 = np.asarray(first_out(plugin.compute(one, {0: x, 1: w})))
+        assert one['_hip_f16'] == 'MaxPool + 1x1'
+        assert_close(got1, want, 1e-5, 'f16 MaxPool + 1x1 {} k{}'.format(xs, k))
+
+
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
     """The reference's own FP16 node fixture (resources/node_args_6.pickle, replayed as test_node_sample.py:1-16 does; cropped)
     in float16 as the reference computes it: the f16-MFMA result is within fp16 tolerance of the reference's float16 output
