@@ -233,8 +233,9 @@ def extra_configs(blob=None):
                                 'accumulation, fp32 tensors in HBM; one synchronous infer() at a time',
                     'dtype': 'f16 operands / f32 accumulate', 'images_per_sec': round(rate, 1), 'ms_per_infer': round(ms, 3),
                     'convolution_ms': round(conv_ms, 3), 'convolution_TFLOPs_algorithmic': round(conv_fl / (conv_ms * 1e-3) / 1e12, 1),
-                    'note': 'first f16-MFMA kernel (one general implicit-GEMM form, register-staged fp32 -> fp16 gather): gather-bound, far from the '
-                            '2.5 PFLOP/s f16 MFMA peak'})
+                    'note': 'f16 forms of the LDS-DMA kernel (1x1 layers, the sibling launch, MaxPool + pool_proj; their device time is in '
+                            'convolution_ms) and the span kernel (3x3 / 5x5); conv1 on the register-staged gather kernel.  Latency- and '
+                            'traffic-bound (fp32 tensors in HBM), far from the 2.5 PFLOP/s f16 MFMA peak'})
     return out
 
 
