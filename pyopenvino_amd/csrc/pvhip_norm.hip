@@ -169,6 +169,7 @@ struct LrnPoolArgs {
     int   band_rows, n_bands;
     int   plane_l;               // floats per normalised plane in LDS
     float alpha, beta, bias;
+    int   abl;                   // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no LRN arithmetic, 2 no pooling, 4 no stores, 8 loads hit L2
 };
 
 template <int SIZE, int VEC, int BETA_MODE, int ST, int NI>     // NI: pooled outputs of a band and plane per lane (ceil(band_rows * ow / 256))
@@ -180,6 +181,11 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
     static_assert(2 * HALF <= T, "window halo must fit in one chunk");
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     extern __shared__ __attribute__((aligned(16))) float planes[];   // [T][plane_l]
+#ifdef PVHIP_DIAG
+    const int abl = a.abl;          // scripts/time_lrnpool_abl.py: parts switched off
+#else
+    constexpr int abl = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int img = (int)fdiv(blockIdx.x, d_bands), band = (int)blockIdx.x - img * a.n_bands;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
         vec_t o_;                                                                              \
         _Pragma("unroll") for (int v = 0; v < VEC; ++v) {                                      \
             const float d_ = a.bias + a.alpha * s_[v];                                         \
-            o_[v]          = lrn_div(ext[(j_) + HALF][v], d_, a.beta, beta_mode);              \
+            o_[v]          = (abl & 1) ? ext[(j_) + HALF][v] : lrn_div(ext[(j_) + HALF][v], d_, a.beta, beta_mode); \
         }                                                                                      \
         if (active) *reinterpret_cast<vec_t*>(mine + (slot_) * a.plane_l) = o_;                \
     }
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (!live[i]) continue;
+            if (!live[i] || (abl & 2)) continue;
             float* yo = yimg + (size_t)ch0 * ohw + outo[i];
             unsigned pb = 0u;
             for (int p = 0; p < n_pl; ++p, pb += plane_bytes, yo += ohw) {
@@ -261,7 +267,9 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
                     anynan = anynan | __builtin_isunordered(v0, v1) | (v2 != v2);
                 }
                 if (zpad[i]) m = fmaxf(m, 0.0f);
-                stnt(yo, anynan ? NAN : m);
+                // PLAIN stores: a lane writes one float per plane, 896-byte runs per plane and band -- nontemporal stores of such pieces
+                // cost 4 % here and 9 % in maxpool3x3_lrn_kernel (the dense 16-byte runs of the MaxPool kernel are the opposite case)
+                if (!(abl & 4)) *yo = anynan ? NAN : m;
             }
         }
         __syncthreads();
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
 #pragma unroll
     for (int j = 0; j < T; ++j) ext[2 * HALF + j] = ldnt(xv + (size_t)j * cstride);
     for (int k = 0; k + 1 < n_chunks; ++k) {
-        const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
+        const vec_t* __restrict__ xn = xv + (size_t)((abl & 8) ? 0 : (k + 1) * T) * cstride;        // abl 8: the first chunk again (L2 hits)
 #pragma unroll
         for (int j = 0; j < T; ++j) nxt[j] = ldnt(xn + (size_t)j * cstride);
         if (k == 0) {
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_kernel(LrnPoolArgs a, F
             float s_ = win[i_][0] * win[i_][0];                                                \
             _Pragma("unroll") for (int q = 1; q < SIZE; ++q) s_ = s_ + win[i_][q] * win[i_][q]; \
             const float d_ = a.bias + a.alpha * s_;                                            \
-            stnt(yimg + (size_t)((ch_) - HALF) * ohw + outo[i_], lrn_div(win[i_][HALF], d_, a.beta, beta_mode)); \
+            yimg[(size_t)((ch_) - HALF) * ohw + outo[i_]] = lrn_div(win[i_][HALF], d_, a.beta, beta_mode);   /* plain store: see lrn_maxpool3x3_kernel */ \
         }                                                                                      \
     }
 
@@ -571,6 +579,10 @@ int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, 
         return fail(PVHIP_EUNSUPPORTED, "pvhip_lrn_maxpool_f32: shape outside the fused kernel (ask pvhip_lrn_maxpool_supported first)");
     PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
     a.x = x; a.y = y; a.alpha = alpha; a.beta = beta; a.bias = bias;
+    a.abl = 0;
+#ifdef PVHIP_DIAG
+    a.abl = settings().conv_ablate;
+#endif
     const dim3 grid((unsigned)(n * a.n_bands));
     const FastDiv d_bands = make_fastdiv((unsigned)a.n_bands), d_ow = make_fastdiv((unsigned)ow);
     const int ni = (a.band_rows * ow + kBlock - 1) / kBlock;          // 1 at stride 2 (a band holds <= 1024 input pixels), up to 4 at stride 1
