@@ -125,7 +125,16 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     if pre_add is not None:
         pre_add = dev.as_device(pre_add)
         assert pre_add.size == c
-    if prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16) or pre_add is not None:
+    # which kernel forms the library offers for this geometry: asked once per node and settings (not on every launch)
+    route_key = (dev.settings_serial, x.shape, w.shape, tuple(strides), tuple(pads_begin), tuple(pads_end), bool(f16))
+    route = node.get('_hip_route')
+    if route is None or route[0] != route_key:
+        span_ok = f16 and dev.conv_f16_span >= (2 if kh == 1 else 1) and bool(dev.call(
+            'pvhip_conv2d_f16_span_supported', c, h, wd, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
+        route = (route_key, prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16), span_ok,
+                 f16 and not span_ok and dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw)))
+        node['_hip_route'] = route
+    if route[1] or pre_add is not None:
         # The zero-padded image (Convolution.py:64-66) as a tensor of its own, convolved WITHOUT padding: the gather of a layer whose
         # channel count is not a multiple of 16 (conv1: C = 3) then needs no window test -- zero vector instructions per gathered row
         # instead of five, and vector instructions are matrix time lost.  The pass costs less than the tests did.
@@ -134,9 +143,7 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
                  pads_end[0], pads_end[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
         x, h, wd, pads_begin, pads_end = xp, hp, wp, (0, 0), (0, 0)
     # FP16 IRs: layers with C % 16 == 0 run the f16 form of the LDS-DMA kernel on the fp32 panel (PVHIP_CONV_F16_DMA=0: the first f16 kernel)
-    f16_span = f16 and dev.conv_f16_span >= (2 if kh == 1 else 1) and bool(dev.call('pvhip_conv2d_f16_span_supported', c, h, wd, kh, kw, strides[0], strides[1],
-                                                            pads_begin[0], pads_begin[1], oh, ow))
-    f16_dma = f16 and not f16_span and dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
+    f16_span, f16_dma = route[2], route[3]
     if f16_span:
         wpack = packed_weights_f16_span(node, w)
     else:
