@@ -59,7 +59,7 @@ __device__ __forceinline__ void pc_load(pc_f2& d, __amdgpu_buffer_rsrc_t r, unsi
 // kF16 (FP16 IRs): the same tiles, a stage of 16 channels as ONE v_mfma_f32_32x32x16_f16 per 32-channel tile, both operands rounded to
 // fp16 as they are read from LDS (the maximum of the window is taken in fp32, then rounded: what MaxPool followed by pvhip_conv2d_f16_dma does)
 template <int BM, int VEC, bool kF16 = false>
-__global__ __launch_bounds__(512) void conv_pool1x1_kernel(PoolConvArgs a) {
+__global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(PoolConvArgs a) {      // 64 channels: 73 -> 64 registers, four workgroups per CU (3b: -3 %)
     constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
     constexpr int CONSUMERS = 4, PRODUCERS = 4;
     constexpr int A_PIECES = kBK * BM * 4 / 1024, A_PER_WAVE = (A_PIECES + CONSUMERS - 1) / CONSUMERS;
