@@ -36,6 +36,7 @@ struct PoolConvArgs {
     int   relu;
     float act_lo, act_hi;
     int y_ctotal, y_coff;
+    int abl;              // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no activation loads, 2 no pooling arithmetic, 4 no MFMAs, 8 no weight copies, 16 no stores
 };
 
 __device__ __forceinline__ void pc_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
@@ -83,6 +84,11 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
     const int ptile = lid / a.n_mtiles;
     const int m0    = mt * BM;
 
+#ifdef PVHIP_DIAG
+    const int abl = a.abl;          // scripts/time_poolconv_abl.py: parts switched off
+#else
+    constexpr int abl = 0;
+#endif
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -129,6 +135,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
         const int se_ = (s_) < nk ? (s_) : nk - 1;                 /* past the end: the last stage again (unused) */ \
         const unsigned soff = (unsigned)(se_ * kBK + (it_) * CSUB) * chan_bytes;                                 \
         _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
+            if (abl & 1) continue;                                                                               \
             pc_load(ring[it_][r], xr, offv[r], soff);                                                            \
             edge[it_][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offe[r], soff, 0));  \
         }                                                                                                        \
@@ -138,6 +145,11 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
         // fetch stage s_next_
 #define PVP_POOL(it_, buf_, s_next_)                                                                             \
     {                                                                                                            \
+        if (abl & 2) {                                                                                           \
+            *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = ring[it_][1];                     \
+            PVP_LOAD(it_, s_next_);                                                                              \
+            continue;                                                                                            \
+        }                                                                                                        \
         float cm_[VEC + 2];                                                                                      \
         int   cn_[VEC + 2];                                                                                      \
         _Pragma("unroll") for (int c = 0; c < VEC; ++c) {                                                        \
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
 #define PVP_LOAD_A(s_, buf_)                                                                                     \
     _Pragma("unroll") for (int q = 0; q < A_PER_WAVE; ++q)                                                       \
         if (A_PIECES % CONSUMERS == 0 || wid + CONSUMERS * q < A_PIECES)                                         \
-            pc_dma_b128(wr, &As[buf_][0][0] + (wid + CONSUMERS * q) * 256, avoff[q], (unsigned)(s_) * a_stage_bytes);
+            if (!(abl & 8)) pc_dma_b128(wr, &As[buf_][0][0] + (wid + CONSUMERS * q) * 256, avoff[q], (unsigned)(s_) * a_stage_bytes);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
                     bf[nxt] = Bs[buf][2 * (kk + 1) + lh][b_col];
                 }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur], acc[i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) if (!(abl & 4)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur], acc[i], 0, 0, 0);
                 if (kk + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, TM + 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
             }
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
-                if (row0 + dr < a.K) conv_store1(yp + (size_t)dr * HW, vv[r]);
+                if (row0 + dr < a.K && !(abl & 16)) conv_store1(yp + (size_t)dr * HW, vv[r]);
             }
         }
     }
@@ -307,6 +319,10 @@ static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int 
     a.relu = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
+    a.abl = 0;
+#ifdef PVHIP_DIAG
+    a.abl = settings().conv_ablate;
+#endif
     const int bm = k_out <= 32 ? 32 : (k_out <= 64 ? 64 : 128);
     a.n_mtiles = (k_out + bm - 1) / bm;
     const int n_ptiles = (a.P + 127) / 128;
