@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """GPU-box tool: random shapes through the kernels that have a slower twin -- the six-point Winograd kernel (3x3, 5x5; forced) against the
-direct kernel, MaxPool + 1x1 convolution / MaxPool + LRN / LRN + MaxPool as one launch against two.  python scripts/fuzz_kernels.py [cases] [seed]"""
+direct kernel, MaxPool + 1x1 convolution / MaxPool + LRN / LRN + MaxPool as one launch against two, the padding pass + test-free
+gather of the c-major kernel (with and without the Add folded in) against the window test in the gather, and the f16 kernels of an
+FP16 IR (span kernel, LDS-DMA form, the first gather kernel) against each other.  python scripts/fuzz_kernels.py [cases] [seed]"""
 import os, sys, random
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,12 +18,12 @@ def node(type_, ins, data):
             'input': {i: {'precision': 'I64' if a.dtype == np.int64 else 'FP32', 'dims': tuple(a.shape)} for i, a in enumerate(ins)},
             'output': {len(ins): {'precision': 'FP32', 'dims': ()}}}
 def setenv(env):
-    for k_ in ('PVHIP_CONV_WINOGRAD4', 'PVHIP_CONV_WINOGRAD5', 'PVHIP_CONV_WINOGRAD'): os.environ.pop(k_, None)
+    for k_ in ('PVHIP_CONV_WINOGRAD4', 'PVHIP_CONV_WINOGRAD5', 'PVHIP_CONV_WINOGRAD', 'PVHIP_CONV_PREPAD', 'PVHIP_CONV_F16_SPAN', 'PVHIP_CONV_F16_DMA'): os.environ.pop(k_, None)
     os.environ.update(env); dev.reload_settings()
 bad = 0
 compared = {}
 for i in range(cases):
-    kind = rng.choice(['w3', 'w5', 'poolconv', 'poollrn', 'lrnpool'])
+    kind = rng.choice(['w3', 'w5', 'poolconv', 'poollrn', 'lrnpool', 'prepad', 'f16'])
     n, h, w = rng.randint(1, 9), rng.randint(1, 30), rng.randint(1, 30)
     if kind in ('w3', 'w5'):
         ks = 3 if kind == 'w3' else 5
@@ -37,6 +39,45 @@ for i in range(cases):
         err = float(np.abs(outs[0] - outs[1]).max() / max(1e-20, np.abs(outs[1]).max()))
         ok = err < 5e-5
         what = '{}x{} conv x{} k{}: {:.1e}'.format(ks, ks, (n, c, h, w), k, err)
+    elif kind == 'prepad':            # c-major layers (C % 16 != 0) with padding: padding pass + test-free gather == window test in the gather, bit for bit
+        c, k, ks, st = rng.choice([1, 3, 5, 7, 24]), rng.randint(1, 80), rng.choice([3, 5, 7]), rng.choice([1, 2])
+        pb, pe = (rng.randint(0, ks // 2), rng.randint(0, ks // 2)), (rng.randint(0, ks // 2), rng.randint(0, ks // 2))
+        h, w = h + ks, w + ks
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w)) * 20.0
+        wt = (synth.normal(i, 3, k * c * ks * ks) * (2.0 / (c * ks * ks)) ** 0.5).astype(np.float32).reshape((k, c, ks, ks))
+        addc = synth.normal(i, 5, c).astype(np.float32).reshape((1, c, 1, 1)) * 50.0
+        b = dev.DeviceTensor.from_numpy(synth.normal(i, 4, k).astype(np.float32).reshape((1, k, 1, 1)))
+        outs = []
+        for env, pre in (({'PVHIP_CONV_PREPAD': '0'}, False), ({'PVHIP_CONV_PREPAD': '1'}, False), ({'PVHIP_CONV_PREPAD': '1'}, True)):
+            setenv(env)
+            nd = {'_pre_add': dev.DeviceTensor.from_numpy(addc)} if pre else {}
+            xin = dev.DeviceTensor.from_numpy((x + addc).astype(np.float32) if not pre else x)
+            outs.append(np.asarray(Convolution.launch(nd, xin, dev.DeviceTensor.from_numpy(wt), (st, st), pb, pe, 'explicit', bias=b, act=('relu',))))
+        setenv({})
+        # bit for bit where the plugin pads by itself (a c-major layer on the LDS-DMA kernel); a layer it would run on a Winograd kernel
+        # (C % 4 == 0, 3x3 / pad 1) is only handed a folded Add by this tool, never by plan_fusion: then 1e-5 of another kernel's sum
+        oh_, ow_ = outs[0].shape[2:]
+        if Convolution.prepad_wanted(n, c, h, w, k, ks, ks, oh_, ow_, (st, st), pb, pe):
+            ok = all(bool((o.view(np.uint32) == outs[0].view(np.uint32)).all()) for o in outs[1:])
+        else:
+            ok = bool((outs[1].view(np.uint32) == outs[0].view(np.uint32)).all()) and \
+                float(np.abs(outs[2] - outs[0]).max()) <= 1e-5 * max(1e-20, float(np.abs(outs[0]).max()))
+        what = 'padding pass {}x{} conv x{} k{} stride {} pads {} {}'.format(ks, ks, (n, c, h, w), k, st, pb, pe)
+    elif kind == 'f16':               # FP16 IRs: the three f16 kernels agree to 1e-5 (same operands, another summation order)
+        ks = rng.choice([1, 3, 5])
+        c, k = 16 * rng.randint(1, 10), rng.randint(1, 300)
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w))
+        wt = (synth.normal(i, 3, k * c * ks * ks) * (2.0 / (c * ks * ks)) ** 0.5).astype(np.float32).reshape((k, c, ks, ks))
+        b = dev.DeviceTensor.from_numpy(synth.normal(i, 4, k).astype(np.float32).reshape((1, k, 1, 1)))
+        outs = []
+        for env in ({'PVHIP_CONV_F16_SPAN': '2'}, {'PVHIP_CONV_F16_SPAN': '0'}, {'PVHIP_CONV_F16_SPAN': '0', 'PVHIP_CONV_F16_DMA': '0'}):
+            setenv(env)
+            outs.append(np.asarray(Convolution.launch({}, dev.DeviceTensor.from_numpy(x), dev.DeviceTensor.from_numpy(wt), (1, 1), (ks // 2,) * 2, (ks // 2,) * 2,
+                                                      'explicit', bias=b, act=('relu',), f16=True)))
+        setenv({})
+        err = max(float(np.abs(o - outs[2]).max() / max(1e-20, np.abs(outs[2]).max())) for o in outs[:2])
+        ok = err < 1e-5
+        what = 'f16 {}x{} conv x{} k{}: {:.1e}'.format(ks, ks, (n, c, h, w), k, err)
     elif kind == 'poolconv':
         c, k = 16 * rng.randint(1, 6), rng.randint(1, 128)
         w = 2 * rng.randint(1, 15)
