@@ -351,8 +351,10 @@ struct Pool3Plan {
     bool      stage;
 };
 
+// any_align: the caller's kernel copies from the 16-byte boundary below a band / group start and reads its LDS image shifted by the
+// remainder (dwconv3x3_cols_kernel), so starts need not be 16-byte aligned (odd widths, 150-wide rows)
 bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int oh, int ow, int st, int pt, int pl, int hp, int wp,
-                Pool3Plan& out) {
+                Pool3Plan& out, bool any_align = false) {
     if (pt > 2 || pl > 2 || (oh - 1) * st > pt + h - 1 || (ow - 1) * st > pl + w - 1) return false;   // clamped taps stay in their window
     if (ow > kBlock || hp < pt + h || wp < pl + w) return false;
     const int hw = h * w, ohw = oh * ow;
@@ -361,7 +363,7 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
     const bool stage = cfg.pool3_stage != 0;
     int G = cfg.pool3_g, S = cfg.pool3_s, band = cfg.pool3_band;
     const bool forced = G > 0 && S > 0 && band > 0;
-    const bool need4 = (hw % 4 != 0) || (ohw % 4 != 0);      // group starts must stay 16-byte aligned
+    const bool need4 = !any_align && ((hw % 4 != 0) || (ohw % 4 != 0));      // group starts must stay 16-byte aligned
     if (!forced) {
         double best = -1.0;
         const size_t row_b = (size_t)w * 4;
@@ -369,7 +371,7 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
             const int br = (oh + nb - 1) / nb;
             if ((oh + br - 1) / br != nb) continue;
             const int rows_in = (nb == 1) ? h : min(h, (br - 1) * st + 3);
-            if (nb > 1 && (w % 4 != 0)) break;                // band starts must be 16-byte aligned
+            if (nb > 1 && (w % 4 != 0) && !any_align) break;  // band starts must be 16-byte aligned
             const size_t plane_b = (size_t)rows_in * row_b;
             if (plane_b > 2 * budget) continue;
             const double halo_eff = (nb == 1) ? 1.0 : (double)(br * st) / (double)((br - 1) * st + 3);
@@ -377,13 +379,25 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
                 if (g > planes) break;
                 if (need4 && nb == 1 && (g % 4 != 0) && g != planes) continue;
                 if (need4 && nb > 1) continue;
+                // any_align (depthwise): the plan must fit as it is (two input buffers + the output stage in 64 KB: a stride-1 layer's
+                // output is as large as its input), and tiles whose outputs start on 16-byte boundaries are preferred
+                bool   fits = true;
+                double vec_eff = 1.0;
+                if (any_align) {
+                    const size_t in_f  = (nb == 1) ? (((size_t)g * hw + 3 + 255) & ~(size_t)255) : (size_t)g * (((size_t)rows_in * w + 3 + 255) & ~(size_t)255);
+                    const size_t out_f = (nb == 1) ? (size_t)g * ohw : (size_t)g * br * ow;
+                    fits = in_f * 8 + ((out_f + 3) & ~(size_t)3) * 4 <= 64 * 1024;
+                    const bool vec = (nb == 1) ? ((size_t)g * ohw % 4 == 0 || g == planes) : (ohw % 4 == 0 && (br * ow) % 4 == 0);
+                    vec_eff = vec ? 1.0 : 0.8;
+                }
+                if (!fits) break;
                 for (int s = 1; s <= 8 && s <= br; ++s) {
                     const int items = g * s * ow;
                     const int sr = (br + s - 1) / s;
                     const double util = (double)items / (double)(((items + kBlock - 1) / kBlock) * kBlock);
                     const double seg_eff = (double)br / (double)(s * sr) * ((double)(sr * st) / (double)(sr * st + 3 - st));
                     const double size_eff = (double)((size_t)g * plane_b) / (double)((size_t)g * plane_b + 2048);   // per-tile overhead
-                    const double sc = util * seg_eff * halo_eff * size_eff;
+                    const double sc = util * seg_eff * halo_eff * size_eff * vec_eff;
                     if (sc > best) { best = sc; G = g; S = s; band = br; }
                 }
             }
@@ -397,14 +411,15 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
     if (G > planes) G = planes;
     a.G = G; a.S = S; a.band_rows = band; a.n_bands = (oh + band - 1) / band;
     a.dense = (a.n_bands == 1);
-    if (!a.dense && (w % 4 != 0 || need4)) return false;
+    if (!a.dense && !any_align && (w % 4 != 0 || need4)) return false;
     if (a.dense && need4 && (G % 4 != 0) && G != planes) return false;
     const int rows_in = a.dense ? h : min(h, (band - 1) * st + 3);
-    a.plane_l     = a.dense ? hw : ((rows_in * w + 255) & ~255);
-    a.in_floats   = a.dense ? ((G * hw + 255) & ~255) : G * a.plane_l;
+    const int slack = any_align ? 3 : 0;               // the copy starts up to three floats below the first one
+    a.plane_l     = a.dense ? hw : ((rows_in * w + slack + 255) & ~255);
+    a.in_floats   = a.dense ? ((G * hw + slack + 255) & ~255) : G * a.plane_l;
     a.out_plane_l = a.dense ? ohw : band * ow;
     a.n_tiles     = ((planes + G - 1) / G) * a.n_bands;
-    a.vec_out     = a.dense ? 1 : ((ohw % 4 == 0) && ((band * ow) % 4 == 0));
+    a.vec_out     = a.dense ? (((size_t)G * ohw % 4 == 0 || G == planes) ? 1 : 0) : ((ohw % 4 == 0) && ((band * ow) % 4 == 0));
     const size_t out_b = stage ? (size_t)((G * a.out_plane_l + 3) & ~3) * 4 : 0;
     out.lds = (size_t)a.in_floats * 8 + out_b;
     if (out.lds > 64 * 1024 || G * S * ow <= 0) return false;
@@ -420,11 +435,11 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
 
 // The search above costs tens of microseconds; a forward pass asks for the same few shapes over and over.
 bool plan_pool3(const float* x, float* y, int planes, int h, int w, int oh, int ow, int st, int pt, int pl, int hp, int wp,
-                Pool3Plan& out) {
+                Pool3Plan& out, bool any_align = false) {
     if (!settings().pool3) return false;
-    struct Entry { int key[11]; bool ok; Pool3Plan plan; };
+    struct Entry { int key[12]; bool ok; Pool3Plan plan; };
     static std::vector<Entry> cache;
-    const int key[11] = {planes, h, w, oh, ow, st, pt, pl, hp, wp, settings().generation};
+    const int key[12] = {planes, h, w, oh, ow, st, pt, pl, hp, wp, settings().generation, any_align ? 1 : 0};
     for (const Entry& e : cache)
         if (memcmp(e.key, key, sizeof key) == 0) {
             if (!e.ok) return false;
@@ -433,7 +448,7 @@ bool plan_pool3(const float* x, float* y, int planes, int h, int w, int oh, int 
         }
     Entry e;
     memcpy(e.key, key, sizeof key);
-    e.ok = plan_pool3_search(x, y, planes, h, w, oh, ow, st, pt, pl, hp, wp, e.plan);
+    e.ok = plan_pool3_search(x, y, planes, h, w, oh, ow, st, pt, pl, hp, wp, e.plan, any_align);
     if (settings().pool3_verbose)
         fprintf(stderr, "pool3 planes=%d %dx%d->%dx%d s%d: %s G=%d S=%d band=%d bands=%d tiles=%d lds=%zu grid=%d\n", planes, h, w, oh, ow, st,
                 e.ok ? "ok" : "fallback", e.plan.a.G, e.plan.a.S, e.plan.a.band_rows, e.plan.a.n_bands, e.plan.a.n_tiles, e.plan.lds, e.plan.grid);
@@ -609,6 +624,141 @@ __global__ __launch_bounds__(kBlock) void dwconv2d_lds_kernel(const float* __res
         if (ep.act == 1) sum = (sum < 0.0f) ? 0.0f : sum;
         else if (ep.act == 2) { sum = (sum < ep.lo) ? ep.lo : sum; sum = (sum > ep.hi) ? ep.hi : sum; }
         yout[o] = sum;
+    }
+}
+
+// Depthwise 3x3 (stride 1 or 2) on the STRUCTURE of maxpool3x3_cols_kernel (same planner, same tiles): persistent grid, the dense input
+// of tile t + 1 arrives by LDS-DMA (nontemporal, 16 bytes per lane) while tile t is computed; a lane owns one output COLUMN of a row
+// segment and slides down it with the last rows' three taps in registers (stride 1: three LDS reads per output instead of nine, and
+// no LDS reads for the weights: the nine weights of the lane's plane sit in registers; a tap in the padding reads as 0.0);
+// outputs meet in LDS and leave as dense 16-byte nontemporal runs.  The one-shot kernel above zeroes a padded LDS image, fills it
+// through registers with three divisions per 16 bytes, reads 18 LDS words per output and stores 4 bytes per lane: 2.3-3.5 TB/s on the
+// MobileNet layers.  Same products in the same order (ky, then kx; a padded tap is 0 * w): the same bits.
+template <int ST, bool NT>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(Pool3Args a, Pool3Divs dv, const float* __restrict__ wts, int channels,
+                                                                 DwEpilogue ep) {
+    extern __shared__ __attribute__((aligned(1024))) float lds3[];
+    float* const outb = lds3 + 2 * a.in_floats;
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)(tid & 63) * 16u;
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+
+    // Input of tile t -> buffer `dst`.  A copy starts at the 16-byte boundary at or below its first float (a 150- or 75-wide row, a
+    // 5625-float plane do not start on one); the image in LDS is then shifted by the remainder, which the reads add back.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)(a.x_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)a.x_bytes), 0x00020000);
+    auto issue = [&](int t, float* dst) {
+        const int pg = (int)fdiv((unsigned)t, dv.bands), b = t - pg * a.n_bands;
+        const int g0 = pg * a.G, gn = min(a.G, a.n_planes - g0);
+        const int oy0 = b * a.band_rows, oy1 = min(a.oh, oy0 + a.band_rows);
+        const int iy_lo = max(0, oy0 * ST - a.pt), iy_hi = min(a.h, (oy1 - 1) * ST + 3 - a.pt);
+        if (a.dense) {
+            const size_t src = (size_t)g0 * hw;                              // floats
+            const int    sh  = (int)(src & 3);
+            const int pieces = (gn * hw + sh + 255) >> 8;
+            for (int q = wave; q < pieces; q += 4) pool_dma_b128<NT>(xr, dst + q * 256, lane16 + (unsigned)((src - sh) * 4) + (unsigned)q * 1024u, 0u);      // whole offset in the vector offset: range-checked
+        } else {
+            for (int p = 0; p < gn; ++p) {
+                const size_t src = (size_t)(g0 + p) * hw + (size_t)iy_lo * a.w;
+                const int    sh  = (int)(src & 3);
+                const int    ppp = ((iy_hi - iy_lo) * a.w + sh + 255) >> 8;   // pieces of this plane's band
+                for (int q = wave; q < ppp; q += 4)
+                    pool_dma_b128<NT>(xr, dst + p * a.plane_l + q * 256, lane16 + (unsigned)((src - sh) * 4) + (unsigned)q * 1024u, 0u);
+            }
+        }
+    };
+
+    int t = blockIdx.x, cur = 0;
+    if (t < a.n_tiles) issue(t, lds3);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        pool_dma_wait();
+        __syncthreads();          // tile t has landed; every wave is done with the other buffer and with the output stage
+        {
+            const int tn = t + (int)gridDim.x;
+            if (tn < a.n_tiles) issue(tn, lds3 + (cur ^ 1) * a.in_floats);
+        }
+        const float* const in = lds3 + cur * a.in_floats;
+        const int pg = (int)fdiv((unsigned)t, dv.bands), b = t - pg * a.n_bands;
+        const int g0 = pg * a.G, gn = min(a.G, a.n_planes - g0);
+        const int oy0 = b * a.band_rows, oy1 = min(a.oh, oy0 + a.band_rows);
+        const int iy_lo = max(0, oy0 * ST - a.pt);
+        const int rows_t = oy1 - oy0;
+        const int seg_rows = (rows_t + a.S - 1) / a.S;
+        const int n_items = gn * a.S * a.ow;
+        const int sow = a.S * a.ow;
+        for (int it = tid; it < n_items; it += kBlock) {
+            const unsigned p = fdiv((unsigned)it, dv.sow), rem = (unsigned)it - p * (unsigned)sow;
+            const unsigned seg = fdiv(rem, dv.ow), ox = rem - seg * (unsigned)a.ow;
+            const int ys = oy0 + (int)seg * seg_rows, ye = min(oy1, ys + seg_rows);
+            if (ys >= oy1) continue;                                          // trailing segment of a short band
+            const int px0 = (int)ox * ST - a.pl;
+            const int c0 = min(max(px0, 0), a.w - 1), c1 = min(max(px0 + 1, 0), a.w - 1), c2 = min(max(px0 + 2, 0), a.w - 1);
+            // the plane's nine weights in registers; a tap in the padding reads as 0.0 (the VALUE is masked, as in the reference's padded
+            // image: 0 * w -- masking the weight instead would turn an infinite neighbour into NaN)
+            const int ch = (g0 + (int)p) % channels;
+            const bool m0 = (unsigned)px0 < (unsigned)a.w, m1 = (unsigned)(px0 + 1) < (unsigned)a.w, m2 = (unsigned)(px0 + 2) < (unsigned)a.w;
+            float wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = wts[ch * 9 + k];
+            const float bv = ep.bias != nullptr ? ep.bias[ch] : -0.0f;
+            // input row iy of this plane at L + iy * w (the copy started `shift` floats below the band)
+            const int shift = a.dense ? (int)(((size_t)g0 * hw) & 3) : (int)(((size_t)(g0 + (int)p) * hw + (size_t)iy_lo * a.w) & 3);
+            const float* const L = in + (int)p * a.plane_l + shift - iy_lo * a.w;
+            // the three taps of input row IY (zeros for a row in the padding)
+#define PV_DROW(IY, V0, V1, V2)                                                               \
+    do {                                                                                      \
+        const int    iy_ = (IY);                                                              \
+        const bool   ok_ = (unsigned)iy_ < (unsigned)a.h;                                     \
+        const float* q_  = L + min(max(iy_, 0), a.h - 1) * a.w;                               \
+        V0 = (ok_ && m0) ? q_[c0] : 0.0f; V1 = (ok_ && m1) ? q_[c1] : 0.0f; V2 = (ok_ && m2) ? q_[c2] : 0.0f; \
+    } while (0)
+            float a0, a1, a2, b0, b1, b2, c0v, c1v, c2v;
+            PV_DROW(ys * ST - a.pt, a0, a1, a2);
+            if (ST == 1) PV_DROW(ys - a.pt + 1, b0, b1, b2);
+            float* const yo = outb + (int)p * a.out_plane_l + (ys - oy0) * a.ow + (int)ox;
+            for (int oy = ys; oy < ye; ++oy) {
+                if (ST == 2) PV_DROW(oy * 2 - a.pt + 1, b0, b1, b2);
+                PV_DROW(oy * ST - a.pt + 2, c0v, c1v, c2v);
+                float sum = 0.0f;
+                sum += a0 * wk[0]; sum += a1 * wk[1]; sum += a2 * wk[2];
+                sum += b0 * wk[3]; sum += b1 * wk[4]; sum += b2 * wk[5];
+                sum += c0v * wk[6]; sum += c1v * wk[7]; sum += c2v * wk[8];
+                sum = sum + bv;
+                if (ep.act == 1) sum = (sum < 0.0f) ? 0.0f : sum;
+                else if (ep.act == 2) { sum = (sum < ep.lo) ? ep.lo : sum; sum = (sum > ep.hi) ? ep.hi : sum; }
+                yo[(oy - ys) * a.ow] = sum;
+                if (ST == 1) { a0 = b0; a1 = b1; a2 = b2; b0 = c0v; b1 = c1v; b2 = c2v; }
+                else         { a0 = c0v; a1 = c1v; a2 = c2v; }
+            }
+#undef PV_DROW
+        }
+        __syncthreads();
+        if (a.dense) {
+            const int n_out = gn * ohw;
+            float* const yd = a.y + (size_t)g0 * ohw;
+            if (a.vec_out) {
+                const int n4 = n_out >> 2;
+                for (int i = tid; i < n4; i += kBlock) pool_st4<NT>(yd + 4 * i, outb + 4 * i);
+                for (int i = (n4 << 2) + tid; i < n_out; i += kBlock) pool_st1<NT>(yd + i, outb[i]);
+            } else {
+                for (int i = tid; i < n_out; i += kBlock) pool_st1<NT>(yd + i, outb[i]);
+            }
+        } else {
+            const int run = rows_t * a.ow;
+            for (int p = 0; p < gn; ++p) {
+                float* const       yd = a.y + (size_t)(g0 + p) * ohw + (size_t)oy0 * a.ow;
+                const float* const so = outb + p * a.out_plane_l;
+                if (a.vec_out) {
+                    const int n4 = run >> 2;
+                    for (int i = tid; i < n4; i += kBlock) pool_st4<NT>(yd + 4 * i, so + 4 * i);
+                    for (int i = (n4 << 2) + tid; i < run; i += kBlock) pool_st1<NT>(yd + i, so[i]);
+                } else {
+                    for (int i = tid; i < run; i += kBlock) pool_st1<NT>(yd + i, so[i]);
+                }
+            }
+        }
+        cur ^= 1;
     }
 }
 
@@ -790,6 +940,26 @@ int pvhip_dwconv2d_f32(const float* x, const float* w, float* y, int n, int g, i
     int hp = (oh - 1) * sh + kh, wp = (ow - 1) * sw + kw;
     if (hp < h + pad_top) hp = h + pad_top;
     if (wp < wdt + pad_left) wp = wdt + pad_left;
+    // 3x3, stride 1 or 2: the pipelined kernel on the MaxPool kernel's tiles (PVHIP_DWCONV_COLS=0: the one-shot LDS kernel)
+    if (kh == 3 && kw == 3 && sh == sw && (sh == 1 || sh == 2) && settings().dwconv_cols) {
+        Pool3Plan plan;
+        // (bands of odd-width planes -- MobileNet's 75x75 layers -- start on no boundary at all and run 20-50 % slower here than on the
+        // one-shot kernel: 0.335 / 0.242 against 0.285 / 0.157 ms)
+        if (plan_pool3(x, y, n * g, h, wdt, oh, ow, sh, pad_top, pad_left, hp, wp, plan, true) && plan.stage && !(plan.a.n_bands > 1 && (wdt & 1))) {
+            const Pool3Divs dv3{make_fastdiv((unsigned)plan.a.n_bands), make_fastdiv((unsigned)(plan.a.S * ow)), make_fastdiv((unsigned)ow)};
+            const int  ntm = settings().stream_nt;
+            const bool nt  = ntm == 2 || (ntm == 1 && (size_t)n * g * ((size_t)h * wdt + (size_t)oh * ow) * 4 >= ((size_t)64 << 20));
+            if (sh == 1) {
+                if (nt) hipLaunchKernelGGL((dwconv3x3_cols_kernel<1, true>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
+                else    hipLaunchKernelGGL((dwconv3x3_cols_kernel<1, false>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
+            } else {
+                if (nt) hipLaunchKernelGGL((dwconv3x3_cols_kernel<2, true>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
+                else    hipLaunchKernelGGL((dwconv3x3_cols_kernel<2, false>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
+            }
+            PVHIP_LAUNCH_CHECK();
+            return PVHIP_OK;
+        }
+    }
     PoolArgs a{n * g, h, wdt, oh, ow, kh, kw, sh, sw, pad_top, pad_left, hp, wp};
     const size_t group_bytes = 16 * 1024;
     const size_t row_bytes   = (size_t)wp * sizeof(float);

@@ -876,6 +876,34 @@ def test_depthwise_conv_vs_oracle(hip, xs, st, pb, pe):
     vs_oracle('GroupConvolution', [rnd(sum(xs), xs), w], conv_data(st, pb, pe, 'same_upper'))
 
 
+def test_depthwise_pipelined_kernel_has_the_bits_of_the_one_shot_kernel(hip, monkeypatch):
+    """dwconv3x3_cols_kernel (3x3, stride 1 / 2: persistent, LDS-DMA, weights in registers) against dwconv2d_lds_kernel
+    (PVHIP_DWCONV_COLS=0): the same products in the same order -- bit for bit, with bias + ReLU / Clamp fused, on MobileNet's
+    extents, odd extents, several images, asymmetric padding, and with infinities on the border (a padded tap is 0 * w, not inf * 0)."""
+    from pyopenvino_amd import device as dev
+    cases = [((2, 32, 150, 150), (1, 1), (1, 1), (1, 1)), ((2, 64, 150, 150), (2, 2), (0, 0), (1, 1)), ((3, 128, 75, 75), (1, 1), (1, 1), (1, 1)),
+             ((2, 128, 75, 75), (2, 2), (1, 1), (1, 1)), ((3, 512, 19, 19), (2, 2), (1, 1), (1, 1)), ((2, 1024, 10, 10), (1, 1), (1, 1), (1, 1)),
+             ((1, 8, 7, 13), (1, 1), (1, 1), (1, 1)), ((5, 3, 9, 9), (2, 2), (0, 0), (1, 1)), ((1, 4, 3, 3), (1, 1), (1, 1), (1, 1)),
+             ((2, 16, 38, 38), (1, 1), (0, 0), (0, 0))]
+    for xs, st, pb, pe in cases:
+        x = rnd(sum(xs), xs, 3.0)
+        x[0, 0, 0, :] = np.inf
+        x[-1, -1, :, -1] = -np.inf
+        w, b = rnd(7, (xs[1], 1, 1, 3, 3), 0.4), rnd(8, (1, xs[1], 1, 1))
+        for act in (None, ('relu',), ('clamp', 0.0, 6.0)):
+            outs = {}
+            for mode in ('1', '0'):
+                helpers.setenv(monkeypatch, 'PVHIP_DWCONV_COLS', mode)
+                dev.reload_settings()
+                node = make_node('GroupConvolution', [x, w], conv_data(st, pb, pe, 'explicit'))
+                if act is not None:
+                    node['_fuse_bias'], node['_fuse_act'] = dev.DeviceTensor.from_numpy(b), act
+                outs[mode] = np.asarray(first_out(hip_plugin('GroupConvolution').compute(node, {0: x, 1: w})))
+            assert_bit_exact(outs['1'], outs['0'], 'depthwise {} stride {} pads {} {} act {}'.format(xs, st, pb, pe, act))
+    monkeypatch.delenv('PVHIP_DWCONV_COLS', raising=False)
+    dev.reload_settings()
+
+
 def test_hipgraph_capture_and_replay(hip):
     """pvhip_graph_*: a short sequence of launches captured once on the compute stream and replayed on new input
     contents gives what the eager launches give (the buffers are fixed, as a captured forward pass requires)."""
