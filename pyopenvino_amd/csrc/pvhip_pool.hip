@@ -247,12 +247,14 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_cols_kernel(Pool3Args a, Po
             const_cast<float*>(a.x + src), 0, (int)(left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)left), 0x00020000);
         if (a.dense) {
             const int pieces = (gn * hw + 255) >> 8;
-            for (int q = wave; q < pieces; q += 4) pool_dma_b128<NT>(r, dst + q * 256, lane16, (unsigned)q * 1024u);
+            // (the whole offset rides in the VECTOR offset: the scalar one is not range-checked, and the last pieces of the last tile reach
+            // past the tensor -- they must read zeros, not the bytes behind the allocation)
+            for (int q = wave; q < pieces; q += 4) pool_dma_b128<NT>(r, dst + q * 256, lane16 + (unsigned)q * 1024u, 0u);
         } else {
             const int ppp = ((iy_hi - iy_lo) * a.w + 255) >> 8;               // pieces per plane
             for (int p = 0; p < gn; ++p)
                 for (int q = wave; q < ppp; q += 4)
-                    pool_dma_b128<NT>(r, dst + p * a.plane_l + q * 256, lane16, (unsigned)(p * hw) * 4u + (unsigned)q * 1024u);
+                    pool_dma_b128<NT>(r, dst + p * a.plane_l + q * 256, lane16 + (unsigned)(p * hw) * 4u + (unsigned)q * 1024u, 0u);
         }
     };
 
