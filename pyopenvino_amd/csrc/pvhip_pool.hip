@@ -356,13 +356,13 @@ struct Pool3Plan {
 // any_align: the caller's kernel copies from the 16-byte boundary below a band / group start and reads its LDS image shifted by the
 // remainder (dwconv3x3_cols_kernel), so starts need not be 16-byte aligned (odd widths, 150-wide rows)
 bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int oh, int ow, int st, int pt, int pl, int hp, int wp,
-                Pool3Plan& out, bool any_align = false) {
+                Pool3Plan& out, bool any_align = false, int stage_override = -1) {
     if (pt > 2 || pl > 2 || (oh - 1) * st > pt + h - 1 || (ow - 1) * st > pl + w - 1) return false;   // clamped taps stay in their window
     if (ow > kBlock || hp < pt + h || wp < pl + w) return false;
     const int hw = h * w, ohw = oh * ow;
     const Settings& cfg = settings();                   // PVHIP_POOL3_KB / _STAGE / _CFG / _WG: tuning runs only
     const size_t budget = (size_t)cfg.pool3_kb * 1024;
-    const bool stage = cfg.pool3_stage != 0;
+    const bool stage = stage_override >= 0 ? stage_override != 0 : cfg.pool3_stage != 0;
     int G = cfg.pool3_g, S = cfg.pool3_s, band = cfg.pool3_band;
     const bool forced = G > 0 && S > 0 && band > 0;
     const bool need4 = !any_align && ((hw % 4 != 0) || (ohw % 4 != 0));      // group starts must stay 16-byte aligned
@@ -388,9 +388,10 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
                 if (any_align) {
                     const size_t in_f  = (nb == 1) ? (((size_t)g * hw + 3 + 255) & ~(size_t)255) : (size_t)g * (((size_t)rows_in * w + 3 + 255) & ~(size_t)255);
                     const size_t out_f = (nb == 1) ? (size_t)g * ohw : (size_t)g * br * ow;
-                    fits = in_f * 8 + ((out_f + 3) & ~(size_t)3) * 4 <= 64 * 1024;
+                    fits = in_f * 8 + (stage ? ((out_f + 3) & ~(size_t)3) * 4 : 0) <= 64 * 1024;
                     const bool vec = (nb == 1) ? ((size_t)g * ohw % 4 == 0 || g == planes) : (ohw % 4 == 0 && (br * ow) % 4 == 0);
                     vec_eff = vec ? 1.0 : 0.8;
+                    if (nb > 1 && (w & 1)) vec_eff *= 0.6;       // bands of odd-width planes start on no boundary at all (measured: slow)
                 }
                 if (!fits) break;
                 for (int s = 1; s <= 8 && s <= br; ++s) {
@@ -437,11 +438,11 @@ bool plan_pool3_search(const float* x, float* y, int planes, int h, int w, int o
 
 // The search above costs tens of microseconds; a forward pass asks for the same few shapes over and over.
 bool plan_pool3(const float* x, float* y, int planes, int h, int w, int oh, int ow, int st, int pt, int pl, int hp, int wp,
-                Pool3Plan& out, bool any_align = false) {
+                Pool3Plan& out, bool any_align = false, int stage_override = -1) {
     if (!settings().pool3) return false;
     struct Entry { int key[12]; bool ok; Pool3Plan plan; };
     static std::vector<Entry> cache;
-    const int key[12] = {planes, h, w, oh, ow, st, pt, pl, hp, wp, settings().generation, any_align ? 1 : 0};
+    const int key[12] = {planes, h, w, oh, ow, st, pt, pl, hp, wp, settings().generation, (any_align ? 1 : 0) + 2 * (stage_override + 1)};
     for (const Entry& e : cache)
         if (memcmp(e.key, key, sizeof key) == 0) {
             if (!e.ok) return false;
@@ -450,7 +451,7 @@ bool plan_pool3(const float* x, float* y, int planes, int h, int w, int oh, int 
         }
     Entry e;
     memcpy(e.key, key, sizeof key);
-    e.ok = plan_pool3_search(x, y, planes, h, w, oh, ow, st, pt, pl, hp, wp, e.plan, any_align);
+    e.ok = plan_pool3_search(x, y, planes, h, w, oh, ow, st, pt, pl, hp, wp, e.plan, any_align, stage_override);
     if (settings().pool3_verbose)
         fprintf(stderr, "pool3 planes=%d %dx%d->%dx%d s%d: %s G=%d S=%d band=%d bands=%d tiles=%d lds=%zu grid=%d\n", planes, h, w, oh, ow, st,
                 e.ok ? "ok" : "fallback", e.plan.a.G, e.plan.a.S, e.plan.a.band_rows, e.plan.a.n_bands, e.plan.a.n_tiles, e.plan.lds, e.plan.grid);
@@ -636,7 +637,8 @@ __global__ __launch_bounds__(kBlock) void dwconv2d_lds_kernel(const float* __res
 // outputs meet in LDS and leave as dense 16-byte nontemporal runs.  The one-shot kernel above zeroes a padded LDS image, fills it
 // through registers with three divisions per 16 bytes, reads 18 LDS words per output and stores 4 bytes per lane: 2.3-3.5 TB/s on the
 // MobileNet layers.  Same products in the same order (ky, then kx; a padded tap is 0 * w): the same bits.
-template <int ST, bool NT>
+// STAGE = false (stride-1 layers whose planes fill LDS twice over as it is: MobileNet's 75x75): a lane stores its outputs itself
+template <int ST, bool NT, bool STAGE = true>
 __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(Pool3Args a, Pool3Divs dv, const float* __restrict__ wts, int channels,
                                                                  DwEpilogue ep) {
     extern __shared__ __attribute__((aligned(1024))) float lds3[];
@@ -718,7 +720,8 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(Pool3Args a, Poo
             float a0, a1, a2, b0, b1, b2, c0v, c1v, c2v;
             PV_DROW(ys * ST - a.pt, a0, a1, a2);
             if (ST == 1) PV_DROW(ys - a.pt + 1, b0, b1, b2);
-            float* const yo = outb + (int)p * a.out_plane_l + (ys - oy0) * a.ow + (int)ox;
+            float* const yo = STAGE ? outb + (int)p * a.out_plane_l + (ys - oy0) * a.ow + (int)ox
+                                    : a.y + (size_t)(g0 + (int)p) * ohw + (size_t)ys * a.ow + ox;
             for (int oy = ys; oy < ye; ++oy) {
                 if (ST == 2) PV_DROW(oy * 2 - a.pt + 1, b0, b1, b2);
                 PV_DROW(oy * ST - a.pt + 2, c0v, c1v, c2v);
@@ -735,6 +738,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(Pool3Args a, Poo
             }
 #undef PV_DROW
         }
+        if (STAGE) {
         __syncthreads();
         if (a.dense) {
             const int n_out = gn * ohw;
@@ -759,6 +763,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(Pool3Args a, Poo
                     for (int i = tid; i < run; i += kBlock) pool_st1<NT>(yd + i, so[i]);
                 }
             }
+        }
         }
         cur ^= 1;
     }
@@ -945,19 +950,25 @@ int pvhip_dwconv2d_f32(const float* x, const float* w, float* y, int n, int g, i
     // 3x3, stride 1 or 2: the pipelined kernel on the MaxPool kernel's tiles (PVHIP_DWCONV_COLS=0: the one-shot LDS kernel)
     if (kh == 3 && kw == 3 && sh == sw && (sh == 1 || sh == 2) && settings().dwconv_cols) {
         Pool3Plan plan;
-        // (bands of odd-width planes -- MobileNet's 75x75 layers -- start on no boundary at all and run 20-50 % slower here than on the
-        // one-shot kernel: 0.335 / 0.242 against 0.285 / 0.157 ms)
-        if (plan_pool3(x, y, n * g, h, wdt, oh, ow, sh, pad_top, pad_left, hp, wp, plan, true) && plan.stage && !(plan.a.n_bands > 1 && (wdt & 1))) {
+        // The lanes store their outputs themselves (PVHIP_DWCONV_COLS=2: through the MaxPool kernel's output stage in LDS, measured
+        // slower on every MobileNet layer: 1.32 against 1.16 ms over the 13 -- the stage costs LDS, i.e. halo rows and resident tiles).
+        // (bands of odd-width planes start on no boundary at all and ran 20 % slower than the one-shot kernel; MobileNet's 75x75
+        // planes fit whole)
+        const bool ok = plan_pool3(x, y, n * g, h, wdt, oh, ow, sh, pad_top, pad_left, hp, wp, plan, true, settings().dwconv_cols == 2 ? 1 : 0) &&
+                        !(plan.a.n_bands > 1 && (wdt & 1));
+        if (ok) {
             const Pool3Divs dv3{make_fastdiv((unsigned)plan.a.n_bands), make_fastdiv((unsigned)(plan.a.S * ow)), make_fastdiv((unsigned)ow)};
             const int  ntm = settings().stream_nt;
             const bool nt  = ntm == 2 || (ntm == 1 && (size_t)n * g * ((size_t)h * wdt + (size_t)oh * ow) * 4 >= ((size_t)64 << 20));
-            if (sh == 1) {
-                if (nt) hipLaunchKernelGGL((dwconv3x3_cols_kernel<1, true>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
-                else    hipLaunchKernelGGL((dwconv3x3_cols_kernel<1, false>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
-            } else {
-                if (nt) hipLaunchKernelGGL((dwconv3x3_cols_kernel<2, true>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
-                else    hipLaunchKernelGGL((dwconv3x3_cols_kernel<2, false>), dim3(plan.grid), dim3(kBlock), plan.lds, state().stream, plan.a, dv3, w, g, ep);
-            }
+            const dim3 g3(plan.grid), b3(kBlock);
+#define PV_DW(ST_, NT_)                                                                                                       \
+    {                                                                                                                         \
+        if (plan.stage) hipLaunchKernelGGL((dwconv3x3_cols_kernel<ST_, NT_, true>), g3, b3, plan.lds, state().stream, plan.a, dv3, w, g, ep);  \
+        else            hipLaunchKernelGGL((dwconv3x3_cols_kernel<ST_, NT_, false>), g3, b3, plan.lds, state().stream, plan.a, dv3, w, g, ep); \
+    }
+            if (sh == 1) { if (nt) PV_DW(1, true) else PV_DW(1, false) }
+            else         { if (nt) PV_DW(2, true) else PV_DW(2, false) }
+#undef PV_DW
             PVHIP_LAUNCH_CHECK();
             return PVHIP_OK;
         }

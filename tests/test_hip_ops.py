@@ -892,14 +892,15 @@ def test_depthwise_pipelined_kernel_has_the_bits_of_the_one_shot_kernel(hip, mon
         w, b = rnd(7, (xs[1], 1, 1, 3, 3), 0.4), rnd(8, (1, xs[1], 1, 1))
         for act in (None, ('relu',), ('clamp', 0.0, 6.0)):
             outs = {}
-            for mode in ('1', '0'):
+            for mode in ('1', '2', '0'):                     # lanes store their outputs / through an output stage in LDS / one-shot
                 helpers.setenv(monkeypatch, 'PVHIP_DWCONV_COLS', mode)
                 dev.reload_settings()
                 node = make_node('GroupConvolution', [x, w], conv_data(st, pb, pe, 'explicit'))
                 if act is not None:
                     node['_fuse_bias'], node['_fuse_act'] = dev.DeviceTensor.from_numpy(b), act
                 outs[mode] = np.asarray(first_out(hip_plugin('GroupConvolution').compute(node, {0: x, 1: w})))
-            assert_bit_exact(outs['1'], outs['0'], 'depthwise {} stride {} pads {} {} act {}'.format(xs, st, pb, pe, act))
+            for mode in ('1', '2'):
+                assert_bit_exact(outs[mode], outs['0'], 'depthwise {} stride {} pads {} {} act {} mode {}'.format(xs, st, pb, pe, act, mode))
     monkeypatch.delenv('PVHIP_DWCONV_COLS', raising=False)
     dev.reload_settings()
 
