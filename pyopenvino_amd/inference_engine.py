@@ -277,13 +277,21 @@ class InferRequest:
 
     def __init__(self, owner, runner, index: int):
         self.owner, self.runner, self.index = owner, runner, index      # owner: the network load_network returned
-        self._in_flight = False
+        self._in_flight, self._replayed = False, None
 
     def start_async(self, inputs: dict):
         if self._in_flight:
             raise RuntimeError('request {} is still in flight: wait() first'.format(self.index))
         ex = self.runner
         G = ex.ienet.G
+        # The same device-resident tensors as the last calls: the pass is replayed from this request's own recording (one call
+        # instead of ~100 dispatches; every request records its own pass on its own stream and keeps its own tensors, so the
+        # replays of several requests run side by side like their eager passes do).
+        self._replayed = ex._graph_for(inputs, gathers_later=True)
+        if self._replayed is not None:
+            ex.launch_graph(self._replayed)
+            self._in_flight = True
+            return
         by_name = {G.nodes[n]['name']: n for n in G.nodes}
         for node_name, val in inputs.items():
             if node_name in by_name:
@@ -307,8 +315,9 @@ class InferRequest:
         self._in_flight = False
         out = {}
         comm = self.owner.comm
+        replayed, self._replayed = self.__dict__.get('_replayed'), None
         for nid, name in ex.ienet.find_node_by_type('Result'):
-            value = G.nodes[nid]['result']
+            value = replayed['results'][name] if replayed is not None else G.nodes[nid]['result']
             if hasattr(value, 'numpy') and not isinstance(value, np.ndarray):
                 from . import device
                 # The copy to the host synchronises the stream it is issued on: use one that has nothing else queued
@@ -1048,6 +1057,10 @@ class Executable_Network:
 
     def wait_done(self):
         """Host-side wait for a pass dispatched with defer_sync (its streams have been joined on the base stream)."""
+        replayed = self.__dict__.pop('_replay_done', None)
+        if replayed is not None:
+            replayed.synchronize()
+            self.__dict__.setdefault('_event_pool', []).append(replayed)
         pending = self.__dict__.pop('_pending', None)
         if pending is not None:
             from . import device
@@ -1145,14 +1158,14 @@ class Executable_Network:
     # device_timing), a sharded batch -- runs eagerly, and a changed key drops the recording.  PVHIP_AUTO_GRAPH=0 turns it off.
     AUTO_GRAPH_AFTER = 2
 
-    def _auto_graph_key(self, inputs, verbose):
+    def _auto_graph_key(self, inputs, verbose, gathers_later=False):
         from . import device
         if verbose or os.environ.get('PVHIP_AUTO_GRAPH', '1') == '0' or self.__dict__.get('_auto_graph_busy'):
             return None
         if self.expected_result is not None or self.pickle_node_args or self.device_timing is not None or self.defer_sync:
             return None
-        if self.comm is not None and getattr(self.comm, 'world', 1) > 1:
-            return None
+        if not gathers_later and self.comm is not None and getattr(self.comm, 'world', 1) > 1:
+            return None                             # (a request gathers its shards in wait(), after the recorded pass)
         if not inputs or not all(isinstance(v, device.DeviceTensor) for v in inputs.values()):
             return None
         registry = self.ienet.ie.plugins.plugins
@@ -1167,34 +1180,55 @@ class Executable_Network:
         return (tuple(sorted((k, tuple(v.shape), v.ptr) for k, v in inputs.items())), self.compute_streams, self.stream_base,
                 self.__dict__.get('_plan_serial', 0), self.fuse_epilogues, device.settings_serial, self.kernel_type)
 
-    def infer(self, inputs: dict, verbose: bool = False) -> dict:
-        key = self._auto_graph_key(inputs, verbose)
+    def _graph_for(self, inputs, verbose=False, gathers_later=False):
+        """The recording that replays this pass, or None: the pass is dispatched eagerly (and counted; the recording is made on the
+        call after AUTO_GRAPH_AFTER identical eager ones)."""
+        key = self._auto_graph_key(inputs, verbose, gathers_later)
         state = self.__dict__.setdefault('_auto_graph', {'key': None, 'seen': 0, 'failed': False})
         g = self.__dict__.get('_graph')
         if key is None or state['failed'] or (g is not None and g.get('by_hand')):
-            return self._infer_eager(inputs, verbose)
+            return None
         if state['key'] != key:
             if state['key'] is not None and self.__dict__.get('_graph') is not None and state.get('captured'):
                 self.release_graph()
             state.update(key=key, seen=0, captured=False)
         if state.get('captured') and self.__dict__.get('_graph') is not None:
-            self.last_node_times = []
-            return self.infer_graph(inputs)
+            return self._graph
         state['seen'] += 1
         if state['seen'] <= self.AUTO_GRAPH_AFTER:
-            return self._infer_eager(inputs, verbose)
+            return None
         self._auto_graph_busy = True
+        saved_comm = self.comm
+        if gathers_later:
+            self.comm = None                # (the warm pass in front of the recording must not gather either: wait() does)
         try:
             self.capture_graph(inputs, warm=1)
             state['captured'] = True
         except Exception as exc:           # noqa: BLE001 -- replay is an optimisation: say why it is off, keep computing
             state['failed'] = True
             print('pyopenvino_amd: hipGraph replay of infer() disabled for this network ({}: {})'.format(type(exc).__name__, exc), file=sys.stderr)
-            return self._infer_eager(inputs, verbose)
+            return None
         finally:
             self._auto_graph_busy = False
+            self.comm = saved_comm
+        return self._graph
+
+    def infer(self, inputs: dict, verbose: bool = False) -> dict:
+        if self._graph_for(inputs, verbose) is None:
+            return self._infer_eager(inputs, verbose)
         self.last_node_times = []
         return self.infer_graph(inputs)
+
+    def launch_graph(self, g):
+        """Asynchronous replay for an infer request: the recorded pass goes to this network's stream with one call; `wait_done()`
+        waits for the event behind it."""
+        from . import device
+        import ctypes
+        device.select_stream(self.stream_base)
+        device.call('pvhip_graph_launch', ctypes.c_void_p(g['handle']))
+        self._replay_done = self._event().record()
+        device.select_stream(0)
+        self.last_node_times = []
 
     def _infer_eager(self, inputs: dict, verbose: bool = False) -> dict:
         G = self.ienet.G

@@ -241,6 +241,58 @@ def test_requests_in_flight_give_the_synchronous_bits(hip):
     assert np.array_equal(ex.infer({name: xs[1]})[out_name], want[1])
 
 
+def test_requests_with_device_resident_inputs_replay_their_own_recordings(hip, monkeypatch):
+    """start_async() with the SAME device tensors call after call: after AUTO_GRAPH_AFTER eager passes each request records its pass
+    into its own hipGraph (own stream, own tensors) and replays it with one call; three requests side by side, started in changing
+    orders, return the bits of the synchronous eager pass every time; a request given another tensor drops its recording, computes
+    eagerly and records again; PVHIP_AUTO_GRAPH=0 keeps every request eager.  (The temporaries of a recorded pass -- padded images,
+    workspaces -- stay with ITS graph: were they handed to another request, two replays would share scratch memory.)"""
+    from pyopenvino_amd import IECore, synth, device
+    xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    blob = synth.synth_weights(xml, 1234)
+    B, R = 16, 3
+    ie = IECore(plugin_package=HIP)
+    net = ie.read_network(xml, weights=blob)
+    net.set_batch(B)
+    ex = ie.load_network(net, 'GPU', num_requests=R)
+    name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
+    xs_host = [synth.uniform_pixels(700 + i, (B, 3, 224, 224)) for i in range(R + 1)]
+    monkeypatch.setenv('PVHIP_AUTO_GRAPH', '0')
+    want = [ex.infer({name: x})[out_name].copy() for x in xs_host]
+    xs = [device.DeviceTensor.from_numpy(x) for x in xs_host]
+    for rnd_ in range(3):                                   # switched off: eager, and nothing is recorded
+        for i in range(R):
+            ex.start_async(i, {name: xs[i]})
+        for i in range(R):
+            assert np.array_equal(ex.wait(i)[out_name], want[i])
+    assert all(r.runner.__dict__.get('_graph') is None for r in ex.requests)
+    monkeypatch.delenv('PVHIP_AUTO_GRAPH')
+    for rnd_ in range(7):
+        order = [(i + rnd_) % R for i in range(R)]
+        for i in order:
+            ex.start_async(i, {name: xs[i]})
+        for i in reversed(order):
+            assert np.array_equal(ex.wait(i)[out_name], want[i]), 'round {} request {}'.format(rnd_, i)
+        if rnd_ == 1:
+            assert all(r.runner.__dict__.get('_graph') is None for r in ex.requests)
+        if rnd_ >= 2:
+            assert all(r.runner.__dict__.get('_graph') is not None for r in ex.requests), rnd_
+    handles = [r.runner._graph['handle'] for r in ex.requests]
+    assert len(set(handles)) == R
+    for rnd_ in range(4):                                   # request 1 moves to another tensor while 0 and 2 keep replaying
+        ex.start_async(0, {name: xs[0]})
+        ex.start_async(1, {name: xs[R]})
+        ex.start_async(2, {name: xs[2]})
+        assert np.array_equal(ex.wait(2)[out_name], want[2])
+        assert np.array_equal(ex.wait(1)[out_name], want[R]), rnd_
+        assert np.array_equal(ex.wait(0)[out_name], want[0])
+        assert (ex.requests[1].runner.__dict__.get('_graph') is not None) == (rnd_ >= 2)
+    assert [r.runner._graph['handle'] for r in (ex.requests[0], ex.requests[2])] == [handles[0], handles[2]]
+    for x_dev, x_host in zip(xs, xs_host):                  # no recording ever wrote into a caller's tensor
+        assert np.array_equal(np.asarray(x_dev), x_host)
+    assert np.array_equal(ex.infer({name: xs_host[1]})[out_name], want[1])      # the synchronous call on the same network afterwards
+
+
 def test_rccl_binding_single_rank(hip):
     """The RCCL path of the C ABI (dlopen, unique id, communicator, all-gather, destroy) with one rank:
     exercises every call the multi-GPU Result gather makes; with world == 1 the gather is a device copy."""
