@@ -99,6 +99,16 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
     return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shift);
 }
 
+// IEEE 754-2019 maximum of three (gfx950: v_maximum3_f32): a NaN operand gives NaN -- np.max's rule -- in ONE instruction.  v_max3_f32
+// is maxNum (a NaN operand LOSES): next to it every window needed unordered compares, an OR chain and a select (a third of the pooling
+// arithmetic of conv_pool1x1_kernel, which runs on the SIMDs that run the MFMAs).  Two operands: max3_nan(a, b, b).
+__device__ __forceinline__ float max3_nan(float a, float b, float c) {
+    float r;
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+
 // Fused bias + activation of the convolution epilogues WITHOUT branches.  `act` (0 none, 1 ReLU, 2 Clamp) is a launch constant,
 // but written as `if (act == 1) ... else if (act == 2) ...` per value hipcc kept scalar branches around every one of the 16-32
 // values of a lane (the pointwise kernel's epilogue was 1262 instructions with ~300 branches and took a fifth of a workgroup's

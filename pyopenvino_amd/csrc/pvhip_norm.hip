@@ -256,20 +256,19 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
             float* yo = yimg + (size_t)ch0 * ohw + outo[i];
             unsigned pb = 0u;
             for (int p = 0; p < n_pl; ++p, pb += plane_bytes, yo += ohw) {
-                float m      = -INFINITY;
-                bool  anynan = false;
+                float h[3];                      // row maxima: a NaN IS the maximum (max3_nan), as for np.max
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float v0 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * k + 0]);
                     const float v1 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * k + 1]);
                     const float v2 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * k + 2]);
-                    m      = fmaxf(m, fmaxf(fmaxf(v0, v1), v2));
-                    anynan = anynan | __builtin_isunordered(v0, v1) | (v2 != v2);
+                    h[k] = max3_nan(v0, v1, v2);
                 }
-                if (zpad[i]) m = fmaxf(m, 0.0f);
+                float m = max3_nan(h[0], h[1], h[2]);
+                if (zpad[i]) m = max3_nan(m, 0.0f, 0.0f);
                 // PLAIN stores: a lane writes one float per plane, 896-byte runs per plane and band -- nontemporal stores of such pieces
                 // cost 4 % here and 9 % in maxpool3x3_lrn_kernel (the dense 16-byte runs of the MaxPool kernel are the opposite case)
-                if (!(abl & 4)) *yo = anynan ? NAN : m;
+                if (!(abl & 4)) *yo = m;
             }
         }
         __syncthreads();
@@ -416,18 +415,17 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_kernel(LrnPoolArgs a, F
             unsigned pb = 0u;
 #pragma unroll
             for (int p = 0; p < T; ++p, pb += plane_bytes) {
-                float m      = -INFINITY;
-                bool  anynan = false;
+                float h[3];                      // row maxima: a NaN IS the maximum (max3_nan), as for np.max
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const float v0 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * q + 0]);
                     const float v1 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * q + 1]);
                     const float v2 = *reinterpret_cast<const float*>(planes_b + pb + tap[i][3 * q + 2]);
-                    m      = fmaxf(m, fmaxf(fmaxf(v0, v1), v2));
-                    anynan = anynan | __builtin_isunordered(v0, v1) | (v2 != v2);
+                    h[q] = max3_nan(v0, v1, v2);
                 }
-                if (zpad[i]) m = fmaxf(m, 0.0f);
-                const float pooled = anynan ? NAN : m;
+                float m = max3_nan(h[0], h[1], h[2]);
+                if (zpad[i]) m = max3_nan(m, 0.0f, 0.0f);
+                const float pooled = m;
                 PV_PUSH_EMIT(i, pooled, k * T + p)
             }
         }

@@ -137,8 +137,7 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __re
         const unsigned ox  = rem - oyl * (unsigned)a.ow;
         const int py0 = (int)(oy0 + oyl) * a.sh, px0 = (int)ox * a.sw;
         const float* __restrict__ tp = tile + g * plane_l + (py0 - py_lo) * wl + px0;
-        float m      = -INFINITY;
-        bool  anynan = false;
+        float m = -INFINITY;             // max3_nan: a NaN in the window IS its maximum
         if (KH != 0) {
 #pragma unroll
             for (int ky = 0; ky < (KH ? KH : 1); ++ky) {
@@ -147,8 +146,7 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __re
                 for (int kx = 0; kx < (KW ? KW : 1); ++kx) {
                     if (row_ok && (!CLIP || (px0 + kx < a.wp))) {
                         const float v = tp[ky * wl + kx];
-                        anynan |= (v != v);
-                        m = fmaxf(m, v);
+                        m = max3_nan(m, v, v);
                     }
                 }
             }
@@ -156,11 +154,10 @@ __global__ __launch_bounds__(kBlock) void maxpool2d_lds_kernel(const float* __re
             for (int ky = 0; ky < kh && py0 + ky < a.hp; ++ky)
                 for (int kx = 0; kx < kw && px0 + kx < a.wp; ++kx) {
                     const float v = tp[ky * wl + kx];
-                    anynan |= (v != v);
-                    m = fmaxf(m, v);
+                    m = max3_nan(m, v, v);
                 }
         }
-        yout[o] = anynan ? NAN : m;
+        yout[o] = m;
     }
 }
 
@@ -286,29 +283,27 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_cols_kernel(Pool3Args a, Po
             const bool  zc    = (px0 < 0) || (min((int)ox * ST + 2, a.wp - 1) - a.pl >= a.w);
             const float flr_c = zc ? 0.0f : -INFINITY;
             const float* const L = in + (int)p * a.plane_l - iy_lo * a.w;      // input row iy of this plane at L + iy*w
-#define PV_HROW(IY, HV, NV)                                                                   \
+#define PV_HROW(IY, HV)                                                                       \
     do {                                                                                      \
         const int    r_ = min(max((IY), 0), a.h - 1);                                         \
         const float* q_ = L + r_ * a.w;                                                       \
         const float  v0_ = q_[c0], v1_ = q_[c1], v2_ = q_[c2];                                \
-        HV = fmaxf(fmaxf(v0_, v1_), v2_);                                                     \
-        NV = __builtin_isunordered(v0_, v1_) | (v2_ != v2_);                                  \
+        HV = max3_nan(v0_, v1_, v2_);           /* a NaN in the row IS its maximum, as for np.max */ \
     } while (0)
             float hA, hB, hC;
-            bool  nA, nB, nC;
-            PV_HROW(ys * ST - a.pt, hA, nA);
-            if (ST == 1) PV_HROW(ys - a.pt + 1, hB, nB);
+            PV_HROW(ys * ST - a.pt, hA);
+            if (ST == 1) PV_HROW(ys - a.pt + 1, hB);
             float* const yo = STAGE ? outb + (int)p * a.out_plane_l + (ys - oy0) * a.ow + (int)ox
                                     : a.y + (size_t)(g0 + (int)p) * ohw + (size_t)ys * a.ow + ox;
             for (int oy = ys; oy < ye; ++oy) {
-                if (ST == 2) PV_HROW(oy * 2 - a.pt + 1, hB, nB);
-                PV_HROW(oy * ST - a.pt + 2, hC, nC);
-                float m = fmaxf(fmaxf(hA, hB), hC);
-                const bool zr = (oy * ST < a.pt) || (min(oy * ST + 2, a.hp - 1) - a.pt >= a.h);
-                m = fmaxf(m, zr ? 0.0f : flr_c);
-                yo[(oy - ys) * a.ow] = (nA | nB | nC) ? NAN : m;
-                if (ST == 1) { hA = hB; nA = nB; hB = hC; nB = nC; }
-                else         { hA = hC; nA = nC; }
+                if (ST == 2) PV_HROW(oy * 2 - a.pt + 1, hB);
+                PV_HROW(oy * ST - a.pt + 2, hC);
+                const float m  = max3_nan(hA, hB, hC);
+                const bool  zr = (oy * ST < a.pt) || (min(oy * ST + 2, a.hp - 1) - a.pt >= a.h);
+                const float fl = zr ? 0.0f : flr_c;
+                yo[(oy - ys) * a.ow] = max3_nan(m, fl, fl);
+                if (ST == 1) { hA = hB; hB = hC; }
+                else         { hA = hC; }
             }
 #undef PV_HROW
         }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
             edge[it_][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offe[r], soff, 0));  \
         }                                                                                                        \
     }
-        // 3x3 max of iteration it_ into the B tile of buffer buf_ (columns first: one max3 and one NaN test per column, the
+        // 3x3 max of iteration it_ into the B tile of buffer buf_ (columns first: one NaN-propagating max3 per column, the
         // outer columns' from the neighbour lanes, then a max3 over three adjacent columns per pixel), then the same registers
         // fetch stage s_next_
 #define PVP_POOL(it_, buf_, s_next_)                                                                             \
@@ -150,26 +150,15 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
             PVP_LOAD(it_, s_next_);                                                                              \
             continue;                                                                                            \
         }                                                                                                        \
-        float cm_[VEC + 2];                                                                                      \
-        int   cn_[VEC + 2];                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < VEC; ++c) {                                                        \
-            const float e0 = ring[it_][0][c], e1 = ring[it_][1][c], e2 = ring[it_][2][c];                        \
-            cm_[c + 1] = fmaxf(fmaxf(e0, e1), e2);                                                               \
-            cn_[c + 1] = (__builtin_isunordered(e0, e1) | (e2 != e2)) ? 1 : 0;                                   \
-        }                                                                                                        \
-        const float em_ = fmaxf(fmaxf(edge[it_][0], edge[it_][1]), edge[it_][2]);                                \
-        const int   en_ = (__builtin_isunordered(edge[it_][0], edge[it_][1]) | (edge[it_][2] != edge[it_][2])) ? 1 : 0; \
+        float cm_[VEC + 2];                  /* column maxima; a NaN in the column IS the maximum (max3_nan): no bookkeeping beside it */ \
+        _Pragma("unroll") for (int c = 0; c < VEC; ++c) cm_[c + 1] = max3_nan(ring[it_][0][c], ring[it_][1][c], ring[it_][2][c]); \
+        const float em_ = max3_nan(edge[it_][0], edge[it_][1], edge[it_][2]);                                    \
         const float lm_ = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, cm_[VEC]), 0x138, 0xf, 0xf, true)); \
-        const int   ln_ = __builtin_amdgcn_mov_dpp(cn_[VEC], 0x138, 0xf, 0xf, true);                             \
         const float rm_ = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, cm_[1]), 0x130, 0xf, 0xf, true)); \
-        const int   rn_ = __builtin_amdgcn_mov_dpp(cn_[1], 0x130, 0xf, 0xf, true);                               \
         cm_[0]       = zl ? 0.0f : (first ? em_ : lm_);                                                          \
-        cn_[0]       = zl ? 0 : (first ? en_ : ln_);                                                             \
         cm_[VEC + 1] = zr ? 0.0f : (last ? em_ : rm_);                                                           \
-        cn_[VEC + 1] = zr ? 0 : (last ? en_ : rn_);                                                              \
         vec_t o_;                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < VEC; ++i)                                                          \
-            o_[i] = (cn_[i] | cn_[i + 1] | cn_[i + 2]) ? NAN : fmaxf(fmaxf(cm_[i], cm_[i + 1]), cm_[i + 2]);     \
+        _Pragma("unroll") for (int i = 0; i < VEC; ++i) o_[i] = max3_nan(cm_[i], cm_[i + 1], cm_[i + 2]);        \
         *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = o_;                                   \
         PVP_LOAD(it_, s_next_);                                                                                  \
     }

@@ -554,9 +554,23 @@ def test_pools_seeded_random_shapes(hip):
 
 
 def test_maxpool_nan_propagates(hip):
+    """np.max's rule (MaxPool.py:66-69): a NaN in the window is the result.  The kernels take it from v_maximum3_f32 (IEEE 754-2019
+    maximum), not from bookkeeping beside a maxNum: NaNs of either sign, in corners next to the zero padding, beside +-inf, on the
+    pipelined 3x3 kernel (stride 1 and 2), the one-shot kernel (2x2, 5x5 windows) and ragged extents."""
     x = rnd(5, (1, 2, 6, 6))
     x[0, 1, 2, 3] = np.nan
     vs_oracle('MaxPool', [x], pool_data((3, 3), (1, 1), (1, 1), (1, 1), 'ceil'))
+    for xs, k, st, pb, pe in [((2, 24, 28, 28), (3, 3), (1, 1), (1, 1), (1, 1)), ((2, 24, 28, 28), (3, 3), (2, 2), (0, 0), (0, 0)),
+                              ((3, 5, 14, 14), (3, 3), (2, 2), (0, 0), (0, 0)), ((2, 7, 13, 9), (5, 5), (1, 1), (2, 2), (2, 2)),
+                              ((1, 3, 9, 9), (2, 2), (2, 2), (0, 0), (0, 0)), ((2, 832, 7, 7), (3, 3), (1, 1), (1, 1), (1, 1))]:
+        x = rnd(sum(xs), xs, 2.0)
+        x[0, 0, 0, 0] = np.nan
+        x[-1, -1, -1, -1] = -np.nan
+        x[0, 1, xs[2] // 2, :] = np.inf
+        x[0, 1, xs[2] // 2, 1] = np.nan
+        x[-1, 0, :, xs[3] // 2] = -np.inf
+        x[-1, 0, 0, xs[3] // 2] = -np.nan
+        vs_oracle('MaxPool', [x], pool_data(k, st, pb, pe, 'ceil'))
 
 
 def test_avgpool_googlenet_shape(hip):
