@@ -2,14 +2,15 @@
 """GPU-box tool: random shapes through the kernels that have a slower twin -- the six-point Winograd kernel (3x3, 5x5; forced) against the
 direct kernel, MaxPool + 1x1 convolution / MaxPool + LRN / LRN + MaxPool as one launch against two, the padding pass + test-free
 gather of the c-major kernel (with and without the Add folded in) against the window test in the gather, and the f16 kernels of an
-FP16 IR (span kernel, LDS-DMA form, the first gather kernel) against each other.  python scripts/fuzz_kernels.py [cases] [seed]"""
+FP16 IR (span kernel, LDS-DMA form, the first gather kernel) against each other; the pipelined depthwise 3x3 kernel (lanes storing / through an output stage) against the one-shot one, and the
+pipelined 3x3 MaxPool against the one-shot one with NaNs and infinities strewn in -- bit for bit.  python scripts/fuzz_kernels.py [cases] [seed]"""
 import os, sys, random
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests'))
 from pyopenvino_amd import device as dev, synth
-from pyopenvino_amd.op_plugins import Convolution, MaxPool, LRN
+from pyopenvino_amd.op_plugins import Convolution, MaxPool, LRN, GroupConvolution
 dev.init(0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -18,12 +19,12 @@ def node(type_, ins, data):
             'input': {i: {'precision': 'I64' if a.dtype == np.int64 else 'FP32', 'dims': tuple(a.shape)} for i, a in enumerate(ins)},
             'output': {len(ins): {'precision': 'FP32', 'dims': ()}}}
 def setenv(env):
-    for k_ in ('PVHIP_CONV_WINOGRAD4', 'PVHIP_CONV_WINOGRAD5', 'PVHIP_CONV_WINOGRAD', 'PVHIP_CONV_PREPAD', 'PVHIP_CONV_F16_SPAN', 'PVHIP_CONV_F16_DMA'): os.environ.pop(k_, None)
+    for k_ in ('PVHIP_CONV_WINOGRAD4', 'PVHIP_CONV_WINOGRAD5', 'PVHIP_CONV_WINOGRAD', 'PVHIP_CONV_PREPAD', 'PVHIP_CONV_F16_SPAN', 'PVHIP_CONV_F16_DMA', 'PVHIP_DWCONV_COLS', 'PVHIP_POOL3'): os.environ.pop(k_, None)
     os.environ.update(env); dev.reload_settings()
 bad = 0
 compared = {}
 for i in range(cases):
-    kind = rng.choice(['w3', 'w5', 'poolconv', 'poollrn', 'lrnpool', 'prepad', 'f16'])
+    kind = rng.choice(['w3', 'w5', 'poolconv', 'poollrn', 'lrnpool', 'prepad', 'f16', 'dw', 'pool'])
     n, h, w = rng.randint(1, 9), rng.randint(1, 30), rng.randint(1, 30)
     if kind in ('w3', 'w5'):
         ks = 3 if kind == 'w3' else 5
@@ -78,6 +79,46 @@ for i in range(cases):
         err = max(float(np.abs(o - outs[2]).max() / max(1e-20, np.abs(outs[2]).max())) for o in outs[:2])
         ok = err < 1e-5
         what = 'f16 {}x{} conv x{} k{}: {:.1e}'.format(ks, ks, (n, c, h, w), k, err)
+    elif kind == 'dw':                # depthwise 3x3, stride 1 / 2: the pipelined kernel in both store forms == the one-shot kernel
+        c, st = rng.randint(1, 40), rng.choice([1, 2])
+        n, h, w = rng.randint(1, 6), rng.randint(1, 160), rng.randint(1, 160)
+        pb, pe = (rng.randint(0, 1), rng.randint(0, 1)), (rng.randint(0, 1), rng.randint(0, 1))
+        if h + pb[0] + pe[0] < 3 or w + pb[1] + pe[1] < 3:
+            continue
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w)) * 3.0
+        x.reshape(-1)[rng.randrange(x.size)] = np.inf
+        x.reshape(-1)[rng.randrange(x.size)] = -np.inf
+        wt = (synth.normal(i, 3, c * 9) * 0.4).astype(np.float32).reshape((c, 1, 1, 3, 3))
+        gn = node('GroupConvolution', [x, wt], {'strides': '{0}, {0}'.format(st), 'dilations': '1, 1', 'pads_begin': '{}, {}'.format(*pb), 'pads_end': '{}, {}'.format(*pe), 'auto_pad': 'explicit'})
+        act = rng.choice([None, ('relu',), ('clamp', 0.0, 6.0)])
+        if act is not None:
+            gn['_fuse_bias'], gn['_fuse_act'] = dev.DeviceTensor.from_numpy(synth.normal(i, 4, c).astype(np.float32).reshape((1, c, 1, 1))), act
+        outs = []
+        for mode in ('0', '1', '2'):
+            setenv({'PVHIP_DWCONV_COLS': mode})
+            outs.append(np.asarray(GroupConvolution.compute(dict(gn), {0: dev.DeviceTensor.from_numpy(x), 1: dev.DeviceTensor.from_numpy(wt)})[2]))
+        setenv({})
+        ok = all(bool(((o.view(np.uint32) == outs[0].view(np.uint32)) | (np.isnan(o) & np.isnan(outs[0]))).all()) for o in outs[1:])
+        what = 'depthwise x{} stride {} pads {} {} act {}'.format(x.shape, st, pb, pe, act)
+    elif kind == 'pool':              # MaxPool 3x3, stride 1 / 2: the pipelined kernel == the one-shot kernel, NaNs and infinities included
+        c, st = rng.randint(1, 48), rng.choice([1, 2])
+        n, h, w = rng.randint(1, 6), rng.randint(1, 120), rng.randint(1, 120)
+        pb, pe = rng.choice([0, 1]), rng.choice([0, 1])
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w)) * 3.0
+        for bad_v in (np.nan, -np.nan, np.inf, -np.inf):
+            x.reshape(-1)[rng.randrange(x.size)] = bad_v
+        pn = node('MaxPool', [x], {'kernel': '3, 3', 'strides': '{0}, {0}'.format(st), 'pads_begin': '{0}, {0}'.format(pb), 'pads_end': '{0}, {0}'.format(pe), 'rounding_type': rng.choice(['ceil', 'floor']), 'auto_pad': 'explicit'})
+        outs = []
+        try:
+            for mode in ('0', '1'):
+                setenv({'PVHIP_POOL3': mode})
+                outs.append(np.asarray(MaxPool.compute(dict(pn), {0: dev.DeviceTensor.from_numpy(x)})[1]))
+        except (ValueError, dev.PvhipError):
+            setenv({})
+            continue
+        setenv({})
+        ok = bool(((outs[1].view(np.uint32) == outs[0].view(np.uint32)) | (np.isnan(outs[1]) & np.isnan(outs[0]))).all())
+        what = 'MaxPool 3x3 x{} stride {} pads {} {}'.format(x.shape, st, pb, pe)
     elif kind == 'poolconv':
         c, k = 16 * rng.randint(1, 6), rng.randint(1, 128)
         w = 2 * rng.randint(1, 15)
