@@ -5,9 +5,16 @@
 
 One "step" = one pass of the whole per-layer compute() path (Executable_Network.infer) over one batch of
 256 synthetic images per GPU, input already resident in HBM, ending with the Result tensor back on the
-host (and, for N > 1, an RCCL all-gather of the Result tensors first).  For N > 1 launch one process per
-GPU with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; torch.distributed
-(gloo) is used for the rendezvous / barrier / max-over-ranks only.
+host (and, for N > 1, an RCCL all-gather of the Result tensors first).  For N > 1 there is one process per GPU:
+either the driver starts them (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or `python bench.py --gpus N` starts them itself
+(shard.launch_ranks: N fresh child processes with the same variables; the parent never touches a GPU).  Rendezvous,
+barrier and max-over-ranks go over plain sockets (shard.TcpGroup); no torch in the process.
+
+Parity of the timed path: rows 0-7 of every rank's request 0 are the eight images of tests/golden/googlenet_rows8.npz (the
+reference's own N=1 answers); after the timed region the LAST replayed Result of every request is checked -- request 0's
+rows 0-7 against the fixture (1e-4 in both norms), every request bit for bit against one eager synchronous infer() of the
+same tensor -- and the line says so (`parity_of_timed_path`).  A mismatch fails the run.
 
 The timed region is a block of exactly K steps between barrier + device synchronisation on both sides (max over
 ranks); the block is repeated until at least --min-seconds (1 s) have been timed and the MEDIAN block is reported
@@ -112,19 +119,52 @@ def cpu_baseline(blob, n_images):
             'sample': '{} googlenet-v1 images, one N=1 forward each, oracle numpy/OpenBLAS plugins, {:.1f} s'.format(n_images, dt)}
 
 
+_diag = None
+
+
+def diag_library(device):
+    """The DIAGNOSTIC build (libpvhip_diag.so, include/pvhip_diag.h: measurement probes that are not part of the product) as a second
+    library handle with its own state, initialised on the same device.  Harness only -- and only AFTER the timed region: while the
+    benchmark is timed, libpvhip.so is the only library of this repository mapped into the process."""
+    global _diag
+    if _diag is None:
+        path = device.DIAG_LIB_PATH
+        if not os.path.isfile(path):
+            raise RuntimeError('diagnostic build {} is missing -- run `make -C pyopenvino_amd/csrc diag`'.format(path))
+        lib = ctypes.CDLL(path)
+        lib.pvhip_last_error.restype = ctypes.c_char_p
+        if lib.pvhip_init(int(device.current_device())) != 0:
+            raise RuntimeError('diagnostic build: pvhip_init failed: {}'.format(lib.pvhip_last_error().decode(errors='replace')))
+        lib.pvhip_mfma_ceiling_f32.restype = ctypes.c_int
+        lib.pvhip_mfma_ceiling_f32.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        _diag = lib
+    return _diag
+
+
+def mfma_ceiling_f32(device, with_valu_partner=False, iters=20000):
+    """(TFLOP/s, shader clock in GHz) this device sustains on v_mfma_f32_32x32x2_f32 alone -- or with a VALU-only wave beside every
+    MFMA wave (include/pvhip_diag.h: pvhip_mfma_ceiling_f32)."""
+    lib = diag_library(device)
+    tf, ghz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc = lib.pvhip_mfma_ceiling_f32(1 if with_valu_partner else 0, int(iters), ctypes.byref(tf), ctypes.byref(ghz))
+    if rc != 0:
+        raise RuntimeError('pvhip_mfma_ceiling_f32 failed ({}): {}'.format(rc, lib.pvhip_last_error().decode(errors='replace')))
+    return float(tf.value), float(ghz.value)
+
+
 def mfma_ceiling(device):
     """What THIS box sustains on v_mfma_f32_32x32x2_f32 with nothing else in the instruction stream (pvhip_mfma_ceiling_f32: one
     wave per SIMD, operands in registers, random data, a 2-3 ms kernel), the shader clock it holds meanwhile, and the same with a
     VALU-only wave beside every MFMA wave.  157.3 TFLOP/s is the rate at 2.4 GHz; the chip lowers its clock under matrix load."""
-    # a probe of the DIAGNOSTIC build (libpvhip_diag.so, include/pvhip_diag.h), loaded beside the product library for this measurement only
+    # a probe of the DIAGNOSTIC build, loaded after the timed region for this measurement only
     try:
-        device.diag_library()
+        diag_library(device)
     except Exception as exc:       # noqa: BLE001 -- informational: the line then says it has no such figure
         print('bench.py: roofline.sustained not measured: {}'.format(exc), file=sys.stderr)
         return None
     # the clock ramps up over the first milliseconds after idle: best of four back-to-back runs
-    tf, ghz = max(device.mfma_ceiling_f32(False, 20000) for _ in range(4))
-    tf_v, ghz_v = max(device.mfma_ceiling_f32(True, 20000) for _ in range(2))
+    tf, ghz = max(mfma_ceiling_f32(device, False, 20000) for _ in range(4))
+    tf_v, ghz_v = max(mfma_ceiling_f32(device, True, 20000) for _ in range(2))
     return {'TFLOPs': round(tf, 1), 'clock_GHz': round(ghz, 2), 'with_a_VALU_wave_per_SIMD_TFLOPs': round(tf_v, 1),
             'note': 'fp32 MFMA alone, every SIMD of every CU issuing; with an fp32 VALU wave on the same SIMD the MFMA rate drops by '
                     'that wave\'s share of the issue cycles: matrix and vector fp32 instructions of a SIMD do not overlap'}
@@ -253,13 +293,18 @@ def main():
     ap.add_argument('--requests', type=int, default=8, help='infer requests in flight per GPU (each a whole batch; 1 = synchronous infer())')
     args = ap.parse_args()
 
-    from pyopenvino_amd import IECore, device, shard, synth
+    from pyopenvino_amd import shard
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not started by a launcher: be one.  N fresh processes of this command, one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+        # MASTER_* exported as torch.distributed.run would; this process has not touched the GPU and never will.
+        sys.exit(shard.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    from pyopenvino_amd import IECore, device, synth
     from pyopenvino_amd.op_plugins import Convolution as conv_plugin
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and world != args.gpus:
-        sys.exit('bench.py --gpus {} must be launched with torch.distributed.run --nproc-per-node {}'.format(args.gpus, args.gpus))
-    group = shard.TorchGroup('gloo') if world > 1 else shard.SingleGroup()
+    if args.gpus != world:
+        sys.exit('bench.py --gpus {} inside a launcher that exported WORLD_SIZE={}'.format(args.gpus, world))
+    group = shard.TcpGroup() if world > 1 else shard.SingleGroup()
     rank = group.rank
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     device.init(local_rank if device.device_count() > 1 else 0)
@@ -288,32 +333,45 @@ def main():
 
     # synthetic input of this rank's shard, resident in HBM before the timed region
     x_host = synth.uniform_pixels(1000 + rank, (args.batch, 3, 224, 224))
+    # rows 0-7 of request 0: the eight images the REFERENCE answered at N=1 on these weights (tests/golden/googlenet_rows8.npz,
+    # recorded by tests/golden/make_golden.py from /root/reference): the timed path is checked against them below
+    golden = np.load(os.path.join(REPO, 'tests', 'golden', 'googlenet_rows8.npz'))
+    assert int(golden['weight_seed']) == WEIGHT_SEED
+    n_gold = min(len(golden['image_seeds']), args.batch)
+    for i in range(n_gold):
+        x_host[i] = synth.uniform_pixels(int(golden['image_seeds'][i]), (1, 3, 224, 224))[0]
     x_dev = device.DeviceTensor.from_numpy(x_host)
     x_req = [x_dev] + [device.DeviceTensor.from_numpy(synth.uniform_pixels(1000 + rank + 100 * r, (args.batch, 3, 224, 224)))
                        for r in range(1, n_req)]
     in_name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
     dispatch_s = [0.0]       # host seconds spent dispatching asynchronous passes
+    last_result = {}         # request index -> the Result its LAST pass of the timed region returned (gathered over the ranks)
 
     def pipelined(steps, first=0, on_sample=None):
         """`steps` forward passes with up to n_req whole-batch requests in flight (request i on its own streams and
         its own resident input); every SAMPLE_EVERY-th pass is taken out of the pipeline when on_sample is given."""
         in_flight, out = [], None
+
+        def finish(r):
+            last_result[r] = ex.wait(r)[out_name]
+            return last_result[r]
+
         for step in range(first, first + steps):
             if on_sample is not None and step % SAMPLE_EVERY == 0:
                 while in_flight:
-                    out = ex.wait(in_flight.pop(0))[out_name]
+                    out = finish(in_flight.pop(0))
                 out = on_sample()
                 continue
             r = step % n_req
             if r in in_flight:
                 in_flight.remove(r)
-                out = ex.wait(r)[out_name]
+                out = finish(r)
             t_d = time.perf_counter()
             ex.start_async(r, {in_name: x_req[r]})       # (replays the request's recorded pass: one call; PVHIP_AUTO_GRAPH=0: ~100 dispatches)
             dispatch_s[0] += time.perf_counter() - t_d
             in_flight.append(r)
         while in_flight:
-            out = ex.wait(in_flight.pop(0))[out_name]
+            out = finish(in_flight.pop(0))
         return out
 
     # set-up, like the weight upload: three passes per request bring the device-memory pool to its steady state (a pass
@@ -326,7 +384,6 @@ def main():
     pcie_ms = single_rate = single_ms = ceiling = graph_ms = sustained = eager_rate = eager_ms = None
     if informational:
         ceiling = copy_ceiling(device)
-        sustained = mfma_ceiling(device)
         # the same step fed from a HOST array (Parameter uploads 154 MB over PCIe from pageable memory, then the forward
         # pass) -- SURVEY 8(d) asks for the end-to-end rate beside the resident one
         ex.device_timing, ex.compute_streams = None, n_streams
@@ -445,6 +502,49 @@ def main():
     dev_ms = statistics.median(b[1] for b in blocks)
     n_blocks = len(blocks)
 
+    # ---- parity of the path that was just timed (every rank takes part: a gathered Result is a collective) ----
+    # The last Result every request returned inside the timed region -- replayed from its own hipGraph with the other requests in
+    # flight beside it -- against (a) the reference's recorded N=1 answers for rows 0-7 of request 0 (of EVERY rank: the gathered
+    # tensor carries them at rank * batch), 1e-4 in both norms; (b) one eager, synchronous infer() of the same tensor, bit for bit.
+    parity = {'checked_requests': 0, 'rows_vs_reference': 0, 'max_norm_error_vs_reference': None, 'worst_element_of_1e-4_allowance': None,
+              'replayed_equals_eager_bits': None}
+    if n_req == 1:
+        last_result[0] = ex.infer({in_name: x_dev})[out_name]
+    saved_env = os.environ.get('PVHIP_AUTO_GRAPH')
+    os.environ['PVHIP_AUTO_GRAPH'] = '0'
+    try:
+        bits_ok = True
+        for r in sorted(last_result):
+            req = ex.requests[r] if n_req > 1 else None
+            eager = (req.infer({in_name: x_req[r]}) if req is not None else ex.infer({in_name: x_dev}))[out_name]
+            got = np.asarray(last_result[r])
+            assert got.shape == (args.batch * world, 1000) and np.isfinite(got).all(), 'request {}: non-finite Result'.format(r)
+            if not np.array_equal(got, np.asarray(eager)):
+                bits_ok = False
+                print('bench.py rank {}: request {}: the replayed Result of the timed region differs from the eager infer() of the same '
+                      'tensor in {} elements'.format(rank, r, int((got != np.asarray(eager)).sum())), file=sys.stderr, flush=True)
+            parity['checked_requests'] += 1
+            if r == 0 and n_gold:
+                want = np.asarray(golden['out'][:n_gold], dtype=np.float64)
+                for w in range(world):
+                    rows = got[w * args.batch: w * args.batch + n_gold].astype(np.float64)
+                    err = float(np.abs(rows - want).max() / np.abs(want).max())
+                    rms = float(np.sqrt(np.mean(want * want)))
+                    excess = float((np.abs(rows - want) / (1e-4 * np.abs(want) + 1e-4 * rms)).max())
+                    parity['rows_vs_reference'] += n_gold
+                    parity['max_norm_error_vs_reference'] = max(parity['max_norm_error_vs_reference'] or 0.0, err)
+                    parity['worst_element_of_1e-4_allowance'] = max(parity['worst_element_of_1e-4_allowance'] or 0.0, excess)
+        parity['replayed_equals_eager_bits'] = bits_ok
+    finally:
+        os.environ.pop('PVHIP_AUTO_GRAPH')
+        if saved_env is not None:
+            os.environ['PVHIP_AUTO_GRAPH'] = saved_env
+    parity_ok = bool(parity['replayed_equals_eager_bits']) and (not parity['rows_vs_reference'] or (
+        parity['max_norm_error_vs_reference'] <= 1e-4 and parity['worst_element_of_1e-4_allowance'] <= 1.0))
+    parity['ok'] = parity_ok
+    if informational:
+        sustained = mfma_ceiling(device)       # (diagnostic library: mapped only now, after the timed region)
+
     if rank == 0:
         total_images = args.batch * world * args.steps
         result = {
@@ -465,6 +565,7 @@ def main():
             'ms_per_step_instrumented_blocks': (1e3 * statistics.median(instrumented_blocks) / args.steps) if instrumented_blocks else None,
             'device_ms_per_step': dev_ms / args.steps,
             'host_dispatch_ms_per_step': 1000.0 * host_dispatch / (args.steps * n_blocks),
+            'parity_of_timed_path': parity,
         }
         if single_rate is not None:
             result['single_request_images_per_sec'] = single_rate
@@ -547,9 +648,30 @@ def main():
                         doc = json.load(open(path))
                         k = doc['kernels']['convolution_kernels']
                         traffic = k['read_bytes_per_launch'] + k['write_bytes_per_launch']
-                        traffic_by_kernel = {name: {'launches_per_step': v.get('launches_per_step'), 'bytes_per_launch': v['read_bytes_per_launch'] + v['write_bytes_per_launch'],
-                                                    'algorithmic_bytes_per_launch': v.get('algorithmic_bytes_per_launch')}
-                                             for name, v in doc.get('convolution_kernels_by_family', {}).items()}
+                        # the same split as scripts/summarize_profile.py::conv_family makes of rocprofv3's kernel names, with the algorithmic
+                        # bytes (4 * (input + weights + output), the shared input of a multi-arm launch once) of THIS run's launches beside
+                        # the counted ones: traffic_ratio well above 1 = re-reads
+                        algo = {}
+                        for fam, agg in families.items():
+                            if agg['flops'] <= 0:
+                                continue
+                            key = ('conv_pool1x1_kernel' if 'conv_pool1x1' in fam else 'conv_wino4_kernel' if ('F(4x4' in fam or '5x5)' in fam)
+                                   else 'conv_wino_kernel' if 'F(2x2,3x3)' in fam else 'conv_stem_kernel' if 'stem' in fam
+                                   else 'conv_module_kernel' if 'module launch' in fam else 'conv_pw_kernel' if 'pointwise' in fam
+                                   else 'conv_igemm_dma_kernel')
+                            a = algo.setdefault(key, [0.0, 0])
+                            a[0] += agg['bytes']
+                            a[1] += agg['launches']
+                        traffic_by_kernel = {}
+                        for name, v in doc.get('convolution_kernels_by_family', {}).items():
+                            counted = v['read_bytes_per_launch'] + v['write_bytes_per_launch']
+                            a = algo.get(name)
+                            per_launch = (a[0] / a[1]) if a and a[1] else None
+                            traffic_by_kernel[name] = {'launches_per_step': v.get('launches_per_step'), 'bytes_per_launch': counted,
+                                                       'read_bytes_per_launch': v['read_bytes_per_launch'], 'write_bytes_per_launch': v['write_bytes_per_launch'],
+                                                       'algorithmic_bytes_per_launch': per_launch,
+                                                       'launches_per_step_this_run': a[1] if a else None,
+                                                       'traffic_ratio': round(counted / per_launch, 3) if per_launch else None}
                         traffic_src = 'static: {} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_bench.sh, tree {}; ' \
                                       'not re-measured in this run)'.format(os.path.relpath(path, REPO), doc.get('tree', 'unknown'))
                         break
@@ -574,6 +696,7 @@ def main():
                                      'that figure says how fast the layers are done, not how busy the MFMA pipe is, and may exceed 1',
                         'sustained': dict(sustained, frac_of_sustained=round(tf_exec / sustained['TFLOPs'], 3)) if sustained else None,
                         'traffic': traffic, 'traffic_source': traffic_src, 'traffic_by_kernel': traffic_by_kernel or None,
+                        'traffic_ratio': round(traffic / (conv['bytes'] / n_launch), 3) if traffic else None,
                         'kernel': 'all Convolution launches of a step: conv_wino4_kernel (F(4x4,3x3), F(2x2,5x5)) + conv_wino_kernel (F(2x2,3x3)) + conv_pw_kernel '
                                   '(1x1; the 1x1 / 3x3_reduce / 5x5_reduce convolutions of an inception module are one launch) + conv_pool1x1_kernel (MaxPool + pool_proj) '
                                   '+ conv_igemm_dma_kernel (conv1, the 7x7-sized 5x5): {} launches per step for the 57 Convolution nodes, bias+ReLU fused'.format(n_launch),
@@ -624,6 +747,8 @@ def main():
     if world > 1:
         group.barrier()
         group.close()
+    if not parity_ok:
+        sys.exit('bench.py rank {}: the timed path disagrees with its references: {}'.format(rank, parity))
 
 
 if __name__ == '__main__':

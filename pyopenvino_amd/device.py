@@ -216,40 +216,9 @@ def synchronize():
     call('pvhip_sync')
 
 
-_diag_lib = None
-
-
-def diag_library():
-    """The diagnostic build as a SECOND library handle (its own state: initialised on the same device), for measurement probes that are
-    not part of the product library (include/pvhip_diag.h).  Harness only (bench.py, scripts/): nothing in the product path calls it."""
-    global _diag_lib
-    if _diag_lib is None:
-        if os.path.abspath(LIB_PATH) == os.path.abspath(DIAG_LIB_PATH):
-            _diag_lib = load_library()
-        else:
-            if not os.path.isfile(DIAG_LIB_PATH):
-                raise PvhipError('diagnostic build {} is missing -- run `make -C pyopenvino_amd/csrc diag`'.format(DIAG_LIB_PATH))
-            ensure_init()
-            lib = ctypes.CDLL(DIAG_LIB_PATH)
-            lib.pvhip_last_error.restype = _c.c_char_p
-            if lib.pvhip_init(int(_initialised_device)) != 0:
-                raise PvhipError('diagnostic build: pvhip_init failed: {}'.format(lib.pvhip_last_error().decode(errors='replace')))
-            _diag_lib = lib
-        _diag_lib.pvhip_mfma_ceiling_f32.restype = _c.c_int
-        _diag_lib.pvhip_mfma_ceiling_f32.argtypes = [_c.c_int, _c.c_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]
-    return _diag_lib
-
-
-def mfma_ceiling_f32(with_valu_partner: bool = False, iters: int = 20000):
-    """(TFLOP/s, shader clock in GHz) this device sustains on v_mfma_f32_32x32x2_f32 alone -- or with a VALU-only wave beside
-    every MFMA wave (include/pvhip_diag.h: pvhip_mfma_ceiling_f32, DIAGNOSTIC build).  A measurement utility for bench.py's roofline."""
-    ensure_init()
-    lib = diag_library()
-    tf, ghz = _c.c_double(0.0), _c.c_double(0.0)
-    rc = lib.pvhip_mfma_ceiling_f32(1 if with_valu_partner else 0, int(iters), _c.byref(tf), _c.byref(ghz))
-    if rc != 0:
-        raise PvhipError('pvhip_mfma_ceiling_f32 failed ({}): {}'.format(rc, lib.pvhip_last_error().decode(errors='replace')))
-    return float(tf.value), float(ghz.value)
+def current_device():
+    """Index of the GPU this process is bound to (None before init)."""
+    return _initialised_device
 
 
 def pool_stats():

@@ -346,7 +346,8 @@ class Executable_Network:
     def __init__(self, ienetwork: IENetwork):
         self.ienet = ienetwork
         self.kernel_type = 'hip'        # the reference's 'naive' / 'numpy' / 'special' are accepted too
-        self.expected_result = None     # {node name: ndarray}: per-layer compare hook (cf. :284-287)
+        self.expected_result = None     # {node name: [precision, dims, ndarray]} (the reference's format) or {node name: ndarray}: per-layer compare hook (cf. :284-287)
+        self.expected_rtol = 1.0        # the reference compares with np.allclose(rtol=1) (common_def.py:72)
         self.pickle_node_args = []      # node ids whose (node, inputs) run_tasks dumps to node_args_<id>.pickle (cf. :216, :275-278)
         self.pickle_dir = '.'           # where (the reference writes into the working directory)
         self.task_list = []
@@ -890,10 +891,10 @@ class Executable_Network:
             if verbose:
                 print('{}, {}, {}, {}'.format(task, node_type, node['name'], dt))
             if self.expected_result is not None and node['name'] in self.expected_result and len(res) > 0:
-                got = np.asarray(next(iter(res.values())))
-                want = np.asarray(self.expected_result[node['name']]).astype(got.dtype)
-                ok = got.shape == want.shape and np.allclose(got, want, rtol=1e-4, atol=1e-4 * max(1e-30, float(np.abs(want).max())))
-                print('{} : {}'.format(node['name'], 'match' if ok else 'MISMATCH'))
+                # the reference's hook (inference_engine.py:284-287 -> common_def.py:71-105); entries in its format
+                # {name: [precision, dims, ndarray]} or bare arrays; `expected_rtol` = its rtol of 1 unless the caller tightens it
+                common_def.compare_results(node['name'], next(iter(res.values())), self.expected_result, disp_results=False,
+                                           rtol=self.expected_rtol)
             if len(res) > 0:
                 for port_id, data in res.items():
                     node['output'][port_id]['data'] = data

@@ -5,12 +5,17 @@ The reference has no counterpart (it is single-process, N=1); images of a batch 
 the whole graph, so each rank runs the unchanged scheduler on a contiguous slice of the batch.
 
 Host-side coordination (rendezvous, barrier, exchanging RCCL's unique id, max-over-ranks timing) goes
-through a small HostGroup protocol; TorchGroup adapts ``torch.distributed`` (backend ``gloo``) to it,
-which is what the launcher (``python -m torch.distributed.run``) sets up the environment for.  The
-data path never touches torch.
+through a small HostGroup protocol; TcpGroup implements it over plain sockets from the environment the
+launcher exports (``python -m torch.distributed.run``, or ``bench.py --gpus N`` by itself through
+``launch_ranks``).  Nothing here imports torch.
 """
 import ctypes
 import os
+import pickle
+import socket
+import struct
+import tempfile
+import time
 
 import numpy as np
 
@@ -44,41 +49,181 @@ class SingleGroup:
         return float(value)
 
 
-class TorchGroup:
-    """HostGroup over torch.distributed (gloo).  Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
-    from the environment when the default process group is not initialised yet."""
+def _send_msg(sock, obj):
+    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    sock.sendall(struct.pack('<Q', len(blob)) + blob)
 
-    def __init__(self, backend: str = 'gloo'):
-        import torch.distributed as dist
-        self._dist = dist
-        if not dist.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group(backend=backend)
-        self.rank = dist.get_rank()
-        self.world = dist.get_world_size()
+
+def _recv_exact(sock, n):
+    parts, got = [], 0
+    while got < n:
+        piece = sock.recv(min(n - got, 1 << 20))
+        if not piece:
+            raise ConnectionError('host group: peer closed the connection')
+        parts.append(piece)
+        got += len(piece)
+    return b''.join(parts)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    return pickle.loads(_recv_exact(sock, n))
+
+
+class TcpGroup:
+    """HostGroup over plain TCP sockets on one node (a star: rank 0 serves, ranks 1.. connect): rendezvous, barrier, the RCCL unique
+    id, row counts and max-over-ranks timing -- a few hundred bytes per call, never tensors of the data path on a GPU run.  No torch.
+
+    Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment, which is what `python -m torch.distributed.run` and
+    `bench.py --gpus N` (its own launcher) both export.  MASTER_PORT itself belongs to the launcher (torchrun keeps its store there),
+    so rank 0 listens on a port the system picks and publishes `host port` in a rendezvous file named after MASTER_PORT and the
+    launcher's pid (all ranks are children of one launcher; PVHIP_RDV_FILE overrides the name).  A stale file of an earlier run is
+    harmless: a rank that cannot connect, or whose hello is not answered with this run's world size, reads the file again."""
+
+    def __init__(self, rank=None, world=None, timeout=600.0, rdv_file=None):
+        self.rank = int(os.environ['RANK'] if rank is None else rank)
+        self.world = int(os.environ['WORLD_SIZE'] if world is None else world)
+        if not 0 <= self.rank < self.world:
+            raise ValueError('bad rank/world {}/{}'.format(self.rank, self.world))
+        self.timeout = float(timeout)
+        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = os.environ.get('MASTER_PORT', '29500')
+        self._rdv = rdv_file or os.environ.get('PVHIP_RDV_FILE') or os.path.join(
+            tempfile.gettempdir(), 'pvhip_rdv_{}_{}_{}'.format(os.getuid(), port, os.getppid()))
+        self._peers, self._sock, self._server = {}, None, None
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                srv.bind((addr, 0))
+            except OSError:
+                srv.bind(('127.0.0.1', 0))
+            srv.listen(self.world)
+            srv.settimeout(self.timeout)
+            self._server = srv
+            self._token = '{}-{}'.format(os.getpid(), time.time_ns())
+            tmp = '{}.{}'.format(self._rdv, os.getpid())
+            with open(tmp, 'w') as f:
+                f.write('{} {} {}\n'.format(srv.getsockname()[0], srv.getsockname()[1], self._token))
+            os.replace(tmp, self._rdv)
+            while len(self._peers) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.settimeout(self.timeout)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                try:
+                    hello = _recv_msg(conn)
+                except (ConnectionError, OSError, struct.error, pickle.UnpicklingError):
+                    conn.close()
+                    continue
+                ok = (isinstance(hello, dict) and hello.get('world') == self.world and hello.get('token') == self._token
+                      and isinstance(hello.get('rank'), int) and 0 < hello['rank'] < self.world and hello['rank'] not in self._peers)
+                _send_msg(conn, {'ok': bool(ok), 'world': self.world})
+                if ok:
+                    self._peers[hello['rank']] = conn
+                else:
+                    conn.close()
+        else:
+            deadline = time.monotonic() + self.timeout
+            while True:
+                sock = None
+                try:
+                    with open(self._rdv) as f:
+                        host, rport, token = f.read().split()
+                    sock = socket.create_connection((host, int(rport)), timeout=5.0)
+                    sock.settimeout(self.timeout)
+                    sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    _send_msg(sock, {'rank': self.rank, 'world': self.world, 'token': token})
+                    if _recv_msg(sock).get('ok'):
+                        self._sock = sock
+                        break
+                    sock.close()
+                except (OSError, ValueError, ConnectionError, struct.error, pickle.UnpicklingError):
+                    if sock is not None:
+                        sock.close()
+                if time.monotonic() > deadline:
+                    raise TimeoutError('host group: rank {} found no rank 0 behind {} in {:.0f} s'.format(self.rank, self._rdv, self.timeout))
+                time.sleep(0.05)
+
+    # every collective: ranks 1.. send their part to rank 0, which answers each of them with the combined result
+    def _exchange(self, part, combine):
+        if self.world == 1:
+            return combine([part])
+        if self.rank == 0:
+            parts = [part] + [None] * (self.world - 1)
+            for r, conn in self._peers.items():
+                parts[r] = _recv_msg(conn)
+            result = combine(parts)
+            for conn in self._peers.values():
+                _send_msg(conn, result)
+            return result
+        _send_msg(self._sock, part)
+        return _recv_msg(self._sock)
 
     def barrier(self):
-        self._dist.barrier()
+        self._exchange(None, lambda parts: None)
 
     def broadcast_bytes(self, data, src=0):
-        box = [data if self.rank == src else None]
-        self._dist.broadcast_object_list(box, src=src)
-        return box[0]
+        return self._exchange(data if self.rank == src else None, lambda parts: parts[src])
 
     def allgather_array(self, arr):
-        parts = [None] * self.world
-        self._dist.all_gather_object(parts, np.ascontiguousarray(arr))
-        return parts
+        return self._exchange(np.ascontiguousarray(arr), list)
 
     def allreduce_max(self, value: float) -> float:
-        import torch
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(self._exchange(float(value), max))
 
     def close(self):
-        if self._dist.is_initialized():
-            self._dist.destroy_process_group()
+        for conn in self._peers.values():
+            conn.close()
+        self._peers = {}
+        if self._sock is not None:
+            self._sock.close()
+            self._sock = None
+        if self._server is not None:
+            self._server.close()
+            self._server = None
+            try:
+                os.remove(self._rdv)
+            except OSError:
+                pass
+
+
+def launch_ranks(argv, world, master_port=None, env=None):
+    """Start `world` fresh processes of `argv` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT exported, as
+    `python -m torch.distributed.run` would) and wait for them.  The caller must not have touched the GPU.  Returns the first
+    non-zero exit code (the remaining ranks are then terminated), or 0."""
+    import subprocess
+    if master_port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            master_port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        e = dict(os.environ if env is None else env)
+        e.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
+                  'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(master_port)})
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # RCCL across processes needs dmabuf IPC on this driver
+        procs.append(subprocess.Popen(list(argv), env=e))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 class BatchShardComm:

@@ -94,8 +94,18 @@ def test_conv_pointwise_16byte_gather_variant(hip, monkeypatch):
 def test_mfma_ceiling_probe_reports_a_plausible_rate(hip):
     """bench.py's roofline.sustained: fp32 MFMA alone is below the 157.3 TFLOP/s of 2.4 GHz and far above any convolution here; a
     VALU-only wave beside every MFMA wave takes a visible share away (the two do not overlap on a SIMD)."""
-    alone = max(hip.mfma_ceiling_f32(False, 4000) for _ in range(3))
-    shared = max(hip.mfma_ceiling_f32(True, 4000) for _ in range(2))
+    import ctypes
+    lib = hip.load_library()             # this process runs on the diagnostic build (PVHIP_LIBRARY), which exports the probe
+    lib.pvhip_mfma_ceiling_f32.restype = ctypes.c_int
+    lib.pvhip_mfma_ceiling_f32.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+
+    def probe(partner, iters):
+        tf, ghz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        assert lib.pvhip_mfma_ceiling_f32(int(partner), iters, ctypes.byref(tf), ctypes.byref(ghz)) == 0
+        return tf.value, ghz.value
+
+    alone = max(probe(False, 4000) for _ in range(3))
+    shared = max(probe(True, 4000) for _ in range(2))
     assert 90.0 < alone[0] < 158.0 and 1.2 < alone[1] < 2.6, alone
     assert shared[0] < 0.85 * alone[0], (alone, shared)
 

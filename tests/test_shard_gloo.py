@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: two processes, torch.distributed (gloo), each running the unchanged scheduler on its
-batch shard with the product Result plugin gathering the shards (host path of BatchShardComm; on GPUs the same
-call goes through RCCL).  The per-node numerics here are the oracle plugins -- this test is about the shard /
-gather logic, not the kernels."""
+"""N > 1 path on CPU: two processes, each running the unchanged scheduler on its batch shard with the product Result
+plugin gathering the shards (host path of BatchShardComm; on GPUs the same call goes through RCCL).  The host group is
+the product's own `shard.TcpGroup` (plain sockets, no torch in the package) and, beside it, torch.distributed's gloo
+backend behind the same HostGroup protocol (`GlooGroup` below: test-only, what rounds 1-3 shipped as TorchGroup).  The
+per-node numerics here are the oracle plugins -- this test is about the shard / gather logic, not the kernels."""
 import os
 import socket
 import sys
@@ -12,6 +13,43 @@ import pytest
 import helpers
 
 
+class GlooGroup:
+    """The HostGroup protocol over torch.distributed (gloo): rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        dist.init_process_group(backend='gloo')
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def broadcast_bytes(self, data, src=0):
+        box = [data if self.rank == src else None]
+        self._dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def allgather_array(self, arr):
+        parts = [None] * self.world
+        self._dist.all_gather_object(parts, np.ascontiguousarray(arr))
+        return parts
+
+    def allreduce_max(self, value):
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self._dist.destroy_process_group()
+
+
+def _group(kind):
+    from pyopenvino_amd import shard
+    return GlooGroup() if kind == 'gloo' else shard.TcpGroup(timeout=120)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -20,13 +58,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, total, out_dir):
+def _worker(rank, world, port, total, out_dir, kind):
     os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
                        'LOCAL_RANK': str(rank)})
     sys.path.insert(0, helpers.REPO)
     import importlib
     from pyopenvino_amd import IECore, shard, synth
-    group = shard.TorchGroup('gloo')
+    group = _group(kind)
     comm = shard.BatchShardComm(group, use_rccl=False)
     lo, hi = comm.shard(total)
     ie = IECore(plugin_package='oracle.op_plugins')
@@ -43,17 +81,19 @@ def _worker(rank, world, port, total, out_dir):
     for r in (1, 0):
         assert np.array_equal(ex.wait(r)[net.outputs[0]['name']], out)
     t = group.allreduce_max(float(rank + 1))
+    assert group.broadcast_bytes(b'id' * 64 if rank == 0 else None, src=0) == b'id' * 64      # (how the RCCL unique id travels)
+    assert [int(a[0]) for a in group.allgather_array(np.array([rank * 7]))] == [0, 7]
     group.barrier()
     np.save(os.path.join(out_dir, 'rank{}.npy'.format(rank)), out)
     assert t == float(world)
     group.close()
 
 
-@pytest.mark.parametrize('total', [6, 5])
-def test_two_rank_batch_shard_and_gather(tmp_path, total):
+@pytest.mark.parametrize('kind,total', [('tcp', 6), ('tcp', 5), ('gloo', 6), ('gloo', 5)])
+def test_two_rank_batch_shard_and_gather(tmp_path, kind, total):
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path), kind), nprocs=world, join=True)
     from pyopenvino_amd import synth
     x = np.concatenate([synth.uniform_pixels(300 + i, (1, 1, 28, 28)) for i in range(total)], 0)
     _, net, ex = helpers.build_network('oracle.op_plugins', 'mnist', batch=total)
@@ -64,13 +104,13 @@ def test_two_rank_batch_shard_and_gather(tmp_path, total):
         helpers.assert_close(got, want, 1e-6, 'rank {} gathered batch'.format(r))
 
 
-def _fallback_worker(rank, world, port, out_dir):
+def _fallback_worker(rank, world, port, out_dir, kind):
     os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
                        'LOCAL_RANK': str(rank)})
     os.environ.pop('PVHIP_NO_RCCL', None)
     sys.path.insert(0, helpers.REPO)
     from pyopenvino_amd import shard
-    group = shard.TorchGroup('gloo')
+    group = _group(kind)
     comm = shard.BatchShardComm(group)              # use_rccl: the communicator cannot be made here (no GPU)
     assert comm.use_rccl
     path, err = comm.agree_on_gather()
@@ -82,7 +122,8 @@ def _fallback_worker(rank, world, port, out_dir):
     group.close()
 
 
-def test_every_rank_agrees_on_the_host_gather_when_rccl_is_unavailable(tmp_path):
+@pytest.mark.parametrize('kind', ['tcp', 'gloo'])
+def test_every_rank_agrees_on_the_host_gather_when_rccl_is_unavailable(tmp_path, kind):
     """bench.py's N > 1 branch without GPUs: no rank can create the communicator, all of them learn it through the host
     group, switch to the host gather together and say so; the gather then still returns every rank's rows."""
     from pyopenvino_amd import device
@@ -90,7 +131,7 @@ def test_every_rank_agrees_on_the_host_gather_when_rccl_is_unavailable(tmp_path)
         pytest.skip('a GPU is visible here: the communicator can be created')
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
-    mp.spawn(_fallback_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_fallback_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
     for r in range(world):
         path, use_rccl, rows, ranks = open(os.path.join(str(tmp_path), 'rank{}.txt'.format(r))).read().split('\n')[:4]
         assert path.startswith('host group (RCCL communicator unavailable') and use_rccl == '0' and rows == '5' and ranks == '0'
@@ -186,3 +227,59 @@ def test_row_counts_never_depend_on_a_rank_local_cache():
     comm = shard.BatchShardComm(g, use_rccl=False)
     assert comm.row_counts(3) == [4, 3] and comm.row_counts(3) == [4, 3] and comm.row_counts(4) == [4, 4]
     assert g.exchanges == 3
+
+
+def test_tcp_group_survives_a_stale_rendezvous_file(tmp_path):
+    """A rendezvous file left behind by an earlier run (dead port, other token) does not mislead rank 1: it keeps reading the file
+    until this run's rank 0 has published itself.  Three ranks as threads of one process."""
+    import threading
+    from pyopenvino_amd import shard
+    rdv = str(tmp_path / 'rdv')
+    with open(rdv, 'w') as f:
+        f.write('127.0.0.1 {} stale-token\n'.format(_free_port()))
+    out, errs = {}, []
+
+    def run(rank, delay):
+        try:
+            import time
+            time.sleep(delay)
+            g = shard.TcpGroup(rank=rank, world=3, timeout=60, rdv_file=rdv)
+            out[rank] = (g.allreduce_max(float(rank)), [int(a[0]) for a in g.allgather_array(np.array([10 + rank]))],
+                         g.broadcast_bytes(b'x' if rank == 2 else None, src=2))
+            g.barrier()
+            g.close()
+        except Exception as exc:      # noqa: BLE001
+            errs.append((rank, exc))
+
+    threads = [threading.Thread(target=run, args=(r, 0.3 if r == 0 else 0.0)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(90)
+    assert not errs, errs
+    assert all(out[r] == (2.0, [10, 11, 12], b'x') for r in range(3)), out
+    assert not os.path.exists(rdv)
+
+
+def test_launch_ranks_exports_the_launcher_contract_and_reports_failures(tmp_path):
+    """shard.launch_ranks (what `bench.py --gpus N` uses when it was not started by torch.distributed.run): every child sees RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_*; a failing rank makes the launch fail and the others are ended."""
+    from pyopenvino_amd import shard
+    script = tmp_path / 'child.py'
+    script.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, {!r})\n"
+        "from pyopenvino_amd import shard\n"
+        "g = shard.TcpGroup(timeout=60)\n"
+        "assert g.world == int(os.environ['WORLD_SIZE']) == 2 and g.rank == int(os.environ['LOCAL_RANK'])\n"
+        "assert g.allreduce_max(float(g.rank)) == 1.0\n"
+        "open(os.path.join({!r}, 'ok%d' % g.rank), 'w').close()\n"
+        "g.barrier(); g.close()\n"
+        "if len(sys.argv) > 1 and g.rank == 1: sys.exit(3)\n"
+        "if len(sys.argv) > 1: time.sleep(30)\n".format(helpers.REPO, str(tmp_path)))
+    assert shard.launch_ranks([sys.executable, str(script)], 2) == 0
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('ok')) == ['ok0', 'ok1']
+    import time
+    t0 = time.time()
+    assert shard.launch_ranks([sys.executable, str(script), 'fail'], 2) == 3
+    assert time.time() - t0 < 25            # rank 0 did not sleep its 30 s out
