@@ -327,3 +327,40 @@ def test_no_inline_asm_statement_loads_into_a_register(tmp_path):
     ok = 'asm volatile("s_mov_b32 m0, %0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m), "v"(v), "s"(r), "s"(o) : "memory");'
     inst = [i for _, code in mod.asm_statements(ok) for i in code.split('\n')]
     assert any('lds' in i for i in inst)
+
+
+def test_expected_result_hook_takes_the_references_golden_dict(capsys):
+    """Executable_Network.expected_result in the reference's own format, {node name: [precision, dims, ndarray]} (it reads
+    GT[name][2]: common_def.py:76, called from inference_engine.py:284-287), and as bare arrays; a node without an entry is not
+    reported by run_tasks (inference_engine.py:285), compare_results itself prints 'Skipped' (common_def.py:73-75)."""
+    from pyopenvino_amd import common_def, synth
+    _, net, ex = helpers.build_network('oracle.op_plugins', 'mnist', batch=1)
+    x = synth.uniform_pixels(77, (1, 1, 28, 28))
+    helpers.infer_one(ex, net, x)
+    G = net.G
+    gt = {}
+    for nid in G.nodes:
+        node = G.nodes[nid]
+        if node['type'] in ('Convolution', 'MaxPool', 'SoftMax'):
+            port = next(iter(node['output'].values()))
+            gt[node['name']] = [port['precision'], port['dims'], np.array(np.asarray(port['data']), copy=True)]
+    assert len(gt) >= 5
+    ex.expected_result = gt
+    capsys.readouterr()
+    helpers.infer_one(ex, net, x)
+    out = capsys.readouterr().out
+    assert out.count('\x1b[32m') == len(gt) and '\x1b[31m' not in out
+    wrong = next(iter(gt))
+    gt[wrong] = [gt[wrong][0], gt[wrong][1], gt[wrong][2] * -3.0 + 1.0]
+    ex.expected_result = {k: (v if k == wrong else v[2]) for k, v in gt.items()}      # bare arrays are taken too
+    helpers.infer_one(ex, net, x)
+    out = capsys.readouterr().out
+    assert out.count('\x1b[31m') == 1 and out.count('\x1b[32m') == len(gt) - 1 and '\x1b[31m' + wrong in out
+    assert common_def.compare_results('no such node', np.zeros(3), gt) is None and 'Skipped' in capsys.readouterr().out
+    # the other debug helpers of the reference's common_def (:60-67, :109-126)
+    common_def.disp_result(np.arange(8, dtype=np.float32).reshape(1, 2, 2, 2))
+    out = capsys.readouterr().out
+    assert out.count('C=') == 2 and ' 7.000,' in out
+    common_def.dump_graph(G)
+    out = capsys.readouterr().out
+    assert out.count('node id=') == len(G.nodes) and out.count('edge_id=') == len(G.edges)
