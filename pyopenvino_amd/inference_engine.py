@@ -342,6 +342,53 @@ class InferRequest:
         return self.wait()
 
 
+class CaptureStreamModel:
+    """What ROCm 7.2's runtime keeps per stream while a multi-stream hipGraph recording is open, restated from the disassembly of
+    its hipStreamWaitEvent / Stream::EndCapture (libamdhip64.so.7.2.70200 +0x2f63b9 / +0x2df7f0; profiles/r04_capture.md).
+
+    When a stream W that is not the origin of the capture waits for an event recorded on stream E, and E's current parent is not
+    W, the runtime sets parent(W) = E and appends W to E's list of parallel streams (once) -- on EVERY such wait, not only on the
+    one that makes W join.  hipStreamEndCapture then walks those lists recursively from the origin and clears them on the way
+    back.  The parent test stops a 2-cycle only while E's parent still IS W; after E has waited for a third stream in between,
+    W <-> E (or a longer ring) closes, the walk never returns and the process dies of stack overflow inside hipStreamEndCapture
+    (what DESIGN lesson 30 filed as "crashes inside the runtime").  The origin never registers anywhere, so a dependency that
+    would close a ring is RELAYED through it: the origin waits for E's event, records a fresh one, W waits for that."""
+
+    def __init__(self):
+        self.parent = {}        # non-origin stream -> stream of the event it last registered under
+        self.lists = {}         # stream -> streams in its parallel-capture list
+
+    def _reaches(self, src, dst):
+        todo, seen = [src], set()
+        while todo:
+            cur = todo.pop()
+            if cur == dst:
+                return True
+            if cur not in seen:
+                seen.add(cur)
+                todo.extend(self.lists.get(cur, ()))
+        return False
+
+    def wait(self, waiter: int, event_stream: int) -> str:
+        """Stream `waiter` is about to wait for an event recorded on `event_stream` (0 = the origin).  'plain': issue the wait;
+        'relay': it would close a ring in the runtime's lists -- go through the origin (the bookkeeping of the relay's own two
+        waits is applied here)."""
+        if waiter == 0 or waiter == event_stream:
+            return 'plain'                              # the origin registers nowhere
+        if self.parent.get(event_stream) == waiter:
+            return 'plain'                              # the runtime's own test: nothing is registered
+        if event_stream != 0 and self._reaches(waiter, event_stream):
+            self.parent[waiter] = 0                     # relayed: origin waits (registers nothing), waiter waits for the origin's event
+            self.lists.setdefault(0, set()).add(waiter)
+            return 'relay'
+        self.parent[waiter] = event_stream
+        self.lists.setdefault(event_stream, set()).add(waiter)
+        return 'plain'
+
+    def has_ring(self) -> bool:
+        return any(self._reaches(w, s) for s, ws in self.lists.items() for w in ws)
+
+
 class Executable_Network:
     def __init__(self, ienetwork: IENetwork):
         self.ienet = ienetwork
@@ -763,6 +810,26 @@ class Executable_Network:
         self._stream_plans[key] = plan
         return plan
 
+    def recorded_waits(self):
+        """The cross-stream waits a RECORDING of the current plan makes, in dispatch order, as (how, waiting stream, event's stream,
+        producer task) with how = 'plain' | 'relay' (CaptureStreamModel) -- what _dispatch_tasks issues while a capture is open,
+        computed from the plan alone (no device)."""
+        plan = self.plan_streams()
+        if plan is None:
+            return [], CaptureStreamModel()
+        stream_of, waits, _ = plan
+        model, out = CaptureStreamModel(), []
+        for task in self.task_list:
+            if task in self._fused_away or task not in stream_of:
+                continue
+            for dep in waits[task]:
+                out.append((model.wait(stream_of[task], stream_of[dep]), stream_of[task], stream_of[dep], dep))
+        return out, model
+
+    def recording_rings(self) -> bool:
+        """True when a recording of the current plan would leave a ring in the runtime's parallel-stream lists."""
+        return self.recorded_waits()[1].has_ring()
+
     def run_tasks(self, verbose: bool = False):
         G = self.ienet.G
         registry = self.ienet.ie.plugins.plugins
@@ -809,6 +876,8 @@ class Executable_Network:
             held = self.__dict__.setdefault('_events_in_flight', [])
             base = self.stream_base
             epoch = self._open_epoch
+            cap_model = CaptureStreamModel() if self.__dict__.get('_recording') else None
+            ops = self.__dict__.get('_stream_ops')      # tests: the cross-stream waits of the pass as they are issued
         for task in self.task_list:
             if task in self._fused_away:
                 continue
@@ -819,7 +888,18 @@ class Executable_Network:
                     current = stream_of[task]
                     device.select_stream(base + current)
                 for dep in waits[task]:
-                    done_events[dep].wait()
+                    how = cap_model.wait(current, stream_of[dep]) if cap_model is not None else 'plain'
+                    if ops is not None:
+                        ops.append((how, current, stream_of[dep], dep))
+                    if how == 'relay':                   # (a recording only: see CaptureStreamModel)
+                        device.select_stream(base)
+                        done_events[dep].wait()
+                        relay = (spare.pop() if spare else device.Event(timed=False)).record()
+                        device.select_stream(base + current)
+                        relay.wait()
+                        held.append(relay)
+                    else:
+                        done_events[dep].wait()
             pooled_in = self._pool_conv.get(task)
             if pooled_in is not None:        # the folded MaxPool hands its own input on: the kernel pools while it builds its tile
                 pool_id, _ = pooled_in
@@ -942,10 +1022,10 @@ class Executable_Network:
         ONE call instead of ~100 dispatches.  The graph holds the addresses of every tensor of the pass: they are kept alive with it
         (`release_graph`).  `streams` = 1 (default): the pass is recorded on one compute stream, a linear chain of launches -- with the
         persistent-grid kernels of this build that replays as fast as the forked form (googlenet-v1 batch 256: 44.5 k images/s either
-        way, scripts/time_replay.py).  `streams='plan'`: recorded as the stream plan forks it (`compute_streams`); hipStreamEndCapture of
-        ROCm 7.2 CRASHES (inside the runtime, not catchable) for some plans that use three or four streams -- the unfused GoogLeNet, the
-        FP16 one, the SSD IR (scripts/repro_capture.py) -- while the fused GoogLeNet plan records fine: use it only for a plan that has
-        been tried."""
+        way, scripts/time_replay.py).  `streams='plan'`: recorded as the stream plan forks it (`compute_streams`).  Until round 4 that
+        killed the process for some plans (stack overflow inside hipStreamEndCapture of ROCm 7.2: its walk over the per-stream lists of
+        parallel capture streams meets a ring when non-origin streams wait for each other in both directions over time,
+        profiles/r04_capture.md); the dispatcher now relays the ring-closing waits through the origin stream (CaptureStreamModel)."""
         if streams != 'plan':
             saved_streams = self.compute_streams
             self.compute_streams = max(1, int(streams))
@@ -968,16 +1048,19 @@ class Executable_Network:
             G.nodes[nid]['comm'] = None
             G.nodes[nid]['_async'] = True       # the Result stays on the device: infer_graph() reads it back
         saved_timing, self.device_timing = self.device_timing, None
+        if self.recording_rings():              # (cannot happen with the relays in place: refuse before any HIP call, never crash)
+            raise device.PvhipError('capture_graph: this stream plan would close a ring in the runtime\'s parallel-stream lists '
+                                    '(hipStreamEndCapture of ROCm 7.2 never returns from it); record on one stream')
         device.select_stream(self.stream_base)
         device.call('pvhip_graph_begin_capture')
         handle = ctypes_void_p()
         first_error = None
         try:
-            self.defer_sync = True
+            self.defer_sync = self._recording = True
             try:
                 self.run_tasks(False)
             finally:
-                self.defer_sync = False
+                self.defer_sync = self._recording = False
                 self.device_timing = saved_timing
                 for nid, _ in results:
                     G.nodes[nid].pop('_async', None)

@@ -87,16 +87,14 @@ def main():
     so = os.path.join(tempfile.gettempdir(), 'segv_trace.so')
     rc = subprocess.run(['gcc', '-shared', '-fPIC', '-O1', '-o', so, os.path.join(REPO, 'scripts', 'diag', 'segv_trace.c')]).returncode
     preload = so if rc == 0 else None
-    budget = 14                                  # cases in all
-    for kind, streams in (('fp32', 3), ('fp16', 3), ('ssd', 2)):
+    budget = 22                                  # cases in all
+    for kind, streams, n_tasks in (('fp32-unfused', 3, 323), ('fp16', 4, 173), ('ssd', 4, 284)):
         if budget <= 0:
             break
         budget -= 1
         if run(kind, streams, 0, preload):
             continue
-        if kind != 'fp16':
-            continue
-        lo, hi = 1, 173                          # bisect on the FP16 plan (the one closest to the fused fp32 plan that records fine)
+        lo, hi = 1, n_tasks                      # bisect: the shortest prefix of the plan whose recording crashes
         while hi - lo > 1 and budget > 0:
             mid = (lo + hi) // 2
             budget -= 1
@@ -104,7 +102,7 @@ def main():
                 lo = mid
             else:
                 hi = mid
-        print('fp16: the first {} dispatched tasks record, the first {} crash'.format(lo, hi), flush=True)
+        print('{} on {} streams: the first {} dispatched tasks record, the first {} crash'.format(kind, streams, lo, hi), flush=True)
 
 
 if __name__ == '__main__':

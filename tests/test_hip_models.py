@@ -466,6 +466,57 @@ def test_hipgraph_replay_of_a_forward_pass_is_bit_identical(hip, model, shape, s
     helpers.assert_bit_exact(infer_one(ex, net, d2), want2, 'eager pass after the graph is gone')
 
 
+@pytest.mark.parametrize('kind,streams', [('unfused', 3), ('ssd', 4), ('fp16', 4), ('unfused', 4)])
+def test_forked_recordings_that_used_to_kill_the_process_replay_the_eager_bits(hip, kind, streams):
+    """capture_graph(streams='plan') on the plans whose recording ended in a stack overflow inside hipStreamEndCapture (ROCm 7.2:
+    its recursive walk over the per-stream lists of parallel capture streams meets a ring when non-origin streams wait for each
+    other in both directions over time; DESIGN lesson 30 rewritten, profiles/r04_capture.md): the dispatcher relays the
+    ring-closing waits through the origin stream while it records, the recording is made, and its replay gives the bits of the
+    eager pass.  The waits issued are the ones Executable_Network.recorded_waits() predicts from the plan."""
+    import tempfile
+    from pyopenvino_amd import IECore, synth
+    ie = IECore(plugin_package=HIP)
+    B = 8
+    if kind == 'ssd':
+        xml = os.path.join(helpers.MODELS, 'ssd_mobilenet_v1_coco.xml')
+        net = ie.read_network(xml, weights=synth.synth_weights(xml, 1234))
+        shape = (B, 3, 300, 300)
+    else:
+        xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+        blob = synth.synth_weights(xml, 1234)
+        shape = (B, 3, 224, 224)
+        if kind == 'fp16':
+            with tempfile.TemporaryDirectory() as tmp:
+                xml16, blob16 = synth.fp16_ir(xml, blob, tmp)
+                net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+        else:
+            net = ie.read_network(xml, weights=blob)
+    net.set_batch(B)
+    ex = ie.load_network(net)
+    if kind == 'unfused':
+        ex.fuse_epilogues = False
+        ex.plan_fusion()
+    ex.compute_streams = streams
+    x = hip.DeviceTensor.from_numpy(synth.uniform_pixels(5, shape))
+    name = net.inputs[0]['name']
+    want = {k: np.array(np.asarray(v), copy=True) for k, v in ex.infer({name: x}).items()}
+    predicted, _ = ex.recorded_waits()
+    assert (kind == 'fp16') == (not any(how == 'relay' for how, *_ in predicted))       # the FP16 plan needs no relay, the others do
+    ex._stream_ops = []
+    try:
+        ex.capture_graph({name: x}, streams='plan')
+        issued = list(ex._stream_ops)
+    finally:
+        del ex._stream_ops
+    assert issued[-len(predicted):] == predicted        # (capture_graph's warm-up passes come first: eager, every wait plain)
+    assert all(how == 'plain' for how, *_ in issued[:-len(predicted)])
+    for _ in range(2):
+        got = ex.infer_graph()
+        for k in want:
+            helpers.assert_bit_exact(np.asarray(got[k]), want[k], 'replay of the forked recording: {}'.format(k))
+    ex.release_graph()
+
+
 def test_pickle_node_args_from_a_fused_device_pass_replays_through_the_oracle(hip, tmp_path):
     """The reference's node-replay hook on the product path: a Convolution that runs fused (bias + ReLU in its epilogue, device
     tensors in and out) is dumped as the plain IR node with host ndarrays, and replaying the file through the oracle's plugin

@@ -364,3 +364,93 @@ def test_expected_result_hook_takes_the_references_golden_dict(capsys):
     common_def.dump_graph(G)
     out = capsys.readouterr().out
     assert out.count('node id=') == len(G.nodes) and out.count('edge_id=') == len(G.edges)
+
+
+def _runtime_lists_after(waits_issued):
+    """ROCm 7.2's bookkeeping for a sequence of (waiting stream, event's stream) waits inside one capture whose origin is stream 0,
+    restated independently of the engine's CaptureStreamModel from the disassembly (profiles/r04_capture.md): a non-origin waiter
+    whose event stream's parent is not the waiter itself gets parent = event stream and is appended to that stream's list.
+    Returns True when hipStreamEndCapture's recursive walk over the lists, started at the origin, would never end."""
+    parent, lists = {}, {}
+    for waiter, ev in waits_issued:
+        if waiter == 0 or parent.get(ev) == waiter:
+            continue
+        parent[waiter] = ev
+        if waiter not in lists.setdefault(ev, []):
+            lists[ev].append(waiter)
+    on_path = set()
+
+    def walk(sid):
+        if sid in on_path:
+            return True
+        on_path.add(sid)
+        ring = any(walk(c) for c in lists.get(sid, []))
+        on_path.discard(sid)
+        return ring
+
+    return walk(0)
+
+
+def test_multi_stream_recordings_never_close_a_ring_in_the_runtimes_stream_lists():
+    """VERDICT r3 item 2.  hipStreamEndCapture died (stack overflow in its recursive walk) exactly for the plans whose raw waits
+    close a ring in the runtime's parallel-stream lists -- the unfused GoogLeNet on three streams and the SSD IR on four (gpurun_out
+    of round 4: scripts/capture_probe.py) -- and recorded fine for the plans that do not (fused GoogLeNet, its FP16 form, the SSD IR
+    on two or three streams).  The model reproduces that split from the plans alone, and with the relays through the origin that
+    _dispatch_tasks issues while recording, no plan closes a ring.  Also: every forked stream is joined back into the origin
+    before the capture ends, and no wait refers to an event of an earlier pass."""
+    import tempfile
+    from pyopenvino_amd import IECore, synth
+    from pyopenvino_amd.inference_engine import CaptureStreamModel
+
+    def network(kind):
+        ie = IECore(plugin_package='pyopenvino_amd.op_plugins')
+        if kind == 'mnist':
+            net = ie.read_network(os.path.join(MODELS, 'mnist.xml'))
+        elif kind == 'ssd':
+            xml = os.path.join(MODELS, 'ssd_mobilenet_v1_coco.xml')
+            net = ie.read_network(xml, weights=synth.synth_weights(xml, 1234))
+        else:
+            xml = os.path.join(MODELS, 'googlenet-v1.xml')
+            blob = synth.synth_weights(xml, 1234)
+            if kind == 'fp16':
+                with tempfile.TemporaryDirectory() as tmp:
+                    xml16, blob16 = synth.fp16_ir(xml, blob, tmp)
+                    net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+            else:
+                net = ie.read_network(xml, weights=blob)
+        net.set_batch(8)
+        ex = ie.load_network(net)
+        if kind == 'unfused':
+            ex.fuse_epilogues = False
+            ex.plan_fusion()
+        return ex
+
+    observed = {('unfused', 3): True, ('ssd', 4): True, ('fused', 3): False, ('fp16', 3): False, ('fp16', 4): False,
+                ('ssd', 2): False, ('ssd', 3): False}           # True: hipStreamEndCapture crashed on the GPU box (raw waits)
+    for kind in ('mnist', 'fused', 'unfused', 'fp16', 'ssd'):
+        ex = network(kind)
+        for streams in (2, 3, 4):
+            ex.compute_streams = streams
+            ex._stream_plans = {}
+            plan = ex.plan_streams()
+            stream_of, waits, records = plan
+            raw = [(stream_of[t], stream_of[d]) for t in ex.task_list if t in stream_of and t not in ex._fused_away for d in waits[t]]
+            if (kind, streams) in observed:
+                assert _runtime_lists_after(raw) == observed[(kind, streams)], (kind, streams)
+            issued, model = ex.recorded_waits()
+            assert [(w, e) for _, w, e, _ in issued] == raw
+            as_issued = []
+            for how, w, e, _ in issued:
+                as_issued += [(0, e), (w, 0)] if how == 'relay' else [(w, e)]
+            assert not _runtime_lists_after(as_issued) and not model.has_ring() and not ex.recording_rings(), (kind, streams)
+            assert any(how == 'relay' for how, *_ in issued) == _runtime_lists_after(raw), (kind, streams)     # relays only where needed
+            # every event waited for was recorded earlier in the SAME pass, by a task on another stream
+            position = {t: i for i, t in enumerate(ex.task_list)}
+            for t in stream_of:
+                for d in waits[t]:
+                    assert d in records and position[d] < position[t] and stream_of[d] != stream_of[t]
+            # the pass ends with a join of every stream the plan uses on the origin (run_tasks: `joins`), so no forked stream is left open
+            assert set(stream_of.values()) <= set(range(streams)) and 0 in set(stream_of.values())
+    m = CaptureStreamModel()        # the smallest ring: 2 registers under 1, re-forks from the origin, then 1 waits for 2
+    assert [m.wait(2, 1), m.wait(2, 0), m.wait(1, 2)] == ['plain', 'plain', 'relay'] and not m.has_ring()
+    assert _runtime_lists_after([(2, 1), (2, 0), (1, 2)]) and not _runtime_lists_after([(2, 1), (1, 2)])
