@@ -293,6 +293,52 @@ def test_requests_with_device_resident_inputs_replay_their_own_recordings(hip, m
     assert np.array_equal(ex.infer({name: xs_host[1]})[out_name], want[1])      # the synchronous call on the same network afterwards
 
 
+def test_eight_requests_of_batch_256_replayed_side_by_side_match_the_reference_and_the_eager_bits(hip):
+    """The exact shape bench.py times: 8 requests x batch 256, each replaying its own hipGraph with the seven others in flight
+    (lesson 24: wrong images showed ONLY at batch 256 next to other streams).  Rows 0-7 of request 0 are the reference's own
+    N=1 answers (googlenet_rows8.npz); every request's replayed Result equals, bit for bit, one eager synchronous infer() of the
+    same tensor -- in three rounds with changing start orders."""
+    from pyopenvino_amd import IECore, synth, device
+    z = np.load(os.path.join(GOLDEN, 'googlenet_rows8.npz'))
+    xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    blob = synth.synth_weights(xml, int(z['weight_seed']))
+    B, R = 256, 8
+    ie = IECore(plugin_package=HIP)
+    net = ie.read_network(xml, weights=blob)
+    net.set_batch(B)
+    ex = ie.load_network(net, 'GPU', num_requests=R)
+    name, out_name = net.inputs[0]['name'], net.outputs[0]['name']
+    xs = []
+    for r in range(R):
+        x = synth.uniform_pixels(9000 + r, (B, 3, 224, 224))
+        if r == 0:
+            for i, sd in enumerate(z['image_seeds']):
+                x[i] = synth.uniform_pixels(int(sd), (1, 3, 224, 224))[0]
+        xs.append(device.DeviceTensor.from_numpy(x))
+        del x
+    for rnd_ in range(4):                               # two eager passes, the third records, then replays
+        for r in range(R):
+            ex.start_async(r, {name: xs[r]})
+        outs = [np.array(ex.wait(r)[out_name], copy=True) for r in range(R)]
+    assert all(req.runner.__dict__.get('_graph') is not None for req in ex.requests)
+    for rnd_ in range(3):
+        order = [(r * 3 + rnd_) % R for r in range(R)]
+        for r in order:
+            ex.start_async(r, {name: xs[r]})
+        for r in reversed(order):
+            got = ex.wait(r)[out_name]
+            assert np.array_equal(got, outs[r]), 'round {} request {}'.format(rnd_, r)
+    assert_close(outs[0][:8], z['out'], helpers.REL_TOL, 'request 0 rows 0-7 vs the reference')
+    os.environ['PVHIP_AUTO_GRAPH'] = '0'
+    try:
+        for r in range(R):
+            eager = ex.requests[r].infer({name: xs[r]})[out_name]
+            assert np.array_equal(np.asarray(eager), outs[r]), 'request {}: replay differs from the eager pass'.format(r)
+            assert np.isfinite(outs[r]).all() and np.allclose(outs[r].sum(axis=1), 1.0, atol=2e-5)
+    finally:
+        os.environ.pop('PVHIP_AUTO_GRAPH')
+
+
 def test_rccl_binding_single_rank(hip):
     """The RCCL path of the C ABI (dlopen, unique id, communicator, all-gather, destroy) with one rank:
     exercises every call the multi-GPU Result gather makes; with world == 1 the gather is a device copy."""

@@ -454,3 +454,31 @@ def test_multi_stream_recordings_never_close_a_ring_in_the_runtimes_stream_lists
     m = CaptureStreamModel()        # the smallest ring: 2 registers under 1, re-forks from the origin, then 1 waits for 2
     assert [m.wait(2, 1), m.wait(2, 0), m.wait(1, 2)] == ['plain', 'plain', 'relay'] and not m.has_ring()
     assert _runtime_lists_after([(2, 1), (2, 0), (1, 2)]) and not _runtime_lists_after([(2, 1), (1, 2)])
+
+
+def test_locality_order_is_another_legal_list_schedule(monkeypatch):
+    """order_for_locality (round 4): behind a module's sibling launch come MaxPool + pool_proj (same input tensor as the launch), then
+    the other arms by ascending output size (5x5, 3x3).  Still a permutation of the reference's list schedule and a topological
+    order of the whole graph; PVHIP_SCHEDULE_LOCALITY=0 and the unfused plan keep the reference's order."""
+    _, net, ex = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=True)
+    G = net.G
+    assert sorted(ex.task_list) == sorted(ex.list_schedule) and ex.task_list != ex.list_schedule
+    pos = {t: i for i, t in enumerate(ex.task_list)}
+    assert all(pos[a] < pos[b] for a, b in G.edges)
+    by_name = {G.nodes[n]['name']: n for n in G.nodes}
+    dispatched = [G.nodes[t]['name'] for t in ex.task_list if t not in ex._fused_away and G.nodes[t]['type'] == 'Convolution']
+    for mod in ('3a', '3b', '4a', '4b', '4c', '4d', '4e'):
+        at = dispatched.index('inception_{}/1x1/WithoutBiases'.format(mod))
+        assert dispatched[at + 1:at + 4] == ['inception_{}/{}/WithoutBiases'.format(mod, arm) for arm in ('pool_proj', '5x5', '3x3')], mod
+    for mod in ('5a', '5b'):            # 7x7 modules: the MaxPool is a launch of its own and pool_proj stays behind it
+        at = dispatched.index('inception_{}/1x1/WithoutBiases'.format(mod))
+        assert dispatched[at + 1:at + 4] == ['inception_{}/{}/WithoutBiases'.format(mod, arm) for arm in ('5x5', '3x3', 'pool_proj')], mod
+    monkeypatch.setenv('PVHIP_SCHEDULE_LOCALITY', '0')
+    ex.plan_fusion()
+    assert ex.task_list == ex.list_schedule
+    monkeypatch.delenv('PVHIP_SCHEDULE_LOCALITY')
+    ex.plan_fusion()
+    assert ex.task_list != ex.list_schedule
+    ex.fuse_epilogues = False
+    ex.plan_fusion()
+    assert ex.task_list == ex.list_schedule
