@@ -37,6 +37,9 @@ int pvhip_diag_pw_stamps(unsigned long long* out);
  * ticket counter is reset), and its s_memtime stamps (64 counters; cleared).                                                        */
 int pvhip_diag_wino4_hw(unsigned* out);
 int pvhip_diag_wino4_stamps(unsigned long long* out);
+int pvhip_diag_wino4s_stamps(unsigned long long* out);
+int pvhip_diag_wino4s_simd(unsigned long long* out);
+int pvhip_diag_wino4s_trace(unsigned* out);                  /* workgroup 3 of the last launch: [wave][stage < 96][saw the image / finished] in cycles since its start */        /* the same workgroups: 16 waves x 4 SIMDs, how often wave w ran on SIMD s */      /* conv_wino4s_kernel (shared-V form): 16 waves x 8 cycle accounts, read and cleared */
 /* the same run's epilogue phases: [wave 0..7][write 0, barrier, read + store 0, barrier, write 1, barrier, read + store 1, barrier]  */
 int pvhip_diag_wino4_epilogue(unsigned long long* out);
 

@@ -56,6 +56,11 @@ struct Settings {
     int  wino_waves = 8;                   // PVHIP_WINO_WAVES=4
     bool wino_ragged = true;               // PVHIP_WINO_RAGGED=0: the six-point Winograd kernel only where the extents are multiples of its patch (A/B runs)
     bool wino_balance = true;              // PVHIP_WINO_BALANCE=0: fixed producer waves in the six-point Winograd kernel (A/B runs)
+    int  wino_shared = 1;                  // PVHIP_WINO_SHARED=0|1|2: the shared-V form of the six-point kernels never / by the tile rule / wherever it applies
+    int  wino_shared_prio = 1;             // PVHIP_WINO_SHARED_PRIO=0: no wave priorities in the shared-V form (A/B runs)
+    int  wino_shared_old = 1;              // PVHIP_WINO_SHARED_OLD=0: the producers of the shared-V form are the youngest waves (A/B runs)
+    int  wino_shared_lag = 1;              // PVHIP_WINO_SHARED_LAG=0: both consumer groups of the shared-V form start together (A/B runs)
+    int  wino_shared_min_tiles = 2048;      // PVHIP_WINO_SHARED_MIN_TILES: tiles (patch blocks x channel-block pairs) from which the rule picks it for launches of 12-16 stages
     // ---- wrong-on-purpose ablations: honoured only by the diagnostic build (make diag -> libpvhip_diag.so, -DPVHIP_DIAG)
     int  conv_ablate = 0, wino4_ablate = 0, pw_ablate = 0;
     bool pool3_tuning() const { return pool3_kb != 16 || pool3_stage != 1 || pool3_wg != 0 || pool3_g != 0; }

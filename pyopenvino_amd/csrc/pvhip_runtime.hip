@@ -64,6 +64,11 @@ void load_settings() {
     s.wino_waves = num("PVHIP_WINO_WAVES", 8) == 4 ? 4 : 8;
     s.wino_balance = num("PVHIP_WINO_BALANCE", 1) != 0;
     s.wino_ragged = num("PVHIP_WINO_RAGGED", 1) != 0;
+    s.wino_shared = num("PVHIP_WINO_SHARED", 1);
+    s.wino_shared_min_tiles = num("PVHIP_WINO_SHARED_MIN_TILES", 2048);
+    s.wino_shared_lag = num("PVHIP_WINO_SHARED_LAG", 1);
+    s.wino_shared_prio = num("PVHIP_WINO_SHARED_PRIO", 1);
+    s.wino_shared_old = num("PVHIP_WINO_SHARED_OLD", 1);
 #ifdef PVHIP_DIAG
     // the predecessor convolution kernels and their tile overrides exist in the diagnostic build only
     if (const char* e = env("PVHIP_CONV_KERNEL")) s.conv_kernel = strcmp(e, "lds") == 0 ? 1 : (strcmp(e, "wave") == 0 ? 2 : 0);

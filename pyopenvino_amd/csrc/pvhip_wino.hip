@@ -45,6 +45,9 @@ struct WinoArgs {
     int   y_ctotal, y_coff;
     int   balance;          // conv_wino4_kernel: producers placed by SIMD (see the kernel)
     int   n_tiles;          // conv_wino4_kernel: channel blocks x patch blocks, walked by a persistent grid
+    int   s_prio;           // conv_wino4s_kernel: producers at wave priority 3, epilogues at 2 (PVHIP_WINO_SHARED_PRIO=0: everything at 0)
+    int   s_old;            // conv_wino4s_kernel: producers are waves 0-3 (the oldest) rather than 12-15
+    int   s_lag;            // conv_wino4s_kernel: the second consumer group starts kSLag stages behind the first (PVHIP_WINO_SHARED_LAG=0: together)
     // conv_wino4_kernel: patch index -> (image, patch row, patch column) by multiply-high and shift (w4_magic): the divisors are
     // wave-uniform, but hipcc's own division keeps their reciprocals in VECTOR registers across the main loop -- spilled there
     unsigned tpi_mul, tpi_sh, tx_mul, tx_sh;
@@ -575,6 +578,24 @@ __device__ __forceinline__ void wino4_bt_row(w4_float2v pa, w4_float2v pb, w4_fl
 }
 
 
+// The output transforms of wino4_at / wino2_at on PAIRS (two accumulator registers, or two columns) in packed fp32: the same
+// operations in the same order on each half (an fp32 add is exact-rounding identical in v_add_f32 and v_pk_add_f32), half the
+// vector instructions -- and every vector instruction of an epilogue is matrix time of the other consumer group.
+__device__ __forceinline__ void wino4_at2(w4_float2v m0, w4_float2v m1, w4_float2v m2, w4_float2v m3, w4_float2v m4, w4_float2v m5,
+                                          w4_float2v& o0, w4_float2v& o1, w4_float2v& o2, w4_float2v& o3) {
+    const w4_float2v s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    o0 = (m0 + s12) + s34;
+    o1 = w4_fma2(w4_splat(2.0f), d34, d12);
+    o2 = w4_fma2(w4_splat(4.0f), s34, s12);
+    o3 = w4_fma2(w4_splat(8.0f), d34, d12) + m5;
+}
+__device__ __forceinline__ void wino2_at2(w4_float2v m0, w4_float2v m1, w4_float2v m2, w4_float2v m3, w4_float2v m4, w4_float2v m5,
+                                          w4_float2v& o0, w4_float2v& o1) {
+    const w4_float2v s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    o0 = (m0 + s12) + s34;
+    o1 = w4_fma2(w4_splat(2.0f), d34, d12) + m5;
+}
+
 // M = 4: F(4x4, 3x3), pad 1.  M = 2: F(2x2, 5x5), pad 2 -- the same six interpolation points, hence the same B^T, the same 36 products
 // per channel and patch (for 4 outputs of a 5x5 window: 9 per output instead of 25) and the same kernel; only the gather geometry (an
 // aligned 8-byte load per row, TWO columns from each neighbour), the weight transform G (6x5) and the output transform A^T (2x6) differ.
@@ -1037,6 +1058,538 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
 #endif
 }
 
+
+// ======================================================================================================================
+// The six-point kernels with the transformed patches SHARED by 64 output channels and no barrier in the main loop (round 4).
+//
+// conv_wino4_kernel gathers and transforms every input patch once per 32 output channels: its two producer waves issue ~600
+// cycles of vector arithmetic per stage on SIMDs whose matrix pipe the consumers want for 2304 (fp32 MFMA and vector
+// instructions of a SIMD never overlap: lessons 25, 35) -- a quarter of the matrix time, and the patch bytes behind it keep the
+// CU's L1 miss queue full a third of the time.  Round 3 built the form in which two consumer groups (neighbouring channel
+// blocks) read ONE transformed image per stage -- half the gathers and transforms per output -- as one 16-wave workgroup with one
+// s_barrier per stage, and it lost (lesson 36): all twelve consumers leave the barrier together, run their MFMA segments on the
+// same pipe at the same time, and the pipe then idles through every barrier, which the second workgroup of the CU used to fill.
+//
+// This form keeps the sharing and drops the barrier.  One workgroup of 16 waves per CU:
+//   waves 0-5   consumers of channel block 2 kp     (row i of the 6x6 transform domain each, six accumulator tiles)
+//   waves 6-11  consumers of channel block 2 kp + 1
+//   waves 12-15 producers: pair p = waves 12 + 2p, 13 + 2p makes the stages q = p (mod 2) (lane <-> patch x channel of the stage)
+// (waves are dealt round robin over the SIMDs: every SIMD carries three consumers and one producer).  The transformed images go
+// through a RING of four LDS buffers, stage q (numbered across tiles) in buffer q & 3, and two counters per buffer replace the
+// barrier: ready[b] counts producer waves that have finished writing (a consumer of stage q waits for 2 (q / 4 + 1)), done[b]
+// counts consumer waves that have finished reading (a producer waits for 12 (q / 4) before it overwrites).  A consumer that finishes
+// its MFMAs goes on to the next stage at once if its image is there -- nobody waits for the slowest wave of the CU, the twelve
+// MFMA streams drift apart by themselves, and while one group is in its epilogue the other runs up to four stages ahead.
+// The epilogue is per GROUP (six waves, 384 lanes): exchange area of its own, passes of 12 / 12 / 8 channels (register sets 0-5,
+// 6-11, 12-15 of the accumulators: slot = 2 (register - first) + lane half), ordered by a counter barrier of the six waves.
+// Same arithmetic in the same order as conv_wino4_kernel: the same bits (tests: test_conv_winograd_shared_v_has_the_bits...).
+// For launches with an even number of channel blocks, a stage count that is a multiple of four and enough tiles (wino4_conv).
+constexpr int kSRing = 4;
+constexpr int kSLag  = 3;      // stages the second consumer group starts behind the first (< kSRing)
+
+// The two counter primitives, in ONE asm statement each (a spin loop or a branch in C++ between a wave's loads and their first use
+// makes hipcc's waitcnt pass merge its bookkeeping over the extra control flow and wait for vmcnt(0) in front of the first MFMA of
+// every stage: lessons 4, 31).  LDS executes a wave's instructions in order, so a counter increment issued behind a wave's LDS
+// writes (reads) is performed behind them: whoever sees the new count sees the data (may overwrite the buffer).  The "memory"
+// clobber is the compiler-side fence.  The load of the poll has its wait inside the same statement (lesson 24).
+__device__ __forceinline__ void w4s_wait_ge(unsigned lds_addr, unsigned target) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned v, sv;
+    asm volatile("1:\n\t"
+                 "ds_read_b32 %0, %2\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_readfirstlane_b32 %1, %0\n\t"
+                 "s_sub_i32 %1, %1, %3\n\t"
+                 "s_cmp_ge_i32 %1, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_sleep 1\n\t"
+                 "s_branch 1b\n\t"
+                 "2:"
+                 : "=&v"(v), "=&s"(sv) : "v"(lds_addr), "s"(target) : "memory", "scc");
+#endif
+}
+#ifdef PVHIP_DIAG
+// one poll taken apart: cycles from before the LDS read to its arrival, and from there to behind the v_readfirstlane
+__device__ __forceinline__ void w4s_poll_probe(unsigned lds_addr, unsigned long long& lds_cycles, unsigned long long& valu_cycles) {
+    (void)lds_addr; (void)lds_cycles; (void)valu_cycles;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned v, sv;
+    unsigned long long ta, tb, tc;
+    asm volatile("s_memtime %2\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_read_b32 %0, %5\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_memtime %3\n\t"
+                 "v_readfirstlane_b32 %1, %0\n\t"
+                 "s_nop 0\n\t"
+                 "s_memtime %4\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v), "=&s"(sv), "=&s"(ta), "=&s"(tb), "=&s"(tc) : "v"(lds_addr) : "memory");
+    lds_cycles += tb - ta;
+    valu_cycles += tc - tb;
+#endif
+}
+#define PVS_PWAIT(addr_, target_) { w4s_poll_probe(addr_, st[6], st[5]); w4s_wait_ge(addr_, target_); }
+#else
+#define PVS_PWAIT(addr_, target_) w4s_wait_ge(addr_, target_)
+#endif
+__device__ __forceinline__ void w4s_signal(unsigned lds_addr) {        // one increment per WAVE (lane 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_u32 %1, %2\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(lds_addr), "v"(1u) : "memory");
+#endif
+}
+// the increment with the count BEFORE it returned (wave-uniform): how many waves were here first
+__device__ __forceinline__ unsigned w4s_signal_rank(unsigned lds_addr) {
+    unsigned sv = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long saved;
+    unsigned v;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_rtn_u32 %1, %3, %4\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_readfirstlane_b32 %2, %1\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved), "=&v"(v), "=&s"(sv) : "v"(lds_addr), "v"(1u) : "memory");
+#endif
+    return sv;
+}
+#define PVS_LDS_ADDR(p_) ((unsigned)(unsigned long)(lds_ptr_t)(p_))
+#ifdef PVHIP_DIAG
+// diagnostic build: cycle accounts per wave of every 16th workgroup of conv_wino4s_kernel, [wave][account] (scripts/stamps_wino4s.py).
+// consumers: 0 waiting for the stage's image, 1 LDS reads + MFMAs + weight loads, 2 epilogue work, 3 epilogue counter barriers, 5 stages, 6 tiles
+// producers: 0 waiting for a free buffer, 1 transform + LDS writes, 2 gather issue, 5 own stages;  4 = the wave's life, 7 = workgroups
+__device__ unsigned long long g_w4s_stamps[16][8];
+__device__ unsigned long long g_w4s_simd[16][4];
+__device__ unsigned g_w4s_trace[16][96][4];              // workgroup 3: cycle (since its start) at which wave w saw stage q's image / finished stage q (producers: began / finished writing own stage)
+#define PVS_TRACE(w_, q_, k_, t_) { if (blockIdx.x == 3 && (q_) < 96u && (threadIdx.x & 63) == 0) g_w4s_trace[w_][q_][k_] = (unsigned)((t_) - t_entry); }          // how often wave w of a stamped workgroup ran on SIMD 0..3 (HW_REG_HW_ID)
+#define PVS_NOW() ((unsigned long long)__builtin_readcyclecounter())
+#define PVS_DATA_WAIT() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xF7C); __builtin_amdgcn_sched_barrier(0); }      /* vmcnt(12) */
+#else
+#define PVS_NOW() 0ull
+#define PVS_DATA_WAIT() {}
+#define PVS_TRACE(w_, q_, k_, t_) {}
+#endif
+
+template <int M, bool RAGGED>
+__global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
+    static_assert(M == 4 || M == 2, "F(4x4,3x3) or F(2x2,5x5)");
+    constexpr int PAD = (M == 4) ? 1 : 2;
+    constexpr int KB = 32, NT = 32, CONS = 12, CH = 12;
+    constexpr unsigned kOob = 0x80000000u;
+    struct Smem {
+        float    V[kSRing][kXi4][kCB][NT];             // 4 x 18 KB
+        float    Ex[2][6 * CH * 32 * M];               // per group: [row][slot][patch][M columns]
+        unsigned ready[kSRing], done[kSRing], gbar[2];
+    };
+    __shared__ __attribute__((aligned(1024))) Smem sm;
+    static_assert(sizeof(Smem) <= 150 * 1024, "one workgroup per CU");
+
+    const int G = gridDim.x;
+    int       L;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = G >> 3, r = G & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int n_kp    = a.n_kb >> 1;                    // pairs of channel blocks
+    const int n_tiles = a.n_tiles;                      // patch blocks x pairs
+    const int n_eff   = a.n_stages;                     // a multiple of 4 (wino4_conv)
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW   = a.H * a.W;
+    const int TPI  = a.TY * a.TX;
+    const unsigned chan_bytes = (unsigned)HW * 4u;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    typedef const __attribute__((address_space(4))) float* const_float_p;
+    const const_float_p bias_c = (const_float_p)(unsigned long)a.bias;
+    constexpr unsigned u_stage_bytes = (unsigned)kXi4 * kCB * KB * 4u;
+    constexpr int      v_buf_floats  = kXi4 * kCB * NT;
+
+    if (tid < kSRing) { sm.ready[tid] = 0u; sm.done[tid] = 0u; }
+    if (tid < 2) sm.gbar[tid] = 0u;
+    __syncthreads();                                    // the only barrier of the kernel
+    const unsigned long long t_entry = PVS_NOW();
+    unsigned long long st[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    (void)t_entry; (void)st;
+
+    // Roles: the producers are the OLDEST waves of the workgroup (0-3) unless PVHIP_WINO_SHARED_OLD=0 (then the youngest, 12-15): the
+    // SIMD's arbiter prefers older waves, and a producer that only gets issue slots when no consumer has an MFMA ready makes the
+    // consumers wait for it (stamps: a v_readfirstlane of a young producer waits ~300 cycles for its slot, single ones thousands).
+    const int p_first = a.s_old != 0 ? 0 : CONS;                   // first producer wave
+    const int c_first = a.s_old != 0 ? 4 : 0;                      // first consumer wave
+    if (wid >= p_first && wid < p_first + 4) {
+        // ------------------------------------------------------------------ producers (the gather and the transform of conv_wino4_kernel)
+        const int pair = (wid - p_first) >> 1, pidx = (wid - p_first) & 1;
+        const int g_chan = pidx * 2 + lh;
+        // Producers FIRST.  The SIMD's arbiter picks the oldest wave that has an instruction ready, and the consumers (waves 0-11) are
+        // older: with their MFMA streams never interrupted by a barrier, a producer's vector instructions only got issue slots while
+        // the consumers were waiting -- for the producers (stamps: 2100 cycles per transform, 560-600 in conv_wino4_kernel; consumers
+        // waiting 1.2-1.5 k cycles per stage).  PVHIP_WINO_SHARED_PRIO=0 leaves every wave at priority 0 (A/B runs).
+        if (a.s_prio != 0) __builtin_amdgcn_s_setprio(3);
+        typedef w4_float4v float4v;
+        typedef w4_float2v float2v;
+        unsigned rowo[6], eo[6];
+        bool     zlo, zhi, zlo_n, zhi_n;
+        int      nv = M | 256, nv_n = M | 256;
+        const bool first = l31 == 0, last = l31 == 31;
+#define PVS_ADDRESSES(tile_, zl_, zh_, nv_)                                                                       \
+    {                                                                                                            \
+        const int  t    = ((tile_) / n_kp) * NT + l31;                                                           \
+        const bool live = (tile_) < n_tiles && t < a.T;                                                          \
+        const int  tq = live ? t : 0;                                                                            \
+        const int  n = w4_div(tq, a.tpi_mul, a.tpi_sh), rem = tq - n * TPI;                                      \
+        const int  ty = w4_div(rem, a.tx_mul, a.tx_sh), tx = rem - ty * a.TX;                                    \
+        const unsigned base = (unsigned)(n * a.C * HW + g_chan * HW + M * tx) * 4u;                              \
+        zl_ = tx == 0;                                                                                           \
+        zh_ = tx == a.TX - 1;                                                                                    \
+        if (RAGGED) nv_ = min(M, a.W - M * tx) | ((M * tx + M + 1 < a.W) ? 256 : 0);                             \
+        unsigned eoff;                                                                                           \
+        if (M == 4) eoff = first ? (zl_ ? 0u : 0xFFFFFFFCu) : (zh_ ? 12u : 16u);                                 \
+        else        eoff = first ? (zl_ ? 0u : 0xFFFFFFF8u) : (zh_ ? 0u : 8u);                                   \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
+            const int iy = M * ty - PAD + r;                                                                     \
+            rowo[r] = (live && (unsigned)iy < (unsigned)a.H) ? base + (unsigned)(iy * a.W) * 4u : kOob + 16u;    \
+            eo[r]   = (first || last) ? rowo[r] + eoff : kOob;                                                   \
+            asm volatile("" : "+v"(rowo[r]), "+v"(eo[r]));                                                       \
+        }                                                                                                        \
+    }
+        using VecT = typename std::conditional<M == 4, float4v, float2v>::type;
+        using EdgT = typename std::conditional<M == 4, float, float2v>::type;
+        VecT vA[6], vB[6];
+        EdgT eA[6], eB[6];
+#define PVS_GATHER(v_, e_, s_)                                                                                   \
+    {                                                                                                            \
+        const unsigned soff = (unsigned)((s_) * kCB) * chan_bytes;                                               \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
+            w4_load(v_[r], xr, rowo[r], soff);                                                                   \
+            w4_load(e_[r], xr, eo[r], soff);                                                                     \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }
+#define PVS_TRANSFORM_STORE(v_, e_, Vb_, zl_, zh_, nv_)                                                          \
+    {                                                                                                            \
+        float2v pa[6], pb[6], pc[6];                                                                             \
+        if (RAGGED) {                                                                                            \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                        \
+                _Pragma("unroll") for (int q = 1; q < M; ++q) v_[r][q] = q < ((nv_) & 255) ? v_[r][q] : 0.0f;   \
+        }                                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 6; ++r) {                                                          \
+            constexpr int NB = (M == 4) ? 1 : 2;                                                                 \
+            float lo_[NB], hi_[NB];                                                                              \
+            _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                     \
+                const float nl = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)v_[r][M - NB + q]), 0x138, 0xf, 0xf, true)); \
+                const float nh = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)v_[r][q]), 0x130, 0xf, 0xf, true)); \
+                lo_[q] = zl_ ? 0.0f : (first ? w4_edge(e_[r], q) : nl);                                          \
+                hi_[q] = zh_ ? 0.0f : (last ? ((RAGGED && q >= 1 && !((nv_) & 256)) ? 0.0f : w4_edge(e_[r], q)) : nh); \
+            }                                                                                                    \
+            if (M == 4) {                                                                                        \
+                pa[r] = float2v{v_[r][0], v_[r][1]};                                                             \
+                pb[r] = float2v{v_[r][M - 2], v_[r][M - 1]};                                                     \
+                pc[r] = float2v{lo_[0], hi_[0]};                                                                 \
+            } else {                                                                                             \
+                pa[r] = float2v{lo_[0], lo_[NB - 1]};                                                            \
+                pb[r] = float2v{v_[r][0], v_[r][1]};                                                             \
+                pc[r] = float2v{hi_[0], hi_[NB - 1]};                                                            \
+            }                                                                                                    \
+        }                                                                                                        \
+        float2v ma[6], mb[6], mc[6];                                                                             \
+        wino4_bt2(pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], ma[0], ma[1], ma[2], ma[3], ma[4], ma[5]);           \
+        wino4_bt2(pb[0], pb[1], pb[2], pb[3], pb[4], pb[5], mb[0], mb[1], mb[2], mb[3], mb[4], mb[5]);           \
+        wino4_bt2(pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], mc[0], mc[1], mc[2], mc[3], mc[4], mc[5]);           \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                          \
+            float v0, v1, v2, v3, v4, v5;                                                                        \
+            wino4_bt_row<(M == 4) ? 0 : 1>(ma[i], mb[i], mc[i], v0, v1, v2, v3, v4, v5);                         \
+            Vb_[((i * 6 + 0) * kCB + g_chan) * NT + l31] = v0;                                                   \
+            Vb_[((i * 6 + 1) * kCB + g_chan) * NT + l31] = v1;                                                   \
+            Vb_[((i * 6 + 2) * kCB + g_chan) * NT + l31] = v2;                                                   \
+            Vb_[((i * 6 + 3) * kCB + g_chan) * NT + l31] = v3;                                                   \
+            Vb_[((i * 6 + 4) * kCB + g_chan) * NT + l31] = v4;                                                   \
+            Vb_[((i * 6 + 5) * kCB + g_chan) * NT + l31] = v5;                                                   \
+        }                                                                                                        \
+    }
+        // own stage o of a tile is stage s = 2 o + pair; own stages alternate between ring buffers `pair` (o even) and `pair + 2`
+        float* const VbA = &sm.V[pair][0][0][0];
+        float* const VbB = &sm.V[pair + 2][0][0][0];
+        const unsigned readyA = PVS_LDS_ADDR(&sm.ready[0]) + 4u * (unsigned)pair, readyB = readyA + 8u;
+        const unsigned doneA  = PVS_LDS_ADDR(&sm.done[0]) + 4u * (unsigned)pair,  doneB  = doneA + 8u;
+        unsigned  use = 0u;                              // how often each of this pair's buffers has been filled
+        const int n_own = n_eff >> 1;                    // even
+        int tile = L;
+        PVS_ADDRESSES(tile, zlo, zhi, nv);
+        PVS_GATHER(vA, eA, pair);
+        PVS_GATHER(vB, eB, 2 + pair);
+        for (;;) {
+            for (int o = 0; o + 2 < n_own; o += 2) {
+                const unsigned long long p0 = PVS_NOW();
+                PVS_DATA_WAIT();                        /* (diagnostic build: the older gather has landed -- its wait gets an account of its own) */
+                const unsigned long long d0 = PVS_NOW();
+#ifdef PVHIP_DIAG
+                { const unsigned seen_ = *(volatile unsigned*)&sm.done[pair]; PVS_TRACE(wid, 4u * use + (unsigned)pair, 0, t_entry + (unsigned long long)(seen_ * 1000u + (unsigned)CONS * use)); PVS_TRACE(wid, 4u * use + (unsigned)pair, 1, d0); }
+#endif
+                PVS_PWAIT(doneA, (unsigned)CONS * use);
+                const unsigned long long p1 = PVS_NOW();
+                PVS_TRANSFORM_STORE(vA, eA, VbA, zlo, zhi, nv);
+                w4s_signal(readyA);
+                const unsigned long long p2 = PVS_NOW();
+                PVS_GATHER(vA, eA, 2 * (o + 2) + pair);
+                const unsigned long long p3 = PVS_NOW();
+                PVS_DATA_WAIT();
+                const unsigned long long d1 = PVS_NOW();
+                PVS_PWAIT(doneB, (unsigned)CONS * use);
+                const unsigned long long p4 = PVS_NOW();
+                PVS_TRANSFORM_STORE(vB, eB, VbB, zlo, zhi, nv);
+                w4s_signal(readyB);
+                const unsigned long long p5 = PVS_NOW();
+                PVS_GATHER(vB, eB, 2 * (o + 3) + pair);
+                st[0] += (p1 - d0) + (p4 - d1); st[1] += (p2 - p1) + (p5 - p4); st[2] += (p3 - p2) + (PVS_NOW() - p5);
+                st[3] += (d0 - p0) + (d1 - p3);
+                { const unsigned qa = 4u * use + (unsigned)pair, qb = qa + 2u; (void)qb; PVS_TRACE(wid, qa, 2, p1); PVS_TRACE(wid, qa, 3, p2); PVS_TRACE(wid, qb, 1, d1); PVS_TRACE(wid, qb, 2, p4); PVS_TRACE(wid, qb, 3, p5); }
+                ++use;
+            }
+            // the last two own stages of the tile: the gathers behind them are own stages 0 / 1 of the NEXT tile
+            PVS_ADDRESSES(tile + G, zlo_n, zhi_n, nv_n);
+            w4s_wait_ge(doneA, (unsigned)CONS * use);
+            PVS_TRANSFORM_STORE(vA, eA, VbA, zlo, zhi, nv);
+            w4s_signal(readyA);
+            PVS_GATHER(vA, eA, pair);
+            w4s_wait_ge(doneB, (unsigned)CONS * use);
+            PVS_TRANSFORM_STORE(vB, eB, VbB, zlo, zhi, nv);
+            w4s_signal(readyB);
+            PVS_GATHER(vB, eB, 2 + pair);
+            ++use;
+            zlo = zlo_n;
+            zhi = zhi_n;
+            nv  = nv_n;
+            tile += G;
+            if (tile >= n_tiles) break;
+        }
+#undef PVS_ADDRESSES
+#undef PVS_GATHER
+#undef PVS_TRANSFORM_STORE
+    } else {
+        // ------------------------------------------------------------------ consumers
+        const int cw  = wid - c_first;                              // 0 .. 11
+        const int grp = (int)((unsigned)(5 - cw) >> 31);           // scalar arithmetic on purpose: a select would put it in a vector register (lesson 19)
+        const int row = cw - 6 * grp;
+        const unsigned u_lane = (unsigned)lane * 16u;
+#define PVS_LOAD_U(ua_, so_, g_) w4_load(ua_[g_], ur, u_lane + (unsigned)(row * 3 + (g_)) * 1024u, (so_))
+        floatx16 acc[6];
+        const float* const vbs = &sm.V[0][0][0][0] + ((row * 6) * kCB + lh) * NT + l31;
+        // wave-uniform offsets kept as SCALARS (readfirstlane) and turned into addresses where they are used: as pointers hipcc held them
+        // in vector registers across the main loop, spilled them, and a spill reload is a vector memory load whose wait is vmcnt(0) (lesson 34)
+        const int ex_off = __builtin_amdgcn_readfirstlane(grp * (6 * CH * 32 * M));
+#define Exg  (&sm.Ex[0][0] + ex_off)
+        const unsigned gbar = PVS_LDS_ADDR(&sm.gbar[0]) + 4u * (unsigned)grp;
+        const unsigned ready0 = PVS_LDS_ADDR(&sm.ready[0]), done0 = PVS_LDS_ADDR(&sm.done[0]);
+        unsigned gb_n = 0u;                              // counter barriers of this group passed so far
+        const int OH = a.H, OW = a.W;
+        const ActBounds ab = act_bounds(a.act, a.act_lo, a.act_hi);
+        typedef float exv_t __attribute__((ext_vector_type(M)));
+#define PVS_U_BASE(tile_) ((unsigned)((2 * ((tile_) % n_kp) + grp) * (a.n_stages + 1)) * u_stage_bytes)
+#define PVS_GROUP_BARRIER() { const unsigned long long g0_ = PVS_NOW(); w4s_signal(gbar); ++gb_n; w4s_wait_ge(gbar, 6u * gb_n); const unsigned long long g1_ = PVS_NOW(); st[3] += g1_ - g0_; st[2] -= g1_ - g0_; }
+        w4_float4v ua[3];
+        {
+            const unsigned u_first = PVS_U_BASE(L);
+            PVS_LOAD_U(ua, u_first, 0);
+            PVS_LOAD_U(ua, u_first, 1);
+            PVS_LOAD_U(ua, u_first, 2);
+        }
+        unsigned q = 0u;                                 // stage number across tiles
+        // The second group starts kLag stages behind the first and stays there (the ring lets the first run at most kSRing stages
+        // ahead): both groups read the same images in the same order, so left alone they reach their epilogues TOGETHER and the matrix
+        // pipe idles through both (stamps: 1.2-1.5 k cycles of waiting per stage); staggered, a group's epilogue runs beside the
+        // other group's last (first) stages of the tile.
+        if (grp == 1 && a.s_lag != 0) w4s_wait_ge(done0 + 4u * (unsigned)(kSLag - 1), 6u);
+        for (int tile = L; tile < n_tiles; tile += G) {
+            const unsigned u_base = PVS_U_BASE(tile), u_next = PVS_U_BASE(tile + G);
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            for (int s = 0; s < n_eff; ++s, ++q) {
+                const unsigned b = q & (kSRing - 1);
+                const unsigned long long c0 = PVS_NOW();
+                w4s_wait_ge(ready0 + 4u * b, 2u * ((q >> 2) + 1u));
+                const unsigned long long c1 = PVS_NOW();
+                const float* vb = vbs + b * v_buf_floats;
+                const unsigned so_n = s + 1 < n_eff ? u_base + (unsigned)(s + 1) * u_stage_bytes : u_next;
+                float bfr[2][4];
+#define PVS_READ_B(dst_, g_)                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+        const int m = 4 * (g_) + e, kk = m / 6, j = m % 6;                                                       \
+        dst_[e] = vb[(j * kCB + 2 * kk) * NT];                                                                   \
+    }
+                PVS_READ_B(bfr[0], 0);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (g < 2) PVS_READ_B(bfr[(g + 1) & 1], g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = 4 * g + e, j = m % 6;
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[g][e], bfr[g & 1][e], acc[j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    PVS_LOAD_U(ua, so_n, g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef PVS_READ_B
+                // every B operand of this stage is in registers (the MFMAs above used them): the buffer is released.  The count that comes
+                // back says how many of the twelve consumers finished the stage before this wave: the late ones go in front.  The
+                // SIMD's arbiter prefers OLDER waves, so the youngest consumer of a SIMD only got the matrix pipe when the others stalled,
+                // fell a ring behind, and everybody then waited for the buffers it still held (stamps: 6000 cycles between the first and
+                // the last consumer of a stage).
+                if (a.s_prio != 0) {
+                    const unsigned rank = w4s_signal_rank(done0 + 4u * b) - (unsigned)CONS * (q >> 2);
+                    if (rank >= 8u) __builtin_amdgcn_s_setprio(2);
+                    else if (rank >= 4u) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                } else {
+                    w4s_signal(done0 + 4u * b);
+                }
+                { const unsigned long long c2 = PVS_NOW(); st[0] += c1 - c0; st[1] += c2 - c1; st[5] += 1; PVS_TRACE(wid, q, 0, c1); PVS_TRACE(wid, q, 1, c2); }
+            }
+            st[6] += 1;
+            // ---- epilogue of this group: Y = A^T D A, the column half in registers, the rows meet in Exg, 12 / 12 / 8 channels at a time
+            const unsigned long long e0_ = PVS_NOW();
+            if (a.s_prio != 0) __builtin_amdgcn_s_setprio(3);       // in front of the other group's MFMA streams: the group comes back to its own sooner
+            {
+                const int kb_e = 2 * (tile % n_kp) + grp, tb_e = tile / n_kp;
+                const bool even_w = (OW & 1) == 0;
+                (void)even_w;
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass) {
+                    constexpr int kFirst[3] = {0, 6, 12};
+                    const int R0 = kFirst[pass], NR = pass < 2 ? 6 : 4;
+                    // every per-lane value of a pass is made INSIDE it from a lane id hipcc can neither hoist nor merge: kept across the
+                    // passes (or the main loop) they are spilled, and a spill reload waits for vmcnt(0) -- behind the previous pass's stores
+                    int lane_e;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+#else
+                    lane_e = 0;
+#endif
+                    const int tl = lane_e & 31, lh_e = lane_e >> 5;
+#pragma unroll
+                    for (int rr = 0; rr < 6; rr += 2) {       // two accumulator registers (slots 2 rr + lh, 2 rr + 2 + lh) per step: packed fp32
+                        if (rr < NR) {
+                            const int r = R0 + rr;
+                            w4_float2v mm[6], so2[4];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) mm[j] = w4_float2v{acc[j][r], acc[j][r + 1]};
+                            if (M == 4) wino4_at2(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], so2[0], so2[1], so2[2], so2[3]);
+                            else        wino2_at2(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], so2[0], so2[1]);
+                            exv_t sv0, sv1;
+#pragma unroll
+                            for (int c2 = 0; c2 < M; ++c2) { sv0[c2] = so2[c2].x; sv1[c2] = so2[c2].y; }
+                            *reinterpret_cast<exv_t*>(Exg + ((row * CH + 2 * rr + lh_e) * 32 + tl) * M) = sv0;
+                            *reinterpret_cast<exv_t*>(Exg + ((row * CH + 2 * rr + 2 + lh_e) * 32 + tl) * M) = sv1;
+                        }
+                    }
+                    PVS_GROUP_BARRIER();
+                    if (row < NR) {                       // this wave: slots 2 row (lanes 0-31) and 2 row + 1 (lanes 32-63): register R0 + row
+                        const int r_  = R0 + row;
+                        const int m0  = (r_ & 3) + 8 * (r_ >> 2);            // channel of the block for lane half 0; half 1: + 4
+                        const int kgs = kb_e * KB + m0;
+                        const int kg  = kgs + 4 * lh_e;
+                        float bs0 = -0.0f, bs1 = -0.0f;
+                        if (a.bias != nullptr) {
+                            bs0 = bias_c[min(kgs, a.K - 1)];
+                            bs1 = bias_c[min(kgs + 4, a.K - 1)];
+                        }
+                        const int t  = tb_e * NT + tl;
+                        if (t < a.T && kg < a.K) {
+                            const int n_ = w4_div(t, a.tpi_mul, a.tpi_sh), rem_ = t - n_ * TPI;
+                            const int ty_ = w4_div(rem_, a.tx_mul, a.tx_sh), tx_ = rem_ - ty_ * a.TX;
+                            const int  rows_ok = min(M, OH - M * ty_), cols_ok = min(M, OW - M * tx_);
+                            (void)rows_ok; (void)cols_ok;
+                            const float bv = lh_e ? bs1 : bs0;
+                            float* __restrict__ yp = a.y + ((((size_t)n_ * a.y_ctotal + a.y_coff + kg) * OH + M * ty_) * OW + M * tx_);
+                            const int slot = 2 * row + lh_e;
+                            exv_t ev[6];
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(Exg + ((i * CH + slot) * 32 + tl) * M);
+                            float yv[M][M];
+#pragma unroll
+                            for (int c2 = 0; c2 < M; c2 += 2) {          // two columns per step: packed fp32 (the bias add too)
+                                w4_float2v em[6], col2[4];
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) em[i] = w4_float2v{ev[i][c2], ev[i][c2 + 1]};
+                                if (M == 4) wino4_at2(em[0], em[1], em[2], em[3], em[4], em[5], col2[0], col2[1], col2[2], col2[3]);
+                                else        wino2_at2(em[0], em[1], em[2], em[3], em[4], em[5], col2[0], col2[1]);
+#pragma unroll
+                                for (int r2 = 0; r2 < M; ++r2) {
+                                    const w4_float2v yb = col2[r2] + w4_splat(bv);
+                                    yv[r2][c2] = yb.x;
+                                    yv[r2][c2 + 1] = yb.y;
+                                }
+                            }
+                            if (a.act != 0) {
+#pragma unroll
+                                for (int r2 = 0; r2 < M; ++r2)
+#pragma unroll
+                                    for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] < ab.lo) ? ab.lo : yv[r2][c2];
+                            }
+                            if (a.act == 2) {
+#pragma unroll
+                                for (int r2 = 0; r2 < M; ++r2)
+#pragma unroll
+                                    for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] > ab.hi) ? ab.hi : yv[r2][c2];
+                            }
+#pragma unroll
+                            for (int r2 = 0; r2 < M; ++r2) {
+                                float ov[M];
+#pragma unroll
+                                for (int c2 = 0; c2 < M; ++c2) ov[c2] = yv[r2][c2];
+                                if (RAGGED) {
+                                    if (r2 < rows_ok) {
+#pragma unroll
+                                        for (int c2 = 0; c2 < M; c2 += 2) {
+                                            if (even_w && c2 + 1 < cols_ok) conv_store2(yp + (size_t)r2 * OW + c2, ov[c2], ov[c2 + 1]);
+                                            else {
+                                                if (c2 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2, ov[c2]);
+                                                if (c2 + 1 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2 + 1, ov[c2 + 1]);
+                                            }
+                                        }
+                                    }
+                                } else if (M == 4) conv_store4(yp + (size_t)r2 * OW, ov[0], ov[1], ov[2], ov[3]);
+                                else conv_store2(yp + (size_t)r2 * OW, ov[0], ov[1]);
+                            }
+                        }
+                    }
+                    PVS_GROUP_BARRIER();                  // the exchange area is read out: the next pass (or tile) may write it
+                }
+            }
+            if (a.s_prio != 0) __builtin_amdgcn_s_setprio(1);
+            st[2] += PVS_NOW() - e0_;
+        }
+#undef PVS_LOAD_U
+#undef PVS_U_BASE
+#undef PVS_GROUP_BARRIER
+#undef Exg
+    }
+#ifdef PVHIP_DIAG
+    if ((blockIdx.x & 15) == 3 && lane == 0) {
+        st[4] = PVS_NOW() - t_entry;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_w4s_stamps[wid][i], st[i]);
+        atomicAdd(&g_w4s_stamps[wid][7], 1ull);
+        atomicAdd(&g_w4s_simd[wid][(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11))) & 3u], 1ull);
+    }
+#endif
+}
+
 }  // namespace
 
 namespace pvhip {
@@ -1084,7 +1637,7 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.u_bytes = (unsigned)(wino_pack_elems(k_out, c) * 4);
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
-    a.balance = 0; a.n_tiles = 0;
+    a.balance = 0; a.n_tiles = 0; a.s_lag = 0; a.s_prio = 0; a.s_old = 0;
     a.tpi_mul = a.tpi_sh = a.tx_mul = a.tx_sh = 0u;
 #ifdef PVHIP_DIAG
     if (settings().wino4_ablate == 5) a.balance = 5;          // diagnostic build: s_memtime stamps (scripts/stamps_wino.py)
@@ -1164,6 +1717,9 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     a.T  = n * a.TY * a.TX;
     a.n_kb = (k_out + 31) / 32;
     a.balance = settings().wino_balance ? 1 : 0;
+    a.s_lag = settings().wino_shared_lag;
+    a.s_prio = settings().wino_shared_prio;
+    a.s_old = settings().wino_shared_old;
     a.n_stages = c / kCB;
     a.x_bytes = (unsigned)((size_t)n * c * h * w * 4);
     a.u_bytes = (unsigned)(wino4_pack_elems(k_out, c) * 4);
@@ -1174,6 +1730,31 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     a.n_tiles = (int)(n_tb * a.n_kb);
     w4_magic((unsigned)(a.TY * a.TX), a.tpi_mul, a.tpi_sh);
     w4_magic((unsigned)a.TX, a.tx_mul, a.tx_sh);
+    // The shared-V form (conv_wino4s_kernel: one 16-wave workgroup per CU, two channel blocks on one transformed image per stage,
+    // counters instead of barriers): an even number of channel blocks, whole groups of four stages, and tiles for every CU.
+    // PVHIP_WINO_SHARED=0 never, =2 wherever it applies.
+    {
+        const int  mode = settings().wino_shared;
+        const long tiles_s = n_tb * (a.n_kb / 2);
+        const bool shape_ok = a.n_kb % 2 == 0 && a.n_stages % 4 == 0 && a.n_stages >= 4;
+        // Measured on GoogLeNet's layers at batch 256 (scripts/time_wino_shared.py, same box, alternating): it wins where the main loop is
+        // long against the two epilogues of a tile -- C >= 112: 3b -6 %, 4c -7 %, 4e -9 %, 5a -6 %, 5b -11 % -- and on conv2/3x3 (C = 64,
+        // 4704 tiles: -4 %); it loses at C = 96 (3a: +8 %) and is a wash on the 5x5 layers (4 .. 12 stages per tile).
+        const bool pays = a.n_stages >= 28 || (a.n_stages <= 16 && a.n_stages >= 12 && tiles_s >= (long)settings().wino_shared_min_tiles);
+        if (mode != 0 && shape_ok && (mode == 2 || pays)) {
+            a.n_tiles = (int)tiles_s;
+            const dim3 grid_s((unsigned)(tiles_s < kNumCU ? tiles_s : kNumCU));
+            if (m == 2) {
+                if (ragged) hipLaunchKernelGGL((conv_wino4s_kernel<2, true>), grid_s, dim3(1024), 0, state().stream, a);
+                else        hipLaunchKernelGGL((conv_wino4s_kernel<2, false>), grid_s, dim3(1024), 0, state().stream, a);
+            } else {
+                if (ragged) hipLaunchKernelGGL((conv_wino4s_kernel<4, true>), grid_s, dim3(1024), 0, state().stream, a);
+                else        hipLaunchKernelGGL((conv_wino4s_kernel<4, false>), grid_s, dim3(1024), 0, state().stream, a);
+            }
+            PVHIP_LAUNCH_CHECK();
+            return PVHIP_OK;
+        }
+    }
     // persistent: two workgroups per CU (72 KB of LDS each), each walking tiles L, L + G, ...
     const dim3 grid((unsigned)(a.n_tiles < 2 * kNumCU ? a.n_tiles : 2 * kNumCU));
     if (m == 2) {
@@ -1221,6 +1802,25 @@ extern "C" int pvhip_diag_wino4_epilogue(unsigned long long* out) {      // 8 wa
     if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_epi), sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_epi), zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+extern "C" int pvhip_diag_wino4s_stamps(unsigned long long* out) {     // 16 waves x 8 accounts of conv_wino4s_kernel, read and cleared
+    unsigned long long zero[128] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4s_stamps), sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4s_stamps), zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+extern "C" int pvhip_diag_wino4s_trace(unsigned* out) {       // 16 waves x 96 stages x 2 stamps of workgroup 3 (the last launch)
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4s_trace), 16 * 96 * 4 * sizeof(unsigned)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+extern "C" int pvhip_diag_wino4s_simd(unsigned long long* out) {       // 16 waves x 4 SIMDs: where the waves of the stamped workgroups ran; read and cleared
+    unsigned long long zero[64] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4s_simd), sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4s_simd), zero, sizeof(zero)) != hipSuccess) return PVHIP_EHIP;
     return PVHIP_OK;
 }
 extern "C" int pvhip_diag_wino4_stamps(unsigned long long* out) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build check (wired into csrc/Makefile and __graft_entry__.build()): no inline-asm statement of the HIP sources may contain a
-vector-memory load with a REGISTER destination.
+vector-memory load with a REGISTER destination (an LDS read only with its `s_waitcnt lgkmcnt(0)` in the same statement).
 
 Why: a load issued from one asm statement and waited for (`s_waitcnt vmcnt`) in another leaves a window in which hipcc considers the
 destination register defined and may copy or spill it before the data has landed (DESIGN lesson 24: wrong images at batch 256 next to
@@ -15,6 +15,7 @@ import re
 import sys
 
 LOAD = re.compile(r'\b(?:global|buffer|flat|scratch)_load_\w+[^\n\\]*', re.S)
+LDS_READ = re.compile(r'\bds_(?:read\w*|\w+_rtn_\w+)')
 
 
 def asm_statements(text):
@@ -51,6 +52,12 @@ def main():
     for path in sorted(glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h'))):
         text = open(path).read()
         for line, code in asm_statements(text):
+            # an LDS read in asm is allowed only with its wait in the SAME statement (the spin loop of pvhip_wino.hip's counters)
+            insts = code.split('\n')
+            for k, inst in enumerate(insts):
+                if LDS_READ.search(inst) and not any('s_waitcnt lgkmcnt(0)' in later for later in insts[k + 1:]):
+                    bad.append('{}:{}: inline asm reads LDS into a register without waiting for it in the same statement: {}'.format(
+                        os.path.relpath(path), line, inst.strip()))
             for inst in code.split('\n'):
                 m = LOAD.search(inst)
                 if m and not (re.search(r'\blds\b', inst) or '_load_lds_' in inst):

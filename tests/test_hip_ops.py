@@ -277,6 +277,42 @@ def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
     assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
 
 
+@pytest.mark.parametrize('ks', [3, 5])
+def test_conv_winograd_shared_v_form_has_the_bits_of_the_two_workgroup_form(hip, monkeypatch, ks):
+    """conv_wino4s_kernel (round 4: two channel blocks on ONE transformed image per stage, 16 waves, LDS counters instead of barriers)
+    against conv_wino4_kernel: the same arithmetic in the same order, so the same bits -- whole and ragged extents, several tiles per
+    workgroup, patch blocks that end inside an image, partial last channel block, fused bias + ReLU / Clamp into a wider tensor;
+    and against the oracle.  Shapes the shared form does not take (odd number of channel blocks, stage count not a multiple of
+    four) fall back to the two-workgroup form by themselves."""
+    from pyopenvino_amd import device as dev
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD4', 'force')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD5', 'force')
+    pad = ks // 2
+    cases = [((2, 16, 8, 8), 64), ((3, 32, 12, 16), 40), ((1, 64, 56, 56), 128), ((9, 16, 28, 28), 192), ((5, 48, 14, 14), 100),
+             ((40, 16, 7, 7), 64), ((3, 80, 5, 9), 33), ((600, 16, 4, 4), 64), ((2, 16, 8, 8), 32), ((2, 24, 8, 8), 64)]
+    for xs, k in cases:
+        x = rnd(sum(xs), xs)
+        w = rnd(k, (k, xs[1], ks, ks), (2.0 / (xs[1] * ks * ks)) ** 0.5)
+        b = rnd(k + 1, (1, k, 1, 1), 0.3)
+        node = make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad)))
+        outs = {}
+        for mode in ('0', '2'):
+            helpers.setenv(monkeypatch, 'PVHIP_WINO_SHARED', mode)
+            for act in (None, ('relu',), ('clamp', 0.0, 0.5)):
+                wide = dev.DeviceTensor.from_numpy(np.full((xs[0], k + 9, xs[2], xs[3]), -1.0, dtype=np.float32))
+                fused = dict(node)
+                fused['_fuse_bias'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), (wide, 4)
+                if act is not None:
+                    fused['_fuse_act'] = act
+                hip_plugin('Convolution').compute(fused, {0: x, 1: w})
+                outs[(mode, act)] = np.asarray(wide)
+        for act in (None, ('relu',), ('clamp', 0.0, 0.5)):
+            helpers.assert_bit_exact(outs[('2', act)], outs[('0', act)], 'shared V vs two workgroups {} k{} {}'.format(xs, k, act))
+            assert np.all(outs[('2', act)][:, :4] == -1.0) and np.all(outs[('2', act)][:, k + 4:] == -1.0)
+        want = first_out(oracle_plugin('Convolution').compute(dict(node), {0: x, 1: w}, kernel_type='special')) + b
+        assert_close(outs[('2', None)][:, 4:k + 4], want, 5e-5, 'shared V vs oracle {} k{}'.format(xs, k))
+
+
 @pytest.mark.parametrize('kb,waves', [(None, None), ('32', 'small'), ('32', '8'), ('64', '8'), ('32', '4'), ('64', '4')])
 def test_conv_winograd_3x3(hip, monkeypatch, kb, waves):
     """3x3 / stride 1 / pad 1 layers run Winograd F(2x2, 3x3) (the default): odd extents (half-empty last patches),
