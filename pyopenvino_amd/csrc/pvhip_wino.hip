@@ -692,15 +692,17 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     typedef float exv_t __attribute__((ext_vector_type(M)));      // the M column outputs of a (row, channel, patch): one LDS access
 #define PVW4_EPI_WRITE(pass)                                                                                     \
     {                                                                                                            \
-        _Pragma("unroll") for (int rr = 0; rr < CH / 2; ++rr) {                                                  \
+        _Pragma("unroll") for (int rr = 0; rr < CH / 2; rr += 2) {          /* two accumulator registers per step: packed fp32 (round 4) */ \
             const int r  = pass * (CH / 2) + rr;                          /* accumulator register */              \
-            const int kl = (rr & 3) + 8 * (rr >> 2) + 4 * lh_e;           /* channel inside the pass: 0 .. CH-1 */ \
-            float so[4];                                                                                         \
-            if (M == 4) wino4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1], so[2], so[3]); \
-            else        wino2_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], so[0], so[1]); \
-            exv_t sv;                                                                                            \
-            _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) sv[c2] = so[c2];                                    \
-            *reinterpret_cast<exv_t*>(Ex + ((row * CH + kl) * 32 + tl) * M) = sv;                                \
+            const int kl = (rr & 3) + 8 * (rr >> 2) + 4 * lh_e;           /* channel inside the pass: 0 .. CH-1 (register r + 1: the next one) */ \
+            w4_float2v mm_[6], so2_[4];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 6; ++j) mm_[j] = w4_float2v{acc[j][r], acc[j][r + 1]};         \
+            if (M == 4) wino4_at2(mm_[0], mm_[1], mm_[2], mm_[3], mm_[4], mm_[5], so2_[0], so2_[1], so2_[2], so2_[3]); \
+            else        wino2_at2(mm_[0], mm_[1], mm_[2], mm_[3], mm_[4], mm_[5], so2_[0], so2_[1]);             \
+            exv_t sv0_, sv1_;                                                                                    \
+            _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) { sv0_[c2] = so2_[c2].x; sv1_[c2] = so2_[c2].y; }   \
+            *reinterpret_cast<exv_t*>(Ex + ((row * CH + kl) * 32 + tl) * M) = sv0_;                              \
+            *reinterpret_cast<exv_t*>(Ex + ((row * CH + kl + 1) * 32 + tl) * M) = sv1_;                          \
         }                                                                                                        \
     }
 #define PVW4_EPI_NOWRITE(pass) {}
@@ -750,17 +752,20 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
                     exv_t ev[6];                                                                                 \
                     _Pragma("unroll") for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(Ex + ((i * CH + kl) * 32 + tl) * M); \
                     float yv[M][M];                                                                              \
-                    _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) {                                           \
-                        float col[4];                                                                            \
-                        if (M == 4) wino4_at(ev[0][c2], ev[1][c2], ev[2][c2], ev[3][c2], ev[4][c2], ev[5][c2], col[0], col[1], col[2], col[3]); \
-                        else        wino2_at(ev[0][c2], ev[1][c2], ev[2][c2], ev[3][c2], ev[4][c2], ev[5][c2], col[0], col[1]); \
-                        _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) yv[r2][c2] = col[r2];                   \
+                    _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {       /* two columns per step: packed fp32, the bias add too */ \
+                        w4_float2v em_[6], col2_[4];                                                             \
+                        _Pragma("unroll") for (int i = 0; i < 6; ++i) em_[i] = w4_float2v{ev[i][c2], ev[i][c2 + 1]}; \
+                        if (M == 4) wino4_at2(em_[0], em_[1], em_[2], em_[3], em_[4], em_[5], col2_[0], col2_[1], col2_[2], col2_[3]); \
+                        else        wino2_at2(em_[0], em_[1], em_[2], em_[3], em_[4], em_[5], col2_[0], col2_[1]); \
+                        _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) {                                       \
+                            const w4_float2v yb_ = col2_[r2] + w4_splat(bv);                                     \
+                            yv[r2][c2] = yb_.x;                                                                  \
+                            yv[r2][c2 + 1] = yb_.y;                                                              \
+                        }                                                                                        \
                     }                                                                                            \
                     /* bias and activation on all M x M values, the bounds behind WAVE-UNIFORM branches: act_apply's two compare-and- */ \
                     /* selects per value were 64 of the ~210 vector instructions of this block (plus 16 selects for "bias or not"),   */ \
                     /* and every vector instruction here competes with the other workgroup's MFMAs for the SIMD's issue slots          */ \
-                    _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2)                                             \
-                        _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = yv[r2][c2] + bv;           \
                     if (a.act != 0) {                                                                            \
                         _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2)                                         \
                             _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] < ab.lo) ? ab.lo : yv[r2][c2]; \
@@ -1319,8 +1324,10 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         }                                                                                                        \
     }
         // own stage o of a tile is stage s = 2 o + pair; own stages alternate between ring buffers `pair` (o even) and `pair + 2`
-        float* const VbA = &sm.V[pair][0][0][0];
-        float* const VbB = &sm.V[pair + 2][0][0][0];
+        // (scalar offsets turned into addresses where they are used: as pointers they sat in vector registers across the whole loop)
+        const int vb_off = __builtin_amdgcn_readfirstlane(pair * v_buf_floats);
+#define VbA (&sm.V[0][0][0][0] + vb_off)
+#define VbB (&sm.V[0][0][0][0] + vb_off + 2 * v_buf_floats)
         const unsigned readyA = PVS_LDS_ADDR(&sm.ready[0]) + 4u * (unsigned)pair, readyB = readyA + 8u;
         const unsigned doneA  = PVS_LDS_ADDR(&sm.done[0]) + 4u * (unsigned)pair,  doneB  = doneA + 8u;
         unsigned  use = 0u;                              // how often each of this pair's buffers has been filled
@@ -1377,6 +1384,8 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
 #undef PVS_ADDRESSES
 #undef PVS_GATHER
 #undef PVS_TRANSFORM_STORE
+#undef VbA
+#undef VbB
     } else {
         // ------------------------------------------------------------------ consumers
         const int cw  = wid - c_first;                              // 0 .. 11
