@@ -36,6 +36,7 @@ struct PoolConvArgs {
     int   relu;
     float act_lo, act_hi;
     int y_ctotal, y_coff;
+    int prio;             // producers at wave priority 3 (PVHIP_POOLCONV_PRIO=0: everything at 0)
     int abl;              // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no activation loads, 2 no pooling arithmetic, 4 no MFMAs, 8 no weight copies, 16 no stores
 };
 
@@ -100,6 +101,9 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
     floatx16 acc[TM];
     if (wid >= CONSUMERS) {
         // ------------------------------------------------------------------ producers
+        // (PVHIP_POOLCONV_PRIO: wave priorities were tried here after conv_wino4s_kernel's producers needed them -- producers first
+        // costs 11-14 % on the 14x14 modules, consumers first changes nothing: several independent workgroups per CU already interleave)
+        if (a.prio == 1) __builtin_amdgcn_s_setprio(3);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
         const int pl = (wid - CONSUMERS) * kWave + lane;       // 0 .. 255
         const int g = pl % GROUPS, cc = pl / GROUPS;
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
 #undef PVP_POOL
     } else {
         // ------------------------------------------------------------------ consumers
+        if (a.prio == 2) __builtin_amdgcn_s_setprio(3);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wp_bytes, 0x00020000);
         unsigned avoff[A_PER_WAVE];
 #pragma unroll
@@ -309,6 +314,7 @@ static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int 
     a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
     a.abl = 0;
+    a.prio = settings().poolconv_prio;
 #ifdef PVHIP_DIAG
     a.abl = settings().conv_ablate;
 #endif
