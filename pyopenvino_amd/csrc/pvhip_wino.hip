@@ -1148,6 +1148,18 @@ __device__ __forceinline__ void w4s_signal(unsigned lds_addr) {        // one in
                  : "=&s"(saved) : "v"(lds_addr), "v"(1u) : "memory");
 #endif
 }
+// one non-blocking look at a counter (wave-uniform result)
+__device__ __forceinline__ unsigned w4s_poll(unsigned lds_addr) {
+    unsigned sv = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %2\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_readfirstlane_b32 %1, %0"
+                 : "=&v"(v), "=&s"(sv) : "v"(lds_addr) : "memory");
+#endif
+    return sv;
+}
 // the increment with the count BEFORE it returned (wave-uniform): how many waves were here first
 __device__ __forceinline__ unsigned w4s_signal_rank(unsigned lds_addr) {
     unsigned sv = 0;
@@ -1185,12 +1197,13 @@ template <int M, bool RAGGED>
 __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
     static_assert(M == 4 || M == 2, "F(4x4,3x3) or F(2x2,5x5)");
     constexpr int PAD = (M == 4) ? 1 : 2;
-    constexpr int KB = 32, NT = 32, CONS = 12, CH = 12;
+    constexpr int KB = 32, NT = 32, CONS = 12;
     constexpr unsigned kOob = 0x80000000u;
+    constexpr int kExBuf = 6 * 4 * 32 * M;            // floats of one exchange buffer: [row][slot][patch][M columns], 4 slots = 2 accumulator registers x 2 lane halves
     struct Smem {
         float    V[kSRing][kXi4][kCB][NT];             // 4 x 18 KB
-        float    Ex[2][6 * CH * 32 * M];               // per group: [row][slot][patch][M columns]
-        unsigned ready[kSRing], done[kSRing], gbar[2];
+        float    Ex[2][2][kExBuf];                     // per group: two buffers of 12 KB (M = 4), passes alternate
+        unsigned ready[kSRing], done[kSRing], exfull[2][2], exfree[2][2];      // [group][buffer]: a wave may be a pass ahead of its neighbours, so the passes of a buffer are counted apart
     };
     __shared__ __attribute__((aligned(1024))) Smem sm;
     static_assert(sizeof(Smem) <= 150 * 1024, "one workgroup per CU");
@@ -1222,7 +1235,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
     constexpr int      v_buf_floats  = kXi4 * kCB * NT;
 
     if (tid < kSRing) { sm.ready[tid] = 0u; sm.done[tid] = 0u; }
-    if (tid < 2) sm.gbar[tid] = 0u;
+    if (tid < 4) { (&sm.exfull[0][0])[tid] = 0u; (&sm.exfree[0][0])[tid] = 0u; }
     __syncthreads();                                    // the only barrier of the kernel
     const unsigned long long t_entry = PVS_NOW();
     unsigned long long st[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -1332,6 +1345,104 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         const unsigned doneA  = PVS_LDS_ADDR(&sm.done[0]) + 4u * (unsigned)pair,  doneB  = doneA + 8u;
         unsigned  use = 0u;                              // how often each of this pair's buffers has been filled
         const int n_own = n_eff >> 1;                    // even
+        // ---- the second half of the epilogue is the PRODUCERS' work (pair g for consumer group g): a producer spends most of a stage
+        // waiting for a free ring buffer, while a consumer group that stores its own tile keeps its six MFMA streams idle for 15-22 k
+        // cycles per tile (stamps).  The consumers only apply the column half of Y = A^T D A to two accumulator registers at a time
+        // and leave them in one of the group's two exchange buffers (pass P -> buffer P & 1, counter exfull); a producer wave that
+        // finds a pass complete while it waits takes its 64 (slot, patch) items out (exfree: the buffer may be written again), applies
+        // the row half, bias and activation and stores.  Eight passes per tile; channel of (pass p, register half rr, lane half lh):
+        // register r = 2 p + rr -> (r & 3) + 8 (r >> 2) + 4 lh.
+        const int OH = a.H, OW = a.W;
+        const ActBounds ab = act_bounds(a.act, a.act_lo, a.act_hi);
+        typedef float exv_t __attribute__((ext_vector_type(M)));
+        const unsigned exfull_a = PVS_LDS_ADDR(&sm.exfull[0][0]) + 8u * (unsigned)pair, exfree_a = PVS_LDS_ADDR(&sm.exfree[0][0]) + 8u * (unsigned)pair;      // buffer 0; buffer 1: + 4
+        const int      ex_off   = __builtin_amdgcn_readfirstlane(pair * 2 * kExBuf);
+        const unsigned p_total  = L < n_tiles ? 8u * (unsigned)((n_tiles - L + G - 1) / G) : 0u;
+        unsigned       p_store  = 0u;                    // passes of this pair's group stored so far
+        const bool     even_w   = (OW & 1) == 0;
+        (void)even_w;
+#define PVS_STORE_PASS()                                                                                         \
+    {                                                                                                            \
+        const int it_ = (int)(p_store >> 3), p_ = (int)(p_store & 7u);                                           \
+        const int tile_s = L + it_ * G;                                                                          \
+        const int kb_e = 2 * (tile_s % n_kp) + pair, tb_e = tile_s / n_kp;                                       \
+        int lane_e;                                                                                              \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));            \
+        const int tl = lane_e & 31, lh_e = lane_e >> 5;                                                          \
+        const int r_  = 2 * p_ + pidx;                                   /* accumulator register of this wave's two slots */ \
+        const int kgs = kb_e * KB + (r_ & 3) + 8 * (r_ >> 2);            /* channel of lane half 0; half 1: + 4 */ \
+        const int kg  = kgs + 4 * lh_e;                                                                          \
+        float bs0 = -0.0f, bs1 = -0.0f;                                                                          \
+        if (a.bias != nullptr) {                                                                                 \
+            bs0 = bias_c[min(kgs, a.K - 1)];                                                                     \
+            bs1 = bias_c[min(kgs + 4, a.K - 1)];                                                                 \
+        }                                                                                                        \
+        const float* const exb = &sm.Ex[0][0][0] + ex_off + (int)(p_store & 1u) * kExBuf;                        \
+        const int slot = 2 * pidx + lh_e;                                                                        \
+        exv_t ev[6];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(exb + ((i * 4 + slot) * 32 + tl) * M); \
+        w4s_signal(exfree_a + 4u * (p_store & 1u));      /* LDS executes a wave's instructions in order: the six reads above come before this increment */ \
+        const int t = tb_e * NT + tl;                                                                            \
+        if (t < a.T && kg < a.K) {                                                                               \
+            const int n_ = w4_div(t, a.tpi_mul, a.tpi_sh), rem_ = t - n_ * TPI;                                  \
+            const int ty_ = w4_div(rem_, a.tx_mul, a.tx_sh), tx_ = rem_ - ty_ * a.TX;                            \
+            const int rows_ok = min(M, OH - M * ty_), cols_ok = min(M, OW - M * tx_);                            \
+            (void)rows_ok; (void)cols_ok;                                                                        \
+            const float bv = lh_e ? bs1 : bs0;                                                                   \
+            float* __restrict__ yp = a.y + ((((size_t)n_ * a.y_ctotal + a.y_coff + kg) * OH + M * ty_) * OW + M * tx_); \
+            float yv[M][M];                                                                                      \
+            _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {                                                \
+                w4_float2v em[6], col2[4];                                                                       \
+                _Pragma("unroll") for (int i = 0; i < 6; ++i) em[i] = w4_float2v{ev[i][c2], ev[i][c2 + 1]};      \
+                if (M == 4) wino4_at2(em[0], em[1], em[2], em[3], em[4], em[5], col2[0], col2[1], col2[2], col2[3]); \
+                else        wino2_at2(em[0], em[1], em[2], em[3], em[4], em[5], col2[0], col2[1]);               \
+                _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) {                                               \
+                    const w4_float2v yb = col2[r2] + w4_splat(bv);                                               \
+                    yv[r2][c2] = yb.x;                                                                           \
+                    yv[r2][c2 + 1] = yb.y;                                                                       \
+                }                                                                                                \
+            }                                                                                                    \
+            if (a.act != 0) {                                                                                    \
+                _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2)                                                 \
+                    _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] < ab.lo) ? ab.lo : yv[r2][c2]; \
+            }                                                                                                    \
+            if (a.act == 2) {                                                                                    \
+                _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2)                                                 \
+                    _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] > ab.hi) ? ab.hi : yv[r2][c2]; \
+            }                                                                                                    \
+            _Pragma("unroll") for (int r2 = 0; r2 < M; ++r2) {                                                   \
+                float ov[M];                                                                                     \
+                _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) ov[c2] = yv[r2][c2];                            \
+                if (RAGGED) {                                                                                    \
+                    if (r2 < rows_ok) {                                                                          \
+                        _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {                                    \
+                            if (even_w && c2 + 1 < cols_ok) conv_store2(yp + (size_t)r2 * OW + c2, ov[c2], ov[c2 + 1]); \
+                            else {                                                                               \
+                                if (c2 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2, ov[c2]);                \
+                                if (c2 + 1 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2 + 1, ov[c2 + 1]);    \
+                            }                                                                                    \
+                        }                                                                                        \
+                    }                                                                                            \
+                } else if (M == 4) conv_store4(yp + (size_t)r2 * OW, ov[0], ov[1], ov[2], ov[3]);                \
+                else conv_store2(yp + (size_t)r2 * OW, ov[0], ov[1]);                                            \
+            }                                                                                                    \
+        }                                                                                                        \
+        ++p_store;                                                                                               \
+    }
+        // a store pass if one is complete; false: nothing to do right now
+        auto try_store = [&]() -> bool {
+            if (p_store >= p_total) return false;
+            if ((int)(w4s_poll(exfull_a + 4u * (p_store & 1u)) - 6u * ((p_store >> 1) + 1u)) < 0) return false;      // all six rows of this pass are in the buffer
+            const unsigned long long s0_ = PVS_NOW();
+            PVS_STORE_PASS();
+            st[6] += PVS_NOW() - s0_;
+            return true;
+        };
+        // wait for a counter; store passes fill the time
+#define PVS_WAIT_OR_STORE(flag_, target_)                                                                        \
+    while ((int)(w4s_poll(flag_) - (target_)) < 0) {                                                             \
+        if (!try_store()) __builtin_amdgcn_s_sleep(1);                                                           \
+    }
         int tile = L;
         PVS_ADDRESSES(tile, zlo, zhi, nv);
         PVS_GATHER(vA, eA, pair);
@@ -1344,7 +1455,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
 #ifdef PVHIP_DIAG
                 { const unsigned seen_ = *(volatile unsigned*)&sm.done[pair]; PVS_TRACE(wid, 4u * use + (unsigned)pair, 0, t_entry + (unsigned long long)(seen_ * 1000u + (unsigned)CONS * use)); PVS_TRACE(wid, 4u * use + (unsigned)pair, 1, d0); }
 #endif
-                PVS_PWAIT(doneA, (unsigned)CONS * use);
+                PVS_WAIT_OR_STORE(doneA, (unsigned)CONS * use);
                 const unsigned long long p1 = PVS_NOW();
                 PVS_TRANSFORM_STORE(vA, eA, VbA, zlo, zhi, nv);
                 w4s_signal(readyA);
@@ -1353,7 +1464,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
                 const unsigned long long p3 = PVS_NOW();
                 PVS_DATA_WAIT();
                 const unsigned long long d1 = PVS_NOW();
-                PVS_PWAIT(doneB, (unsigned)CONS * use);
+                PVS_WAIT_OR_STORE(doneB, (unsigned)CONS * use);
                 const unsigned long long p4 = PVS_NOW();
                 PVS_TRANSFORM_STORE(vB, eB, VbB, zlo, zhi, nv);
                 w4s_signal(readyB);
@@ -1366,11 +1477,11 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
             }
             // the last two own stages of the tile: the gathers behind them are own stages 0 / 1 of the NEXT tile
             PVS_ADDRESSES(tile + G, zlo_n, zhi_n, nv_n);
-            w4s_wait_ge(doneA, (unsigned)CONS * use);
+            PVS_WAIT_OR_STORE(doneA, (unsigned)CONS * use);
             PVS_TRANSFORM_STORE(vA, eA, VbA, zlo, zhi, nv);
             w4s_signal(readyA);
             PVS_GATHER(vA, eA, pair);
-            w4s_wait_ge(doneB, (unsigned)CONS * use);
+            PVS_WAIT_OR_STORE(doneB, (unsigned)CONS * use);
             PVS_TRANSFORM_STORE(vB, eB, VbB, zlo, zhi, nv);
             w4s_signal(readyB);
             PVS_GATHER(vB, eB, 2 + pair);
@@ -1381,9 +1492,14 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
             tile += G;
             if (tile >= n_tiles) break;
         }
+        while (p_store < p_total) {                      // the last tile's passes
+            if (!try_store()) __builtin_amdgcn_s_sleep(1);
+        }
 #undef PVS_ADDRESSES
 #undef PVS_GATHER
 #undef PVS_TRANSFORM_STORE
+#undef PVS_STORE_PASS
+#undef PVS_WAIT_OR_STORE
 #undef VbA
 #undef VbB
     } else {
@@ -1397,16 +1513,13 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         const float* const vbs = &sm.V[0][0][0][0] + ((row * 6) * kCB + lh) * NT + l31;
         // wave-uniform offsets kept as SCALARS (readfirstlane) and turned into addresses where they are used: as pointers hipcc held them
         // in vector registers across the main loop, spilled them, and a spill reload is a vector memory load whose wait is vmcnt(0) (lesson 34)
-        const int ex_off = __builtin_amdgcn_readfirstlane(grp * (6 * CH * 32 * M));
-#define Exg  (&sm.Ex[0][0] + ex_off)
-        const unsigned gbar = PVS_LDS_ADDR(&sm.gbar[0]) + 4u * (unsigned)grp;
+        const int ex_off = __builtin_amdgcn_readfirstlane(grp * 2 * kExBuf);
+#define Exg  (&sm.Ex[0][0][0] + ex_off)
+        const unsigned exfull_a = PVS_LDS_ADDR(&sm.exfull[0][0]) + 8u * (unsigned)grp, exfree_a = PVS_LDS_ADDR(&sm.exfree[0][0]) + 8u * (unsigned)grp;
+        unsigned pass_n = 0u;                            // exchange passes of this group written so far
         const unsigned ready0 = PVS_LDS_ADDR(&sm.ready[0]), done0 = PVS_LDS_ADDR(&sm.done[0]);
-        unsigned gb_n = 0u;                              // counter barriers of this group passed so far
-        const int OH = a.H, OW = a.W;
-        const ActBounds ab = act_bounds(a.act, a.act_lo, a.act_hi);
         typedef float exv_t __attribute__((ext_vector_type(M)));
 #define PVS_U_BASE(tile_) ((unsigned)((2 * ((tile_) % n_kp) + grp) * (a.n_stages + 1)) * u_stage_bytes)
-#define PVS_GROUP_BARRIER() { const unsigned long long g0_ = PVS_NOW(); w4s_signal(gbar); ++gb_n; w4s_wait_ge(gbar, 6u * gb_n); const unsigned long long g1_ = PVS_NOW(); st[3] += g1_ - g0_; st[2] -= g1_ - g0_; }
         w4_float4v ua[3];
         {
             const unsigned u_first = PVS_U_BASE(L);
@@ -1470,122 +1583,46 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
                 { const unsigned long long c2 = PVS_NOW(); st[0] += c1 - c0; st[1] += c2 - c1; st[5] += 1; PVS_TRACE(wid, q, 0, c1); PVS_TRACE(wid, q, 1, c2); }
             }
             st[6] += 1;
-            // ---- epilogue of this group: Y = A^T D A, the column half in registers, the rows meet in Exg, 12 / 12 / 8 channels at a time
+            // ---- this group's half of the epilogue: the column half of Y = A^T D A on two accumulator registers at a time (packed fp32),
+            // left in the group's exchange buffer P & 1 for the producers (PVS_STORE_PASS); the consumers go straight on to the next tile
             const unsigned long long e0_ = PVS_NOW();
-            if (a.s_prio != 0) __builtin_amdgcn_s_setprio(3);       // in front of the other group's MFMA streams: the group comes back to its own sooner
             {
-                const int kb_e = 2 * (tile % n_kp) + grp, tb_e = tile / n_kp;
-                const bool even_w = (OW & 1) == 0;
-                (void)even_w;
-#pragma unroll
-                for (int pass = 0; pass < 3; ++pass) {
-                    constexpr int kFirst[3] = {0, 6, 12};
-                    const int R0 = kFirst[pass], NR = pass < 2 ? 6 : 4;
-                    // every per-lane value of a pass is made INSIDE it from a lane id hipcc can neither hoist nor merge: kept across the
-                    // passes (or the main loop) they are spilled, and a spill reload waits for vmcnt(0) -- behind the previous pass's stores
-                    int lane_e;
+                int lane_e;
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
 #else
-                    lane_e = 0;
+                lane_e = 0;
 #endif
-                    const int tl = lane_e & 31, lh_e = lane_e >> 5;
+                const int tl = lane_e & 31, lh_e = lane_e >> 5;
+                float* const mine = Exg + ((row * 4 + lh_e) * 32 + tl) * M;
 #pragma unroll
-                    for (int rr = 0; rr < 6; rr += 2) {       // two accumulator registers (slots 2 rr + lh, 2 rr + 2 + lh) per step: packed fp32
-                        if (rr < NR) {
-                            const int r = R0 + rr;
-                            w4_float2v mm[6], so2[4];
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) mm[j] = w4_float2v{acc[j][r], acc[j][r + 1]};
-                            if (M == 4) wino4_at2(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], so2[0], so2[1], so2[2], so2[3]);
-                            else        wino2_at2(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], so2[0], so2[1]);
-                            exv_t sv0, sv1;
-#pragma unroll
-                            for (int c2 = 0; c2 < M; ++c2) { sv0[c2] = so2[c2].x; sv1[c2] = so2[c2].y; }
-                            *reinterpret_cast<exv_t*>(Exg + ((row * CH + 2 * rr + lh_e) * 32 + tl) * M) = sv0;
-                            *reinterpret_cast<exv_t*>(Exg + ((row * CH + 2 * rr + 2 + lh_e) * 32 + tl) * M) = sv1;
-                        }
+                for (int p2 = 0; p2 < 8; ++p2) {
+                    const unsigned P = pass_n + (unsigned)p2;
+                    if (P >= 2u) {                        // the buffer's previous pass (P - 2) has been taken out by both producer waves
+                        const unsigned long long w0_ = PVS_NOW();
+                        w4s_wait_ge(exfree_a + 4u * (unsigned)(p2 & 1), 2u * (P >> 1));
+                        st[3] += PVS_NOW() - w0_;
                     }
-                    PVS_GROUP_BARRIER();
-                    if (row < NR) {                       // this wave: slots 2 row (lanes 0-31) and 2 row + 1 (lanes 32-63): register R0 + row
-                        const int r_  = R0 + row;
-                        const int m0  = (r_ & 3) + 8 * (r_ >> 2);            // channel of the block for lane half 0; half 1: + 4
-                        const int kgs = kb_e * KB + m0;
-                        const int kg  = kgs + 4 * lh_e;
-                        float bs0 = -0.0f, bs1 = -0.0f;
-                        if (a.bias != nullptr) {
-                            bs0 = bias_c[min(kgs, a.K - 1)];
-                            bs1 = bias_c[min(kgs + 4, a.K - 1)];
-                        }
-                        const int t  = tb_e * NT + tl;
-                        if (t < a.T && kg < a.K) {
-                            const int n_ = w4_div(t, a.tpi_mul, a.tpi_sh), rem_ = t - n_ * TPI;
-                            const int ty_ = w4_div(rem_, a.tx_mul, a.tx_sh), tx_ = rem_ - ty_ * a.TX;
-                            const int  rows_ok = min(M, OH - M * ty_), cols_ok = min(M, OW - M * tx_);
-                            (void)rows_ok; (void)cols_ok;
-                            const float bv = lh_e ? bs1 : bs0;
-                            float* __restrict__ yp = a.y + ((((size_t)n_ * a.y_ctotal + a.y_coff + kg) * OH + M * ty_) * OW + M * tx_);
-                            const int slot = 2 * row + lh_e;
-                            exv_t ev[6];
+                    const int r = 2 * p2;
+                    w4_float2v mm[6], so2[4];
 #pragma unroll
-                            for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(Exg + ((i * CH + slot) * 32 + tl) * M);
-                            float yv[M][M];
+                    for (int j = 0; j < 6; ++j) mm[j] = w4_float2v{acc[j][r], acc[j][r + 1]};
+                    if (M == 4) wino4_at2(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], so2[0], so2[1], so2[2], so2[3]);
+                    else        wino2_at2(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], so2[0], so2[1]);
+                    exv_t sv0, sv1;
 #pragma unroll
-                            for (int c2 = 0; c2 < M; c2 += 2) {          // two columns per step: packed fp32 (the bias add too)
-                                w4_float2v em[6], col2[4];
-#pragma unroll
-                                for (int i = 0; i < 6; ++i) em[i] = w4_float2v{ev[i][c2], ev[i][c2 + 1]};
-                                if (M == 4) wino4_at2(em[0], em[1], em[2], em[3], em[4], em[5], col2[0], col2[1], col2[2], col2[3]);
-                                else        wino2_at2(em[0], em[1], em[2], em[3], em[4], em[5], col2[0], col2[1]);
-#pragma unroll
-                                for (int r2 = 0; r2 < M; ++r2) {
-                                    const w4_float2v yb = col2[r2] + w4_splat(bv);
-                                    yv[r2][c2] = yb.x;
-                                    yv[r2][c2 + 1] = yb.y;
-                                }
-                            }
-                            if (a.act != 0) {
-#pragma unroll
-                                for (int r2 = 0; r2 < M; ++r2)
-#pragma unroll
-                                    for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] < ab.lo) ? ab.lo : yv[r2][c2];
-                            }
-                            if (a.act == 2) {
-#pragma unroll
-                                for (int r2 = 0; r2 < M; ++r2)
-#pragma unroll
-                                    for (int c2 = 0; c2 < M; ++c2) yv[r2][c2] = (yv[r2][c2] > ab.hi) ? ab.hi : yv[r2][c2];
-                            }
-#pragma unroll
-                            for (int r2 = 0; r2 < M; ++r2) {
-                                float ov[M];
-#pragma unroll
-                                for (int c2 = 0; c2 < M; ++c2) ov[c2] = yv[r2][c2];
-                                if (RAGGED) {
-                                    if (r2 < rows_ok) {
-#pragma unroll
-                                        for (int c2 = 0; c2 < M; c2 += 2) {
-                                            if (even_w && c2 + 1 < cols_ok) conv_store2(yp + (size_t)r2 * OW + c2, ov[c2], ov[c2 + 1]);
-                                            else {
-                                                if (c2 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2, ov[c2]);
-                                                if (c2 + 1 < cols_ok) conv_store1(yp + (size_t)r2 * OW + c2 + 1, ov[c2 + 1]);
-                                            }
-                                        }
-                                    }
-                                } else if (M == 4) conv_store4(yp + (size_t)r2 * OW, ov[0], ov[1], ov[2], ov[3]);
-                                else conv_store2(yp + (size_t)r2 * OW, ov[0], ov[1]);
-                            }
-                        }
-                    }
-                    PVS_GROUP_BARRIER();                  // the exchange area is read out: the next pass (or tile) may write it
+                    for (int c2 = 0; c2 < M; ++c2) { sv0[c2] = so2[c2].x; sv1[c2] = so2[c2].y; }
+                    float* const dst = mine + (p2 & 1) * kExBuf;
+                    *reinterpret_cast<exv_t*>(dst) = sv0;                       // slot lh (register r)
+                    *reinterpret_cast<exv_t*>(dst + 2 * 32 * M) = sv1;          // slot 2 + lh (register r + 1)
+                    w4s_signal(exfull_a + 4u * (unsigned)(p2 & 1));
                 }
+                pass_n += 8u;
             }
-            if (a.s_prio != 0) __builtin_amdgcn_s_setprio(1);
             st[2] += PVS_NOW() - e0_;
         }
 #undef PVS_LOAD_U
 #undef PVS_U_BASE
-#undef PVS_GROUP_BARRIER
 #undef Exg
     }
 #ifdef PVHIP_DIAG
