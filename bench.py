@@ -655,17 +655,27 @@ def main():
                         for fam, agg in families.items():
                             if agg['flops'] <= 0:
                                 continue
-                            key = ('conv_pool1x1_kernel' if 'conv_pool1x1' in fam else 'conv_wino4_kernel' if ('F(4x4' in fam or '5x5)' in fam)
+                            key = ('conv_pool1x1_kernel' if 'conv_pool1x1' in fam else 'winograd6' if ('F(4x4' in fam or '5x5)' in fam)
                                    else 'conv_wino_kernel' if 'F(2x2,3x3)' in fam else 'conv_stem_kernel' if 'stem' in fam
                                    else 'conv_module_kernel' if 'module launch' in fam else 'conv_pw_kernel' if 'pointwise' in fam
                                    else 'conv_igemm_dma_kernel')
                             a = algo.setdefault(key, [0.0, 0])
                             a[0] += agg['bytes']
                             a[1] += agg['launches']
+                        # the six-point layers run on two kernels (conv_wino4s_kernel: shared V; conv_wino4_kernel: two workgroups per CU) and the
+                        # per-layer table does not say which: their counted traffic is merged for the ratio
+                        fams = dict(doc.get('convolution_kernels_by_family', {}))
+                        six = [fams.pop(k) for k in ('conv_wino4s_kernel', 'conv_wino4_kernel') if k in fams]
+                        if six:
+                            n6 = sum(v.get('launches_per_step') or 0 for v in six) or 1.0
+                            fams['winograd6'] = {'launches_per_step': n6,
+                                                 'read_bytes_per_launch': sum(v['read_bytes_per_launch'] * (v.get('launches_per_step') or 0) for v in six) / n6,
+                                                 'write_bytes_per_launch': sum(v['write_bytes_per_launch'] * (v.get('launches_per_step') or 0) for v in six) / n6}
                         traffic_by_kernel = {}
-                        for name, v in doc.get('convolution_kernels_by_family', {}).items():
+                        for name, v in fams.items():
+                            name = 'conv_wino4s_kernel + conv_wino4_kernel' if name == 'winograd6' else name
                             counted = v['read_bytes_per_launch'] + v['write_bytes_per_launch']
-                            a = algo.get(name)
+                            a = algo.get('winograd6' if name.startswith('conv_wino4s_kernel +') else name)
                             per_launch = (a[0] / a[1]) if a and a[1] else None
                             traffic_by_kernel[name] = {'launches_per_step': v.get('launches_per_step'), 'bytes_per_launch': counted,
                                                        'read_bytes_per_launch': v['read_bytes_per_launch'], 'write_bytes_per_launch': v['write_bytes_per_launch'],
@@ -697,7 +707,7 @@ def main():
                         'sustained': dict(sustained, frac_of_sustained=round(tf_exec / sustained['TFLOPs'], 3)) if sustained else None,
                         'traffic': traffic, 'traffic_source': traffic_src, 'traffic_by_kernel': traffic_by_kernel or None,
                         'traffic_ratio': round(traffic / (conv['bytes'] / n_launch), 3) if traffic else None,
-                        'kernel': 'all Convolution launches of a step: conv_wino4_kernel (F(4x4,3x3), F(2x2,5x5)) + conv_wino_kernel (F(2x2,3x3)) + conv_pw_kernel '
+                        'kernel': 'all Convolution launches of a step: conv_wino4s_kernel / conv_wino4_kernel (F(4x4,3x3), F(2x2,5x5): shared-V form where it pays) + conv_wino_kernel (F(2x2,3x3)) + conv_pw_kernel '
                                   '(1x1; the 1x1 / 3x3_reduce / 5x5_reduce convolutions of an inception module are one launch) + conv_pool1x1_kernel (MaxPool + pool_proj) '
                                   '+ conv_igemm_dma_kernel (conv1, the 7x7-sized 5x5): {} launches per step for the 57 Convolution nodes, bias+ReLU fused'.format(n_launch),
                         'launches_per_step': n_launch, 'flops_per_launch': flops_per_launch, 'flops_executed_per_launch': conv['exec'] / n_launch,

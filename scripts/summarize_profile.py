@@ -20,7 +20,7 @@ def is_conv(name):
 
 def conv_family(name):
     """Which convolution kernel: the split of `convolution_kernels` (profiles/<tag>_traffic.json: convolution_kernels_by_family)."""
-    for key, fam in (('conv_wino4_kernel', 'conv_wino4_kernel'), ('conv_wino_kernel', 'conv_wino_kernel'), ('conv_pw_kernel', 'conv_pw_kernel'),
+    for key, fam in (('conv_wino4s_kernel', 'conv_wino4s_kernel'), ('conv_wino4_kernel', 'conv_wino4_kernel'), ('conv_wino_kernel', 'conv_wino_kernel'), ('conv_pw_kernel', 'conv_pw_kernel'),
                      ('conv_pool1x1_kernel', 'conv_pool1x1_kernel'), ('conv_igemm_dma_kernel', 'conv_igemm_dma_kernel'), ('conv_igemm', 'conv_igemm_other')):
         if key in name:
             return fam
@@ -62,7 +62,7 @@ def main():
                 conv_total_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         if conv_calls:
-            md += ['', '**conv_wino4_kernel + conv_wino_kernel + conv_pw_kernel + conv_igemm_dma_kernel + conv_pool1x1_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+            md += ['', '**conv_wino4s_kernel + conv_wino4_kernel + conv_wino_kernel + conv_pw_kernel + conv_igemm_dma_kernel + conv_pool1x1_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of {} launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * per_pass / 1e6, per_pass)]
     trace = find(os.path.join(raw, 'stats'), '*kernel_trace.csv')
@@ -145,7 +145,7 @@ def main():
                 fa[r['Counter_Name']] = fa.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
         if agg.get('GRBM_GUI_ACTIVE'):
             cyc = agg['GRBM_GUI_ACTIVE'] / 8.0
-            md += ['', '## convolution kernels (conv_wino4 + conv_wino + conv_pw + conv_igemm_dma + conv_pool1x1), SQ counters summed over their launches', '']
+            md += ['', '## convolution kernels (conv_wino4s + conv_wino4 + conv_wino + conv_pw + conv_igemm_dma + conv_pool1x1), SQ counters summed over their launches', '']
             md += ['- MFMA pipe busy: {:.1f} % of SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))'.format(
                 100.0 * agg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / cyc)]
             if agg.get('SQ_BUSY_CU_CYCLES'):
