@@ -653,7 +653,7 @@ def main():
                         # the counted ones: traffic_ratio well above 1 = re-reads
                         algo = {}
                         for fam, agg in families.items():
-                            if agg['flops'] <= 0:
+                            if agg['flops'] <= 0 or fam == 'MatMul':
                                 continue
                             key = ('conv_pool1x1_kernel' if 'conv_pool1x1' in fam else 'winograd6' if ('F(4x4' in fam or '5x5)' in fam)
                                    else 'conv_wino_kernel' if 'F(2x2,3x3)' in fam else 'conv_stem_kernel' if 'stem' in fam
