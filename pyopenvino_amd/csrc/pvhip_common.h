@@ -60,7 +60,8 @@ struct Settings {
     int  wino_shared = 1;                  // PVHIP_WINO_SHARED=0|1|2: the shared-V form of the six-point kernels never / by the tile rule / wherever it applies
     int  wino_shared_prio = 1;             // PVHIP_WINO_SHARED_PRIO=0: no wave priorities in the shared-V form (A/B runs)
     int  wino_shared_old = 1;              // PVHIP_WINO_SHARED_OLD=0: the producers of the shared-V form are the youngest waves (A/B runs)
-    int  wino_shared_lag = 1;              // PVHIP_WINO_SHARED_LAG=0: both consumer groups of the shared-V form start together (A/B runs)
+    bool wino_shared_odd = true;           // PVHIP_WINO_SHARED_ODD=0: the shared-V form only for an even number of channel blocks
+    int  wino_shared_lag = 0;              // PVHIP_WINO_SHARED_LAG=1: the second consumer group of the shared-V form starts three stages behind the first (A/B runs: no gain, the ring bounds the stagger anyway)
     int  wino_shared_min_tiles = 2048;      // PVHIP_WINO_SHARED_MIN_TILES: tiles (patch blocks x channel-block pairs) from which the rule picks it for launches of 12-16 stages
     // ---- wrong-on-purpose ablations: honoured only by the diagnostic build (make diag -> libpvhip_diag.so, -DPVHIP_DIAG)
     int  conv_ablate = 0, wino4_ablate = 0, pw_ablate = 0;

@@ -1090,6 +1090,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
 // Same arithmetic in the same order as conv_wino4_kernel: the same bits (tests: test_conv_winograd_shared_v_has_the_bits...).
 // For launches with an even number of channel blocks, a stage count that is a multiple of four and enough tiles (wino4_conv).
 constexpr int kSRing = 4;
+constexpr int kSEx   = 3;      // exchange buffers per consumer group (epilogue passes in flight)
 constexpr int kSLag  = 3;      // stages the second consumer group starts behind the first (< kSRing)
 
 // The two counter primitives, in ONE asm statement each (a spin loop or a branch in C++ between a wave's loads and their first use
@@ -1202,8 +1203,8 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
     constexpr int kExBuf = 6 * 4 * 32 * M;            // floats of one exchange buffer: [row][slot][patch][M columns], 4 slots = 2 accumulator registers x 2 lane halves
     struct Smem {
         float    V[kSRing][kXi4][kCB][NT];             // 4 x 18 KB
-        float    Ex[2][2][kExBuf];                     // per group: two buffers of 12 KB (M = 4), passes alternate
-        unsigned ready[kSRing], done[kSRing], exfull[2][2], exfree[2][2];      // [group][buffer]: a wave may be a pass ahead of its neighbours, so the passes of a buffer are counted apart
+        float    Ex[2][kSEx][kExBuf];                  // per group: kSEx buffers of 12 KB (M = 4), pass P in buffer P % kSEx
+        unsigned ready[kSRing], done[kSRing], exfull[2][kSEx], exfree[2][kSEx];      // [group][buffer]: a wave may be a pass ahead of its neighbours, so the passes of a buffer are counted apart
     };
     __shared__ __attribute__((aligned(1024))) Smem sm;
     static_assert(sizeof(Smem) <= 150 * 1024, "one workgroup per CU");
@@ -1215,7 +1216,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         const int xcd = bid & 7, q = G >> 3, r = G & 7;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int n_kp    = a.n_kb >> 1;                    // pairs of channel blocks
+    const int n_kp    = (a.n_kb + 1) >> 1;              // pairs of channel blocks (an odd count: the last pair is one block, its second consumer group only keeps the counters going)
     const int n_tiles = a.n_tiles;                      // patch blocks x pairs
     const int n_eff   = a.n_stages;                     // a multiple of 4 (wino4_conv)
 
@@ -1235,7 +1236,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
     constexpr int      v_buf_floats  = kXi4 * kCB * NT;
 
     if (tid < kSRing) { sm.ready[tid] = 0u; sm.done[tid] = 0u; }
-    if (tid < 4) { (&sm.exfull[0][0])[tid] = 0u; (&sm.exfree[0][0])[tid] = 0u; }
+    if (tid < 2 * kSEx) { (&sm.exfull[0][0])[tid] = 0u; (&sm.exfree[0][0])[tid] = 0u; }
     __syncthreads();                                    // the only barrier of the kernel
     const unsigned long long t_entry = PVS_NOW();
     unsigned long long st[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -1355,8 +1356,8 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         const int OH = a.H, OW = a.W;
         const ActBounds ab = act_bounds(a.act, a.act_lo, a.act_hi);
         typedef float exv_t __attribute__((ext_vector_type(M)));
-        const unsigned exfull_a = PVS_LDS_ADDR(&sm.exfull[0][0]) + 8u * (unsigned)pair, exfree_a = PVS_LDS_ADDR(&sm.exfree[0][0]) + 8u * (unsigned)pair;      // buffer 0; buffer 1: + 4
-        const int      ex_off   = __builtin_amdgcn_readfirstlane(pair * 2 * kExBuf);
+        const unsigned exfull_a = PVS_LDS_ADDR(&sm.exfull[0][0]) + 4u * kSEx * (unsigned)pair, exfree_a = PVS_LDS_ADDR(&sm.exfree[0][0]) + 4u * kSEx * (unsigned)pair;      // buffer 0; buffer b: + 4 b
+        const int      ex_off   = __builtin_amdgcn_readfirstlane(pair * kSEx * kExBuf);
         const unsigned p_total  = L < n_tiles ? 8u * (unsigned)((n_tiles - L + G - 1) / G) : 0u;
         unsigned       p_store  = 0u;                    // passes of this pair's group stored so far
         const bool     even_w   = (OW & 1) == 0;
@@ -1377,11 +1378,12 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
             bs0 = bias_c[min(kgs, a.K - 1)];                                                                     \
             bs1 = bias_c[min(kgs + 4, a.K - 1)];                                                                 \
         }                                                                                                        \
-        const float* const exb = &sm.Ex[0][0][0] + ex_off + (int)(p_store & 1u) * kExBuf;                        \
+        const unsigned pb_ = p_store % (unsigned)kSEx;                                                           \
+        const float* const exb = &sm.Ex[0][0][0] + ex_off + (int)pb_ * kExBuf;                                   \
         const int slot = 2 * pidx + lh_e;                                                                        \
         exv_t ev[6];                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(exb + ((i * 4 + slot) * 32 + tl) * M); \
-        w4s_signal(exfree_a + 4u * (p_store & 1u));      /* LDS executes a wave's instructions in order: the six reads above come before this increment */ \
+        w4s_signal(exfree_a + 4u * pb_);                 /* LDS executes a wave's instructions in order: the six reads above come before this increment */ \
         const int t = tb_e * NT + tl;                                                                            \
         if (t < a.T && kg < a.K) {                                                                               \
             const int n_ = w4_div(t, a.tpi_mul, a.tpi_sh), rem_ = t - n_ * TPI;                                  \
@@ -1432,7 +1434,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         // a store pass if one is complete; false: nothing to do right now
         auto try_store = [&]() -> bool {
             if (p_store >= p_total) return false;
-            if ((int)(w4s_poll(exfull_a + 4u * (p_store & 1u)) - 6u * ((p_store >> 1) + 1u)) < 0) return false;      // all six rows of this pass are in the buffer
+            if ((int)(w4s_poll(exfull_a + 4u * (p_store % (unsigned)kSEx)) - 6u * (p_store / (unsigned)kSEx + 1u)) < 0) return false;      // all six rows of this pass are in the buffer
             const unsigned long long s0_ = PVS_NOW();
             PVS_STORE_PASS();
             st[6] += PVS_NOW() - s0_;
@@ -1513,13 +1515,13 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         const float* const vbs = &sm.V[0][0][0][0] + ((row * 6) * kCB + lh) * NT + l31;
         // wave-uniform offsets kept as SCALARS (readfirstlane) and turned into addresses where they are used: as pointers hipcc held them
         // in vector registers across the main loop, spilled them, and a spill reload is a vector memory load whose wait is vmcnt(0) (lesson 34)
-        const int ex_off = __builtin_amdgcn_readfirstlane(grp * 2 * kExBuf);
+        const int ex_off = __builtin_amdgcn_readfirstlane(grp * kSEx * kExBuf);
 #define Exg  (&sm.Ex[0][0][0] + ex_off)
-        const unsigned exfull_a = PVS_LDS_ADDR(&sm.exfull[0][0]) + 8u * (unsigned)grp, exfree_a = PVS_LDS_ADDR(&sm.exfree[0][0]) + 8u * (unsigned)grp;
+        const unsigned exfull_a = PVS_LDS_ADDR(&sm.exfull[0][0]) + 4u * kSEx * (unsigned)grp, exfree_a = PVS_LDS_ADDR(&sm.exfree[0][0]) + 4u * kSEx * (unsigned)grp;
         unsigned pass_n = 0u;                            // exchange passes of this group written so far
         const unsigned ready0 = PVS_LDS_ADDR(&sm.ready[0]), done0 = PVS_LDS_ADDR(&sm.done[0]);
         typedef float exv_t __attribute__((ext_vector_type(M)));
-#define PVS_U_BASE(tile_) ((unsigned)((2 * ((tile_) % n_kp) + grp) * (a.n_stages + 1)) * u_stage_bytes)
+#define PVS_U_BASE(tile_) ((unsigned)(min(2 * ((tile_) % n_kp) + grp, a.n_kb - 1) * (a.n_stages + 1)) * u_stage_bytes)
         w4_float4v ua[3];
         {
             const unsigned u_first = PVS_U_BASE(L);
@@ -1535,6 +1537,25 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         if (grp == 1 && a.s_lag != 0) w4s_wait_ge(done0 + 4u * (unsigned)(kSLag - 1), 6u);
         for (int tile = L; tile < n_tiles; tile += G) {
             const unsigned u_base = PVS_U_BASE(tile), u_next = PVS_U_BASE(tile + G);
+            if (2 * (tile % n_kp) + grp >= a.n_kb) {
+                // the unpaired last block of an odd count: this group has no channels in the tile.  It releases every image at once and
+                // hands the producers empty passes (they store nothing: kg >= K), so that the counters of both protocols keep their meaning
+                for (int s = 0; s < n_eff; ++s, ++q) {
+                    const unsigned b = q & (kSRing - 1);
+                    w4s_wait_ge(ready0 + 4u * b, 2u * ((q >> 2) + 1u));
+                    w4s_signal(done0 + 4u * b);
+                }
+                for (int p2 = 0; p2 < 8; ++p2) {
+                    const unsigned P = pass_n + (unsigned)p2, pb = P % (unsigned)kSEx;
+                    if (P >= (unsigned)kSEx) w4s_wait_ge(exfree_a + 4u * pb, 2u * (P / (unsigned)kSEx));
+                    w4s_signal(exfull_a + 4u * pb);
+                }
+                pass_n += 8u;
+                PVS_LOAD_U(ua, u_next, 0);           // the next tile finds its first weight image in the registers, as after a tile of its own
+                PVS_LOAD_U(ua, u_next, 1);
+                PVS_LOAD_U(ua, u_next, 2);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -1586,6 +1607,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
             // ---- this group's half of the epilogue: the column half of Y = A^T D A on two accumulator registers at a time (packed fp32),
             // left in the group's exchange buffer P & 1 for the producers (PVS_STORE_PASS); the consumers go straight on to the next tile
             const unsigned long long e0_ = PVS_NOW();
+            if (a.s_prio != 0) __builtin_amdgcn_s_setprio(3);       // ~300 vector instructions between two tiles of MFMAs: in front of the other group's streams
             {
                 int lane_e;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1597,10 +1619,10 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
                 float* const mine = Exg + ((row * 4 + lh_e) * 32 + tl) * M;
 #pragma unroll
                 for (int p2 = 0; p2 < 8; ++p2) {
-                    const unsigned P = pass_n + (unsigned)p2;
-                    if (P >= 2u) {                        // the buffer's previous pass (P - 2) has been taken out by both producer waves
+                    const unsigned P = pass_n + (unsigned)p2, pb = P % (unsigned)kSEx;
+                    if (P >= (unsigned)kSEx) {            // the buffer's previous pass (P - kSEx) has been taken out by both producer waves: P / kSEx passes x 2 waves
                         const unsigned long long w0_ = PVS_NOW();
-                        w4s_wait_ge(exfree_a + 4u * (unsigned)(p2 & 1), 2u * (P >> 1));
+                        w4s_wait_ge(exfree_a + 4u * pb, 2u * (P / (unsigned)kSEx));
                         st[3] += PVS_NOW() - w0_;
                     }
                     const int r = 2 * p2;
@@ -1612,13 +1634,14 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
                     exv_t sv0, sv1;
 #pragma unroll
                     for (int c2 = 0; c2 < M; ++c2) { sv0[c2] = so2[c2].x; sv1[c2] = so2[c2].y; }
-                    float* const dst = mine + (p2 & 1) * kExBuf;
+                    float* const dst = mine + (int)pb * kExBuf;
                     *reinterpret_cast<exv_t*>(dst) = sv0;                       // slot lh (register r)
                     *reinterpret_cast<exv_t*>(dst + 2 * 32 * M) = sv1;          // slot 2 + lh (register r + 1)
-                    w4s_signal(exfull_a + 4u * (unsigned)(p2 & 1));
+                    w4s_signal(exfull_a + 4u * pb);
                 }
                 pass_n += 8u;
             }
+            if (a.s_prio != 0) __builtin_amdgcn_s_setprio(1);
             st[2] += PVS_NOW() - e0_;
         }
 #undef PVS_LOAD_U
@@ -1781,12 +1804,14 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     // PVHIP_WINO_SHARED=0 never, =2 wherever it applies.
     {
         const int  mode = settings().wino_shared;
-        const long tiles_s = n_tb * (a.n_kb / 2);
-        const bool shape_ok = a.n_kb % 2 == 0 && a.n_stages % 4 == 0 && a.n_stages >= 4;
+        const long tiles_s = n_tb * ((a.n_kb + 1) / 2);
+        const bool shape_ok = a.n_kb >= 2 && a.n_stages % 4 == 0 && a.n_stages >= 4 && (a.n_kb % 2 == 0 || mode == 2 || settings().wino_shared_odd);
         // Measured on GoogLeNet's layers at batch 256 (scripts/time_wino_shared.py, same box, alternating): it wins where the main loop is
-        // long against the two epilogues of a tile -- C >= 112: 3b -6 %, 4c -7 %, 4e -9 %, 5a -6 %, 5b -11 % -- and on conv2/3x3 (C = 64,
-        // 4704 tiles: -4 %); it loses at C = 96 (3a: +8 %) and is a wash on the 5x5 layers (4 .. 12 stages per tile).
-        const bool pays = a.n_stages >= 28 || (a.n_stages <= 16 && a.n_stages >= 12 && tiles_s >= (long)settings().wino_shared_min_tiles);
+        // long against the epilogue passes of a tile -- C >= 112: 3b -9..-11 %, 4b -9 %, 4c -7 %, 4d -9 %, 4e -9 %, 5a -9 %, 5b -11..-13 %; the
+        // 14x14 layer with C = 96 (4a: -8 %) -- and on conv2/3x3 (C = 64, 4704 tiles: -4..-12 %); it loses on the 28x28 layer with C = 96
+        // (3a: +2 %) and is a wash on the 5x5 layers (4 .. 12 stages per tile).
+        const bool pays = a.n_stages >= 28 || (a.n_stages >= 24 && ragged) ||
+                          (a.n_stages <= 16 && a.n_stages >= 12 && tiles_s >= (long)settings().wino_shared_min_tiles);
         if (mode != 0 && shape_ok && (mode == 2 || pays)) {
             a.n_tiles = (int)tiles_s;
             const dim3 grid_s((unsigned)(tiles_s < kNumCU ? tiles_s : kNumCU));

@@ -281,15 +281,16 @@ def test_conv_winograd_f4x4_3x3(hip, monkeypatch):
 def test_conv_winograd_shared_v_form_has_the_bits_of_the_two_workgroup_form(hip, monkeypatch, ks):
     """conv_wino4s_kernel (round 4: two channel blocks on ONE transformed image per stage, 16 waves, LDS counters instead of barriers)
     against conv_wino4_kernel: the same arithmetic in the same order, so the same bits -- whole and ragged extents, several tiles per
-    workgroup, patch blocks that end inside an image, partial last channel block, fused bias + ReLU / Clamp into a wider tensor;
-    and against the oracle.  Shapes the shared form does not take (odd number of channel blocks, stage count not a multiple of
+    workgroup, patch blocks that end inside an image, partial last channel block, an odd number of channel blocks, fused bias + ReLU / Clamp into a wider tensor;
+    and against the oracle.  Shapes the shared form does not take (a single channel block, a stage count that is not a multiple of
     four) fall back to the two-workgroup form by themselves."""
     from pyopenvino_amd import device as dev
     helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD4', 'force')
     helpers.setenv(monkeypatch, 'PVHIP_CONV_WINOGRAD5', 'force')
     pad = ks // 2
     cases = [((2, 16, 8, 8), 64), ((3, 32, 12, 16), 40), ((1, 64, 56, 56), 128), ((9, 16, 28, 28), 192), ((5, 48, 14, 14), 100),
-             ((40, 16, 7, 7), 64), ((3, 80, 5, 9), 33), ((600, 16, 4, 4), 64), ((2, 16, 8, 8), 32), ((2, 24, 8, 8), 64)]
+             ((40, 16, 7, 7), 64), ((3, 80, 5, 9), 33), ((600, 16, 4, 4), 64), ((2, 16, 8, 8), 32), ((2, 24, 8, 8), 64),
+             ((5, 32, 14, 14), 96), ((700, 16, 4, 4), 160), ((3, 16, 12, 12), 208)]       # odd numbers of channel blocks: the last pair is one block
     for xs, k in cases:
         x = rnd(sum(xs), xs)
         w = rnd(k, (k, xs[1], ks, ks), (2.0 / (xs[1] * ks * ks)) ** 0.5)
