@@ -57,6 +57,10 @@ __device__ __forceinline__ void pc_load(pc_f4& d, __amdgpu_buffer_rsrc_t r, unsi
 __device__ __forceinline__ void pc_load(pc_f2& d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     d = __builtin_bit_cast(pc_f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+typedef float pc_f1 __attribute__((ext_vector_type(1)));
+__device__ __forceinline__ void pc_load(pc_f1& d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    d[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 
 // kF16 (FP16 IRs): the same tiles, a stage of 16 channels as ONE v_mfma_f32_32x32x16_f16 per 32-channel tile, both operands rounded to
 // fp16 as they are read from LDS (the maximum of the window is taken in fp32, then rounded: what MaxPool followed by pvhip_conv2d_f16_dma does)
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
         // column themselves (one more dword load per row, live in two lanes of GROUPS).
         unsigned offv[3], offe[3];
         bool     zl, zr;                         // the group touches the left / right border: its outer column is padding
-        const bool first = g == 0, last = g == GROUPS - 1;
+        // (VEC = 1, round 4: 128 single-pixel groups span two waves, and a DPP shift ends at the wave: its first and last lane load their outer column too)
+        const bool first = g == 0 || (VEC == 1 && lane == 0), last = g == GROUPS - 1 || (VEC == 1 && lane == kWave - 1);
         {
             const int gp = ptile * BN + g * VEC;
             const bool live = gp < a.P;
@@ -276,12 +281,15 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
 inline int round_up_int(int v, int q) { return (v + q - 1) / q * q; }
 
 bool pooled_supported(int n, int c, int h, int w, int k_out) {
-    // Rows of whole 16-byte groups (28x28 modules) or 8-byte groups (14x14); PVHIP_FUSE_POOLCONV=4 keeps it to the former (A/B runs)
+    // Rows of whole 16-byte groups (28x28 modules) or 8-byte groups (14x14); PVHIP_FUSE_POOLCONV=4 keeps it to the former (A/B runs).
+    // Round 4: odd widths (7x7 modules) with single-pixel groups, for 65 .. 128 output channels (the 128-channel form has the
+    // registers for eight iterations of loads in flight) only with PVHIP_FUSE_POOLCONV=1: on GoogLeNet's 7x7 modules the fused launch
+    // takes 0.089 ms against 0.021 + 0.043 for the two (three dword loads per pooled value), so the default keeps them apart
     if (settings().fuse_poolconv == 0) return false;
-    const int min_vec = settings().fuse_poolconv == 4 ? 4 : 2;
+    const int min_vec = settings().fuse_poolconv == 4 ? 4 : (settings().fuse_poolconv == 2 ? 2 : 1);
     if (w % min_vec != 0) return false;
     if (n <= 0 || c < kBK || c % kBK != 0 || h <= 0 || w <= 0 || k_out <= 0 || k_out > 128) return false;
-    if (w % 2 != 0) return false;                                       // aligned 8- or 16-byte groups that never straddle a row
+    if (w % 2 != 0 && k_out <= 64) return false;
     if ((unsigned long long)n * c * h * w >= (1ull << 29)) return false;
     return true;
 }
@@ -333,7 +341,10 @@ static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int 
             else    hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 2>), grid, block, 0, state().stream, a);         \
         }                                                                                                         \
     } while (0)
-    if (bm == 32) PVP_LAUNCH(32);
+    if (w % 2 != 0) {                   // odd width: single-pixel groups, 128-channel tiles only (pooled_supported)
+        if (f16) hipLaunchKernelGGL((conv_pool1x1_kernel<128, 1, true>), grid, block, 0, state().stream, a);
+        else     hipLaunchKernelGGL((conv_pool1x1_kernel<128, 1>), grid, block, 0, state().stream, a);
+    } else if (bm == 32) PVP_LAUNCH(32);
     else if (bm == 64) PVP_LAUNCH(64);
     else PVP_LAUNCH(128);
 #undef PVP_LAUNCH

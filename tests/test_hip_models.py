@@ -153,7 +153,7 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
     _, net_u, ex_u = build_network(HIP, 'googlenet-v1', weights=blob, batch=2, fuse=False)
     assert len(ex_f._fusion) == 57 and len(ex_f._fused_away) == 114 + 9 + 2 + 18 + 7 + 1 and len(ex_f._concat_direct) == 9 and not ex_u._fusion
     assert len(ex_f._pre_add) == 1 and not ex_u._pre_add              # data/mean folded into conv1's padding pass
-    assert len(ex_f._pool_conv) == 7 and not ex_u._pool_conv           # pool + pool_proj of the 28x28 and 14x14 modules (3a .. 4e) as one launch
+    assert len(ex_f._pool_conv) == 7 and not ex_u._pool_conv           # pool + pool_proj of the 28x28 and 14x14 modules (3a .. 4e) as one launch (the 7x7 ones only with PVHIP_FUSE_POOLCONV=1: slower)
     assert len(ex_f._siblings) == 9 and not ex_u._siblings            # 1x1 + 3x3_reduce + 5x5_reduce of a module as one launch
     assert len(ex_f._lrn_pool) == 2 and not ex_u._lrn_pool          # conv2/norm2 -> pool2/3x3_s2 and pool1/3x3_s2 -> pool1/norm1 as one launch each
     out_f, out_u = infer_one(ex_f, net_f, x), infer_one(ex_u, net_u, x)

@@ -722,15 +722,21 @@ def test_sibling_convolutions_decline_other_geometries(hip):
 
 
 @pytest.mark.parametrize('xs,k', [((3, 192, 28, 28), 32), ((2, 480, 14, 14), 64), ((2, 528, 14, 14), 128), ((1, 32, 6, 10), 40),
-                                  ((5, 16, 4, 4), 7), ((1, 48, 9, 36), 100)])
-def test_maxpool_then_1x1_convolution_as_one_launch_is_bit_identical(hip, xs, k):
+                                  ((5, 16, 4, 4), 7), ((1, 48, 9, 36), 100),
+                                  # odd widths (round 4: single-pixel groups; GoogLeNet's 7x7 modules): tiles that span many rows and images
+                                  ((40, 832, 7, 7), 128), ((3, 32, 5, 9), 100), ((7, 16, 3, 3), 65), ((2, 48, 11, 13), 128)])
+def test_maxpool_then_1x1_convolution_as_one_launch_is_bit_identical(hip, monkeypatch, xs, k):
     """3x3 / stride 1 / pad 1 MaxPool -> 1x1 convolution handed over as one call (node['_fuse_pool_in']): the bits of the two
     launches (zero pad cells take part in the max, NaN wins), also with fused bias + ReLU and written in place into a wider
-    tensor; within the tolerance of the oracle's MaxPool -> Convolution."""
+    tensor; within the tolerance of the oracle's MaxPool -> Convolution.  Odd widths run the single-pixel-group form, which the
+    default leaves off (PVHIP_FUSE_POOLCONV=1: measured slower than the two launches on the 7x7 modules)."""
     from pyopenvino_amd import device as dev
+    if xs[3] % 2:
+        helpers.setenv(monkeypatch, 'PVHIP_FUSE_POOLCONV', '1')
     conv, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
     x = rnd(sum(xs), xs, 1.0, -0.4)
-    x[0, 1, 2, 3] = np.nan if k == 40 else x[0, 1, 2, 3]
+    if k == 40:
+        x[0, 1, 2, 3] = np.nan
     w, b = rnd(k, (k, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5), rnd(k + 1, (1, k, 1, 1), 0.2)
     pnode = make_node('MaxPool', [x], pool_data((3, 3), (1, 1), (1, 1), (1, 1), 'ceil'))
     pnode['output'][1]['dims'] = tuple(xs)
@@ -752,7 +758,7 @@ def test_maxpool_then_1x1_convolution_as_one_launch_is_bit_identical(hip, xs, k)
     assert_close(np.ascontiguousarray(got[:, 4:4 + k]), oracle, helpers.REL_TOL, 'MaxPool + 1x1 convolution vs oracle')
 
 
-def test_maxpool_then_convolution_declines_other_geometries(hip):
+def test_maxpool_then_convolution_declines_other_geometries(hip, monkeypatch):
     conv = hip_plugin('Convolution')
     def pair(xs, k=8, kk=1, pool=((3, 3), (1, 1), (1, 1), (1, 1))):
         x = np.zeros(xs, dtype=np.float32)
@@ -763,6 +769,10 @@ def test_maxpool_then_convolution_declines_other_geometries(hip):
     assert conv.pooled_fusable(*pair((2, 32, 12, 12)))
     assert conv.pooled_fusable(*pair((2, 32, 14, 14)))                   # rows of 14: 8-byte groups
     assert not conv.pooled_fusable(*pair((2, 32, 7, 7)))                 # odd width
+    assert not conv.pooled_fusable(*pair((2, 32, 7, 7), k=128))
+    helpers.setenv(monkeypatch, 'PVHIP_FUSE_POOLCONV', '1')             # ... unless asked for: 65 .. 128 output channels on single-pixel groups
+    assert conv.pooled_fusable(*pair((2, 32, 7, 7), k=128)) and not conv.pooled_fusable(*pair((2, 32, 7, 7)))
+    helpers.setenv(monkeypatch, 'PVHIP_FUSE_POOLCONV', None)
     assert not conv.pooled_fusable(*pair((2, 24, 12, 12)))               # 24 channels: not whole 16-row stages
     assert not conv.pooled_fusable(*pair((2, 32, 12, 12), k=200))
     assert not conv.pooled_fusable(*pair((2, 32, 12, 12), kk=3))
