@@ -1360,6 +1360,8 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         const int      ex_off   = __builtin_amdgcn_readfirstlane(pair * kSEx * kExBuf);
         const unsigned p_total  = L < n_tiles ? 8u * (unsigned)((n_tiles - L + G - 1) / G) : 0u;
         unsigned       p_store  = 0u;                    // passes of this pair's group stored so far
+        int            geo_it = -1, geo_ok = 0;          // the lane's output patch of the tile whose passes are being stored
+        unsigned       geo_off = 0u;
         const bool     even_w   = (OW & 1) == 0;
         (void)even_w;
 #define PVS_STORE_PASS()                                                                                         \
@@ -1384,14 +1386,20 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         exv_t ev[6];                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 6; ++i) ev[i] = *reinterpret_cast<const exv_t*>(exb + ((i * 4 + slot) * 32 + tl) * M); \
         w4s_signal(exfree_a + 4u * pb_);                 /* LDS executes a wave's instructions in order: the six reads above come before this increment */ \
-        const int t = tb_e * NT + tl;                                                                            \
-        if (t < a.T && kg < a.K) {                                                                               \
-            const int n_ = w4_div(t, a.tpi_mul, a.tpi_sh), rem_ = t - n_ * TPI;                                  \
+        if (it_ != geo_it) {              /* the lane's patch of this tile: once per tile, not once per pass (eight passes share it) */ \
+            geo_it = it_;                                                                                        \
+            const int t = tb_e * NT + tl;                                                                        \
+            const int tc = t < a.T ? t : 0;                                                                      \
+            const int n_ = w4_div(tc, a.tpi_mul, a.tpi_sh), rem_ = tc - n_ * TPI;                                \
             const int ty_ = w4_div(rem_, a.tx_mul, a.tx_sh), tx_ = rem_ - ty_ * a.TX;                            \
-            const int rows_ok = min(M, OH - M * ty_), cols_ok = min(M, OW - M * tx_);                            \
+            geo_off = (unsigned)(((n_ * a.y_ctotal + a.y_coff) * OH + M * ty_) * OW + M * tx_);                 \
+            geo_ok  = t < a.T ? (min(M, OH - M * ty_) | (min(M, OW - M * tx_) << 4)) : 0;                        \
+        }                                                                                                        \
+        if (geo_ok != 0 && kg < a.K) {                                                                           \
+            const int rows_ok = geo_ok & 15, cols_ok = geo_ok >> 4;                                              \
             (void)rows_ok; (void)cols_ok;                                                                        \
             const float bv = lh_e ? bs1 : bs0;                                                                   \
-            float* __restrict__ yp = a.y + ((((size_t)n_ * a.y_ctotal + a.y_coff + kg) * OH + M * ty_) * OW + M * tx_); \
+            float* __restrict__ yp = a.y + ((size_t)geo_off + (size_t)kg * (size_t)(OH * OW));                   \
             float yv[M][M];                                                                                      \
             _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {                                                \
                 w4_float2v em[6], col2[4];                                                                       \
