@@ -684,7 +684,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     dma_wait_all();
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // c-major: the LAST stage is taken out of the loop.  Its rows past C*kh*kw are zero rows of the panel: only the k-steps that hold
+    // a real row are multiplied (conv1 of GoogLeNet: 147 rows = 9 stages + 3 rows, 2 of the last stage's 8 k-steps -- 148 of 160
+    // MFMA steps), and nothing is copied for a stage behind it.
+    const int nk_loop = kRS ? nk : nk - 1;
+    for (int kt = 0; kt < nk_loop; ++kt) {
         const int buf = kt & 1;
         if (kF16) {
             typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -730,6 +734,18 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
         PV3_ADVANCE();
         dma_wait_all();
         __syncthreads();
+    }
+    if (!kRS) {
+        const int buf   = (nk - 1) & 1;
+        const int steps = min(KK, (a.C * nrs - (nk - 1) * kBK + 1) >> 1);     // k-steps of the last stage with a real reduction row
+        for (int kk = 0; kk < steps; ++kk) {
+            float afl[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) afl[i] = As[buf][2 * kk + lh][l31 + i * 32];
+            const float bfl = Bs[buf][2 * kk + lh][b_col];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(afl[i], bfl, acc[i], 0, 0, 0);
+        }
     }
 #undef PV3_ISSUE
 #undef PV3_LOAD_ENT
