@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   13
+#define PVHIP_ABI_VERSION   14
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -228,6 +228,10 @@ typedef struct pvhip_conv_dest {
     int    k;
     int    channel_offset;
     int    channels_total;
+    int    layout;          /* ABI v14.  0: fp32 NCHW, as above.  1 (pvhip_conv2d_multi_f16_dma only; channels_total = 0; act none or ReLU):
+                             * y is an fp16 tensor with the channels blocked by eight, [n][ceil16(k) / 8][oh * ow][8 halves]
+                             * (pvhip_c8_f16_elems floats), the input format of pvhip_conv2d_f16_c8: what the reference's float16
+                             * tensor of this node holds (common_def.py:13-17), channels past k up to a whole 16 are zeros.           */
 } pvhip_conv_dest;
 int    pvhip_conv2d_multi_supported(int c, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int n_dest);
 int    pvhip_conv2d_multi_f32(const float* x, const float* wpack, int n, int c, int h, int w, int kh, int kw,
@@ -282,6 +286,25 @@ int    pvhip_conv2d_f16_span(const float* x, const float* wf, float* y,
                              float act_lo, float act_hi);
 int    pvhip_matmul_f16(const float* a, const float* b, float* c, int m, int n, int k,
                         int trans_a, int trans_b);
+/* The fourth f16 kernel (ABI v14) and the first fp16 TENSORS in HBM: the 3x3_reduce / 5x5_reduce convolutions of an FP16 IR hand
+ * their output to the 3x3 / 5x5 convolution behind them as fp16 with the channels blocked by eight ("c8": [n][ceil16(c) / 8][h * w][8],
+ * the eight channels of a pixel = one 16-byte MFMA operand; written by pvhip_conv2d_multi_f16_dma through pvhip_conv_dest.layout = 1).
+ * pvhip_conv2d_f16_c8 reads it: stride-1 "same" windows (1x1; 3x3 / pad 1; 5x5 / pad 2) over rows of at most 64 - 2 pad pixels, any c
+ * (padded to whole 16-channel stages with zero weights), fp32 NCHW output with bias / activation / channel offset as pvhip_conv2d_f32.
+ * A producer wave copies whole input rows into LDS (the zero padding is the out-of-range rule of the copy), four consumer waves own a
+ * 32-channel tile each.  wf: fragments packed by _c8_pack (_c8_pack_elems FLOATS).  _from_f32 / _to_f32 convert between NCHW fp32 and
+ * c8 fp16 (round to nearest even): the boundary of the layout for any other reader, and the tests.                                    */
+size_t pvhip_c8_f16_elems(int n, int c, int h, int w);
+int    pvhip_c8_f16_from_f32(const float* x, void* xb, int n, int c, int h, int w);
+int    pvhip_c8_f16_to_f32(const void* xb, float* x, int n, int c, int h, int w);
+int    pvhip_conv2d_f16_c8_supported(int c, int h, int w, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
+size_t pvhip_conv2d_f16_c8_pack_elems(int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_f16_c8_pack(const float* w_oihw, float* wf, int k_out, int c, int kh, int kw);
+int    pvhip_conv2d_f16_c8(const void* xb, const float* wf, float* y,
+                           int n, int c, int h, int w, int k_out, int kh, int kw,
+                           const float* bias, int act,
+                           int out_channel_offset, int out_channels_total,
+                           float act_lo, float act_hi);
 
 /* GroupConvolution.py:53-79 kernel_GroupConvolution_numpy, depthwise case only (weights
  * [G,1,1,kh,kw], one input and one output channel per group), applied to every image.  bias / act /

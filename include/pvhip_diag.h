@@ -38,6 +38,8 @@ int pvhip_diag_pw_stamps(unsigned long long* out);
 int pvhip_diag_wino4_hw(unsigned* out);
 int pvhip_diag_wino4_stamps(unsigned long long* out);
 int pvhip_diag_wino4s_stamps(unsigned long long* out);
+/* conv_f16_c8_kernel: 16 cycle accounts summed over every 16th workgroup (pvhip_f16c8.hip g_c8_stamps), read and cleared */
+int pvhip_diag_c8_stamps(unsigned long long* out);
 int pvhip_diag_wino4s_simd(unsigned long long* out);
 int pvhip_diag_wino4s_trace(unsigned* out);                  /* workgroup 3 of the last launch: [wave][stage < 96][saw the image / finished] in cycles since its start */        /* the same workgroups: 16 waves x 4 SIMDs, how often wave w ran on SIMD s */      /* conv_wino4s_kernel (shared-V form): 16 waves x 8 cycle accounts, read and cleared */
 /* the same run's epilogue phases: [wave 0..7][write 0, barrier, read + store 0, barrier, write 1, barrier, read + store 1, barrier]  */

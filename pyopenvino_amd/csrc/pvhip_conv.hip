@@ -56,6 +56,7 @@ struct ConvArgs {
         float* y;
         int m_begin, k;     // first panel row of the range, real output channels in it
         int ctotal, coff;   // as y_ctotal / y_coff
+        int layout;         // 0: fp32 NCHW; 1 (f16 form only): fp16, channels blocked by eight ([n][ceil16(k) / 8][oh * ow][8]: pvhip_conv_dest)
     } seg[kMaxConvDests];
 };
 
@@ -774,6 +775,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
         const int rem = gp - n * OHW;
         float* __restrict__ yb = a.y;
         int yct = a.y_ctotal, ycoff = a.y_coff, klim = a.K;
+        int c8_blocks = 0, c8_first = 0;    // a range stored as blocked fp16: its channel blocks, and the first block of this workgroup's tile
         if (nseg_l > 0) {                   // the destination range this 32-channel tile belongs to (workgroup-uniform)
             int sg = 0;
             for (int q = 1; q < nseg_l; ++q) sg = (m0 + i * 32 >= ka->seg[q].m_begin) ? q : sg;
@@ -781,12 +783,34 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
             yct   = ka->seg[sg].ctotal;
             ycoff = ka->seg[sg].coff - ka->seg[sg].m_begin;
             klim  = ka->seg[sg].m_begin + ka->seg[sg].k;
+            if (kF16 && ka->seg[sg].layout == 1) {
+                c8_blocks = (ka->seg[sg].k + 15) / 16 * 2;
+                c8_first  = (m0 - ka->seg[sg].m_begin) / 8;      // ranges begin at whole 32-channel tiles
+            }
         }
         float* __restrict__ yp = yb + ((size_t)n * yct + ycoff + row0) * OHW + rem;
         float vv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) vv[r] = acc[i][r];
         bias_act_n<16>(vv, bv, a.bias != nullptr, a.relu, act_bounds(a.relu, a.act_lo, a.act_hi));
+        if (kF16 && c8_blocks > 0) {
+            // the reader is pvhip_conv2d_f16_c8: fp16 (round to nearest even: the value the reader would round this output to anyway),
+            // the eight channels of a pixel in one 16-byte piece.  Registers 4 g .. 4 g + 3 are channels 8 g + 4 lh .. + 3 of the tile:
+            // half a piece per lane, the two lane halves of a wave fill it.  Channels past the range's count up to a whole 16-channel
+            // stage are written too: zero rows of the panel, zero bias -- zeros, which is what the reader's zero weights expect.
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+            _Float16* const yh = reinterpret_cast<_Float16*>(yb);
+            const int blk0 = c8_first + i * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (blk0 + g >= c8_blocks) continue;
+                half4v h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (_Float16)vv[4 * g + j];
+                *reinterpret_cast<half4v*>(yh + (((size_t)n * c8_blocks + blk0 + g) * OHW + rem) * 8 + 4 * lh) = h;
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
@@ -1283,6 +1307,10 @@ static int conv2d_multi_impl(const float* x, const float* wpack, int n, int c, i
         a.seg[i].k       = d.k;
         a.seg[i].ctotal  = d.channels_total > 0 ? d.channels_total : d.k;
         a.seg[i].coff    = d.channels_total > 0 ? d.channel_offset : 0;
+        a.seg[i].layout  = d.layout;
+        if (d.layout != 0) {            // fp16, channels blocked by eight: the f16 form only, a tensor of its own, zeros survive the activation
+            PVHIP_CHECK_ARG(d.layout == 1 && f16 && d.channels_total == 0 && (act == 0 || act == 1));
+        }
         k_panel += round_up_int(d.k, 32);
         const unsigned long long oe = (unsigned long long)n * a.seg[i].ctotal * oh * ow;
         if (oe > out_max) out_max = oe;

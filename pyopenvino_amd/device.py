@@ -89,6 +89,13 @@ SIGNATURES = {
     'pvhip_conv2d_f16_span': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_f16_dma': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 13 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_matmul_f16': (_c.c_int, [_fp, _fp, _fp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'pvhip_c8_f16_elems': (_c.c_size_t, [_c.c_int] * 4),
+    'pvhip_c8_f16_from_f32': (_c.c_int, [_fp, _c.c_void_p] + [_c.c_int] * 4),
+    'pvhip_c8_f16_to_f32': (_c.c_int, [_c.c_void_p, _fp] + [_c.c_int] * 4),
+    'pvhip_conv2d_f16_c8_supported': (_c.c_int, [_c.c_int] * 11),
+    'pvhip_conv2d_f16_c8_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
+    'pvhip_conv2d_f16_c8_pack': (_c.c_int, [_fp, _fp] + [_c.c_int] * 4),
+    'pvhip_conv2d_f16_c8': (_c.c_int, [_c.c_void_p, _fp, _fp] + [_c.c_int] * 7 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),
     'pvhip_conv2d_pooled_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 5 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
@@ -107,7 +114,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -116,7 +123,7 @@ MAX_CONV_DESTS = 6
 
 class ConvDest(_c.Structure):
     """pvhip_conv_dest of include/pvhip.h."""
-    _fields_ = [('y', _c.c_void_p), ('k', _c.c_int), ('channel_offset', _c.c_int), ('channels_total', _c.c_int)]
+    _fields_ = [('y', _c.c_void_p), ('k', _c.c_int), ('channel_offset', _c.c_int), ('channels_total', _c.c_int), ('layout', _c.c_int)]
 
 
 class PvhipError(RuntimeError):
@@ -182,16 +189,18 @@ settings_serial = 0      # bumped by every reload: host-side plans that bake ker
 conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'      # Convolution plugin: pad the input of a c-major layer in a pass of its own
 conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'    # Convolution plugin, FP16 IRs: the f16 form of the LDS-DMA kernel where it applies
 conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)  # ... and the span kernel before it: 1 = 3x3 / 5x5 layers, 2 = 1x1 too (slower there), 0 = never
+conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '1') != '0'      # ... and fp16 tensors blocked by eight channels between a 1x1 convolution and the 3x3 / 5x5 behind it
 
 
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
-    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span
+    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8
     call('pvhip_settings_reload')
     conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'
     conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)
+    conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '1') != '0'
     settings_serial += 1
 
 
@@ -385,6 +394,53 @@ class ChannelSlice:
         return a if dtype is None else a.astype(dtype, copy=False)
 
 
+class BlockedHalf:
+    """An fp16 tensor in HBM with the channels blocked by eight -- [n][ceil16(c) / 8][h * w][8 halves], include/pvhip.h
+    pvhip_c8_f16_* -- as the 3x3_reduce / 5x5_reduce convolutions of an FP16 IR hand it to the 3x3 / 5x5 convolution behind them
+    (what the reference holds there is a float16 ndarray, common_def.py:13-17).  Has the ndarray surface of the LOGICAL tensor
+    (shape (n, c, h, w); dtype float32, the precision its port is declared with) so that the reference's per-plugin validation keeps
+    working; numpy() converts back on the device.  Only pvhip_conv2d_f16_c8 reads the blocked bytes."""
+    __slots__ = ('buf', 'shape', 'dtype')
+
+    def __init__(self, shape):
+        n, c, h, w = (int(d) for d in shape)
+        self.shape = (n, c, h, w)
+        self.dtype = np.dtype(np.float32)
+        self.buf = DeviceTensor.empty((max(1, int(call('pvhip_c8_f16_elems', n, c, h, w))),))
+
+    @classmethod
+    def from_dense(cls, t: 'DeviceTensor'):
+        out = cls(t.shape)
+        call('pvhip_c8_f16_from_f32', _c.c_void_p(t.ptr), _c.c_void_p(out.buf.ptr), *out.shape)
+        return out
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.ptr
+
+    @property
+    def ndim(self):
+        return 4
+
+    @property
+    def size(self):
+        n, c, h, w = self.shape
+        return n * c * h * w
+
+    def dense(self) -> 'DeviceTensor':
+        """The same values as an NCHW fp32 tensor (every one of them an fp16 value)."""
+        t = DeviceTensor.empty(self.shape)
+        call('pvhip_c8_f16_to_f32', _c.c_void_p(self.buf.ptr), _c.c_void_p(t.ptr), *self.shape)
+        return t
+
+    def numpy(self):
+        return self.dense().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+
 def as_device(data, dtype=np.float32) -> DeviceTensor:
     """Accept what a predecessor plugin handed over: a DeviceTensor (ours) or an ndarray (when our
     plugins are mixed with host plugins, e.g. under the reference's own engine)."""
@@ -392,6 +448,8 @@ def as_device(data, dtype=np.float32) -> DeviceTensor:
         return data
     if isinstance(data, ChannelSlice):
         return DeviceTensor.from_numpy(data.numpy())     # densify (debug paths only)
+    if isinstance(data, BlockedHalf):
+        return data.dense()                              # a reader that does not take the blocked layout (debug paths only)
     return DeviceTensor.from_numpy(np.asarray(data), dtype=dtype)
 
 

@@ -465,7 +465,7 @@ class Executable_Network:
                 del node[key]
             for port in node.get('output', {}).values():
                 port.pop('data', None)
-            for key in ('result', 'param', '_sibling_out', '_fuse_bias', '_out_into', '_siblings', '_fuse_pool', '_fuse_pool_in', '_fuse_lrn'):
+            for key in ('result', 'param', '_sibling_out', '_fuse_bias', '_out_into', '_out_c8', '_siblings', '_fuse_pool', '_fuse_pool_in', '_fuse_lrn'):
                 node.pop(key, None)
 
     def start_async(self, request_id: int, inputs: dict):
@@ -511,7 +511,7 @@ class Executable_Network:
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
         self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pool_conv = {}, set(), {}, {}, {}
-        self._pre_add = {}
+        self._pre_add, self._c8_out = {}, set()
         if 'list_schedule' in self.__dict__:
             self.task_list = list(self.list_schedule)
         if not self.fuse_epilogues:
@@ -658,6 +658,27 @@ class Executable_Network:
                 if len(members) >= 2 and conv_plugin.siblings_fusable([G.nodes[m] for m in members]):
                     self._siblings[members[0]] = members[1:]
                     self._fused_away.update(members[1:])
+        # FP16 IRs on the f16 matrix cores: a fused 1x1 convolution chain whose ONLY reader is a 3x3 / 5x5 convolution that
+        # pvhip_conv2d_f16_c8 covers (3x3_reduce -> 3x3, 5x5_reduce -> 5x5) hands its output over as fp16 with the channels blocked by
+        # eight (device.BlockedHalf): what the reference holds there is a float16 tensor too (common_def.py:13-17), and the blocked
+        # form is the reader's MFMA operand as it stands.  PVHIP_CONV_F16_C8=0: fp32 NCHW everywhere, as before.
+        self._c8_out = set()
+        if f16 and os.environ.get('PVHIP_CONV_F16_C8', '1') != '0' and os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0' \
+                and getattr(conv_plugin, 'SUPPORTS_C8', False):
+            for cid, f in self._fusion.items():
+                if G.nodes[cid]['type'] != 'Convolution' or f['into'] is not None or cid in self._pool_conv or cid in self._pre_add:
+                    continue
+                if f['act'] is not None and f['act'][0] != 'relu':
+                    continue
+                tail = f['relu'] if f['relu'] is not None else f['add']
+                readers = list(G.successors(tail))
+                if len(readers) != 1 or G.nodes[readers[0]]['type'] != 'Convolution' or G.edges[(tail, readers[0])]['connection'][3] != 0:
+                    continue
+                rid = readers[0]
+                if rid in self._pool_conv or rid in self._pre_add or rid in self._siblings or rid in self._fused_away:
+                    continue
+                if conv_plugin.c8_writer_ok(G.nodes[cid]) and conv_plugin.c8_reader_ok(G.nodes[rid]):
+                    self._c8_out.add(cid)
         self.order_for_locality()
 
     def order_for_locality(self):
@@ -983,13 +1004,18 @@ class Executable_Network:
                 node.pop('_fuse_bias', None)
                 node.pop('_fuse_act', None)
             sibs = self._siblings.get(task)
+            if task in self._c8_out:
+                node['_out_c8'] = True
+            else:
+                node.pop('_out_c8', None)
             if sibs:
                 node['_siblings'] = []
                 for sid in sibs:
                     sf = self._fusion[sid]
                     node['_siblings'].append({'node': G.nodes[sid], 'inputs': self.prepare_inputs_for_task(sid),
                                               'bias': G.nodes[sf['bias']]['output'][0]['data'],
-                                              'into': (self._concat_buffer(sf['into'][0]), sf['into'][1]) if sf['into'] is not None else None})
+                                              'into': (self._concat_buffer(sf['into'][0]), sf['into'][1]) if sf['into'] is not None else None,
+                                              'c8': sid in self._c8_out})
             else:
                 node.pop('_siblings', None)
             pooled = self._lrn_pool.get(task)        # the node folded into this one: a MaxPool behind an LRN, or an LRN behind a MaxPool

@@ -28,6 +28,9 @@ SUPPORTS_POOLED_INPUT = True
 # with C % 16 != 0 and padding: GoogLeNet's data/mean -> conv1) may be handed over with the convolution: node['_pre_add'] = the constant
 # (1, C, 1, 1), inputs[0] = the Add's own data input.  The padding pass adds it on the way (the same fp32 add: the same bits).
 SUPPORTS_PRE_ADD = True
+# FP16 IRs (node['_f16_mfma']): node['_out_c8'] (a sibling: its dict's 'c8') asks for the output as dev.BlockedHalf -- fp16, channels
+# blocked by eight -- for a reader that c8_reader_ok() accepts; compute() takes such an input through pvhip_conv2d_f16_c8.
+SUPPORTS_C8 = True
 
 
 # A pass made of such nodes can be recorded into a hipGraph (Executable_Network.infer does so by itself for device-resident inputs):
@@ -81,6 +84,72 @@ def packed_weights_f16_span(node: dict, w) -> 'dev.DeviceTensor':
     dev.call('pvhip_conv2d_f16_span_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wpack.ptr), k, c, kh, kw)
     node['_hip_wspan'] = (w._block, w.shape, wpack)
     return wpack
+
+
+def packed_weights_f16_c8(node: dict, w) -> 'dev.DeviceTensor':
+    """fp16 MFMA fragments of pvhip_conv2d_f16_c8 (input channels padded to whole 16-channel stages), cached on the node."""
+    cached = node.get('_hip_wpack_c8')
+    if cached is not None and cached[0] is w._block:
+        return cached[1]
+    k, c, kh, kw = w.shape
+    wpack = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_f16_c8_pack_elems', k, c, kh, kw)),))
+    dev.call('pvhip_conv2d_f16_c8_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wpack.ptr), k, c, kh, kw)
+    node['_hip_wpack_c8'] = (w._block, wpack)
+    return wpack
+
+
+def c8_reader_ok(node: dict) -> bool:
+    """True when pvhip_conv2d_f16_c8 covers this Convolution node (IR attributes and port dims; no device needed): it may then be handed
+    its input as fp16 blocked by eight channels (dev.BlockedHalf) by the 1x1 convolution in front of it."""
+    try:
+        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+        strides, pb, pe = (common_def.string_to_tuple(attrs[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+        if len(xd) != 4 or len(wd) != 4 or wd[1] != xd[1] or tuple(pb) != tuple(pe):
+            return False
+        oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
+        return bool(dev.call('pvhip_conv2d_f16_c8_supported', int(xd[1]), int(xd[2]), int(xd[3]), int(wd[2]), int(wd[3]), strides[0], strides[1],
+                             pb[0], pb[1], oh, ow))
+    except (KeyError, ValueError, AssertionError, IndexError):
+        return False
+
+
+def c8_writer_ok(node: dict) -> bool:
+    """True when the f16 multi-destination launch (launch_siblings with one or more members) runs this Convolution node, i.e. when it
+    can store its output as dev.BlockedHalf: 1x1, stride 1, unpadded, C % 16 == 0."""
+    try:
+        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+        st, pb, pe = (common_def.string_to_tuple(attrs[key]) for key in ('strides', 'pads_begin', 'pads_end'))
+        if len(xd) != 4 or len(wd) != 4 or tuple(pe) != (0, 0) or wd[1] != xd[1] or attrs['auto_pad'] not in ('explicit', 'valid'):
+            return False
+        return bool(dev.call('pvhip_conv2d_multi_supported', int(xd[1]), int(wd[2]), int(wd[3]), st[0], st[1], pb[0], pb[1], 1))
+    except (KeyError, ValueError, AssertionError, IndexError):
+        return False
+
+
+def launch_c8(node, xb, w, bias=None, act=None, into=None):
+    """FP16 IRs: the convolution of a dev.BlockedHalf input (pvhip_conv2d_f16_c8); output fp32 NCHW as launch()."""
+    n, c, h, wd = xb.shape
+    kn, kc, kh, kw = w.shape
+    if kc != c:
+        raise ValueError('shapes {} and {} not aligned: {} (dim 1) != {} (dim 1)'.format(xb.shape, w.shape, c, kc))
+    wpack = packed_weights_f16_c8(node, w)
+    act_code, act_lo, act_hi = 0, 0.0, 0.0
+    if act is not None:
+        act_code = 1 if act[0] == 'relu' else 2
+        if act_code == 2:
+            act_lo, act_hi = float(act[1]), float(act[2])
+    if into is None:
+        target, coff, ctotal = dev.DeviceTensor.empty((n, kn, h, wd)), 0, 0
+        y = target
+    else:
+        target, coff = into
+        ctotal = target.shape[1]
+        assert target.shape[0] == n and tuple(target.shape[2:]) == (h, wd) and coff + kn <= ctotal
+        y = dev.ChannelSlice(target, coff, kn)
+    node['_hip_f16'] = 'c8'
+    dev.call('pvhip_conv2d_f16_c8', ctypes.c_void_p(xb.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), n, c, h, wd, kn, kh, kw,
+             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
+    return y
 
 
 def prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16=False) -> bool:
@@ -309,8 +378,16 @@ def launch_siblings(node, x, members, strides, pads_begin, act, f16=False):
             act_lo, act_hi = float(act[1]), float(act[2])
     dests = (dev.ConvDest * len(members))()
     outs, keep = [], []
-    for i, (w, _, into) in enumerate(members):
+    for i, member in enumerate(members):
+        w, into = member[0], member[2]
         kn = w.shape[0]
+        if len(member) > 3 and member[3]:         # FP16 IRs: this member's only reader is pvhip_conv2d_f16_c8 -- fp16, channels blocked by eight
+            assert f16 and into is None and act_code in (0, 1)
+            target = dev.BlockedHalf((n, kn, h, wd))
+            outs.append(target)
+            keep.append(target)
+            dests[i].y, dests[i].k, dests[i].channel_offset, dests[i].channels_total, dests[i].layout = target.ptr, kn, 0, 0, 1
+            continue
         if into is None:
             target, coff, ctotal = dev.DeviceTensor.empty((n, kn, h, wd)), 0, 0
             outs.append(target)
@@ -320,7 +397,7 @@ def launch_siblings(node, x, members, strides, pads_begin, act, f16=False):
             assert target.shape[0] == n and tuple(target.shape[2:]) == (h, wd) and coff + kn <= ctotal
             outs.append(dev.ChannelSlice(target, coff, kn))
         keep.append(target)
-        dests[i].y, dests[i].k, dests[i].channel_offset, dests[i].channels_total = target.ptr, kn, int(coff), int(ctotal)
+        dests[i].y, dests[i].k, dests[i].channel_offset, dests[i].channels_total, dests[i].layout = target.ptr, kn, int(coff), int(ctotal), 0
     if f16:
         node['_hip_f16'] = 'lds-dma, siblings'
         for m in node.get('_siblings', []):
@@ -341,19 +418,21 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
     pads_end = common_def.string_to_tuple(attrs['pads_end'])
     auto_pad = attrs['auto_pad']
-    x = dev.as_device(inputs[0])
+    x = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and node.get('_f16_mfma') and c8_reader_ok(node) else dev.as_device(inputs[0])
     w = dev.as_device(inputs[1])
     bias = node.get('_fuse_bias')
     if bias is not None:
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
     siblings = node.get('_siblings')
-    if node.get('_f16_mfma') and siblings and dev.conv_f16_dma:
-        members = [(w, bias, node.get('_out_into'))]
-        for sib in siblings:
+    if node.get('_f16_mfma') and isinstance(inputs[0], dev.BlockedHalf) and c8_reader_ok(node):
+        y = launch_c8(node, inputs[0], w, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'))
+    elif node.get('_f16_mfma') and (siblings or node.get('_out_c8')) and dev.conv_f16_dma:
+        members = [(w, bias, node.get('_out_into'), bool(node.get('_out_c8')))]
+        for sib in siblings or ():
             common_def.validate_inputs(sib['node'], sib['inputs'])
             sb = sib.get('bias')
-            members.append((dev.as_device(sib['inputs'][1]), dev.as_device(sb) if sb is not None else None, sib.get('into')))
+            members.append((dev.as_device(sib['inputs'][1]), dev.as_device(sb) if sb is not None else None, sib.get('into'), bool(sib.get('c8'))))
         outs = launch_siblings(node, x, members, strides, pads_begin, node.get('_fuse_act'), f16=True)
         y, node['_sibling_out'] = outs[0], outs[1:]
     elif node.get('_f16_mfma') and node.get('_fuse_pool_in') is not None:

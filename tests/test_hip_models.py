@@ -608,6 +608,16 @@ def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp
     images = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
     prob16, logits16, net16 = _googlenet_fp16_logits(HIP, False, images, tmp_path)
     assert net16.f16_mfma and all('_hip_f16' in net16.G.nodes[n] for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution')
+    # the 3x3_reduce / 5x5_reduce tensors are fp16 in HBM (blocked by eight channels) and every 3x3 / 5x5 convolution reads them so
+    spatial = [n for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution' and net16.G.nodes[n]['input'][1]['dims'][2] in (3, 5)]
+    assert len(spatial) == 19 and all(net16.G.nodes[n]['_hip_f16'] == 'c8' for n in spatial)
+    os.environ['PVHIP_CONV_F16_C8'] = '0'
+    try:
+        _, logits_dense, net_dense = _googlenet_fp16_logits(HIP, False, images, tmp_path)
+    finally:
+        del os.environ['PVHIP_CONV_F16_C8']
+    assert not any(net_dense.G.nodes[n]['_hip_f16'] == 'c8' for n in spatial)
+    assert_close(logits16, logits_dense, 1e-3, 'fp16 tensors between the convolutions vs fp32 tensors rounded at the reader', elementwise=False)      # the same values, other summation orders, and fp16 roundings that flip behind them
     prob32, logits32, net32 = _googlenet_fp16_logits(HIP, True, images, tmp_path)
     assert not net32.f16_mfma
     err_ref, err_32 = helpers.rel_err(logits16, z['logits']), helpers.rel_err(logits16, logits32)

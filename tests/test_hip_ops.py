@@ -1187,6 +1187,90 @@ def test_f16_sibling_launch_and_pooled_launch_match_their_single_launches(hip, x
         assert_close(got1, want, 1e-5, 'f16 MaxPool + 1x1 {} k{}'.format(xs, k))
 
 
+def test_conv_f16_c8_blocked_fp16_tensors_between_two_convolutions(hip):
+    """FP16 IRs, ABI v14: the first fp16 TENSORS in HBM.  (1) dev.BlockedHalf (fp16, channels blocked by eight, pvhip_c8_f16_*): the
+    round trip gives exactly the fp16 rounding of the fp32 tensor, channel counts that are not multiples of 8 or 16 included.
+    (2) pvhip_conv2d_f16_c8 reads such a tensor: against the oracle on the SAME operands rounded to fp16 (1e-5: only the fp32 summation
+    order differs) and against the span kernel on the dense tensor; GoogLeNet's 3x3 / 5x5 layers (56, 28, 14, 7 wide), a 1x1, rows
+    that do not fill a 32-pixel block, images taller than one tile, channel counts that need zero-padded stages (24, 40), output
+    channels below / between / above whole tiles and above one 128-channel group; bias + ReLU fused into a wider tensor.
+    (3) the writer: a member of the f16 sibling launch with layout = 1 stores the fp16 rounding of what it stores as fp32 NCHW."""
+    from pyopenvino_amd import device as dev
+    for xs in [(2, 24, 5, 7), (1, 16, 3, 3), (3, 13, 4, 6), (2, 40, 14, 14)]:
+        x = rnd(sum(xs), xs)
+        blocked = dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))
+        assert blocked.shape == xs and blocked.dtype == np.float32
+        assert_bit_exact(np.asarray(blocked), f16r(x), 'c8 round trip {}'.format(xs))
+    cases = [((1, 64, 56, 56), 192, 3), ((2, 96, 28, 28), 128, 3), ((2, 16, 28, 28), 32, 5), ((1, 160, 14, 14), 320, 3), ((2, 192, 7, 7), 384, 3),
+             ((2, 48, 7, 7), 128, 5), ((2, 24, 14, 14), 64, 5), ((1, 32, 14, 14), 208, 3), ((3, 16, 13, 13), 7, 5), ((1, 40, 9, 5), 33, 3),
+             ((1, 32, 20, 60), 24, 3), ((2, 16, 3, 3), 300, 3), ((2, 64, 14, 14), 96, 1), ((1, 16, 40, 56), 40, 5), ((5, 32, 1, 9), 16, 3)]
+    for xs, k, kk in cases:
+        pad = (kk - 1) // 2
+        x, w = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5)
+        assert dev.call('pvhip_conv2d_f16_c8_supported', xs[1], xs[2], xs[3], kk, kk, 1, 1, pad, pad, xs[2], xs[3]), (xs, kk)
+        node = make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad)))
+        node['_f16_mfma'] = True
+        blocked = dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))
+        got = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: blocked, 1: w})))
+        assert node['_hip_f16'] == 'c8'
+        want = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad))),
+                                                              {0: f16r(x), 1: f16r(w)}, kernel_type='special'))
+        assert_close(got, want, 1e-5, 'f16 c8 kernel {} k{} {}x{}'.format(xs, k, kk, kk))
+        dense = dict(make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad))))
+        dense['_f16_mfma'] = True
+        assert_close(got, np.asarray(first_out(hip_plugin('Convolution').compute(dense, {0: x, 1: w}))), 1e-5, 'c8 vs the dense f16 kernels {}'.format(xs))
+    for c, h, w_, kk, st, pad, oh, ow in [(16, 8, 8, 3, 2, 1, 4, 4), (16, 8, 8, 3, 1, 0, 6, 6), (16, 8, 8, 7, 1, 3, 8, 8), (16, 8, 63, 3, 1, 1, 8, 63),
+                                          (16, 8, 61, 5, 1, 2, 8, 61)]:
+        assert not dev.call('pvhip_conv2d_f16_c8_supported', c, h, w_, kk, kk, st, st, pad, pad, oh, ow), (c, h, w_, kk, st, pad)
+    # a reader the kernel does not cover gets the dense tensor (the values are the same fp16 values)
+    x, w = rnd(5, (1, 16, 8, 8)), rnd(6, (8, 16, 3, 3), 0.1)
+    node = make_node('Convolution', [x, w], conv_data((2, 2), (1, 1), (1, 1)))
+    node['_f16_mfma'] = True
+    blocked = dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))
+    got = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: blocked, 1: w})))
+    assert node['_hip_f16'] != 'c8'
+    want = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x, w], conv_data((2, 2), (1, 1), (1, 1))), {0: f16r(x), 1: f16r(w)},
+                                                          kernel_type='special'))
+    assert_close(got, want, 1e-5, 'dense fallback')
+    # fused epilogue, written in place into a wider tensor
+    x, w, b = np.abs(rnd(1, (2, 32, 10, 6))), rnd(2, (40, 32, 3, 3), 0.1), rnd(3, (1, 40, 1, 1), 0.3)
+    node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
+    node['_f16_mfma'] = True
+    blocked = dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))
+    wide = dev.DeviceTensor.from_numpy(np.full((2, 50, 10, 6), -1.0, dtype=np.float32))
+    fused = dict(node)
+    fused['_fuse_bias'], fused['_fuse_act'], fused['_out_into'] = dev.DeviceTensor.from_numpy(b), ('relu',), (wide, 7)
+    hip_plugin('Convolution').compute(fused, {0: blocked, 1: w})
+    assert fused['_hip_f16'] == 'c8'
+    got = np.asarray(wide)
+    unfused = np.asarray(first_out(hip_plugin('Convolution').compute(dict(node), {0: blocked, 1: w})))
+    assert_bit_exact(got[:, 7:47], np.maximum(unfused + b, 0).astype(np.float32), 'f16 c8 kernel: fused epilogue')
+    assert np.all(got[:, :7] == -1.0) and np.all(got[:, 47:] == -1.0)
+    # the writer: the sibling launch with one and with several members, blocked and dense destinations side by side
+    for xs, ks, c8 in [((3, 192, 28, 28), (64, 96, 16), (False, True, True)), ((2, 512, 14, 14), (160, 112, 24), (False, True, True)),
+                       ((5, 832, 7, 7), (48,), (True,)), ((2, 64, 56, 56), (64,), (True,)), ((1, 32, 6, 10), (40, 8), (True, True))]:
+        x = rnd(11, xs)
+        data = conv_data((1, 1), (0, 0), (0, 0))
+        ws = [rnd(20 + i, (k, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5) for i, k in enumerate(ks)]
+        bs = [rnd(40 + i, (1, k, 1, 1), 0.1) for i, k in enumerate(ks)]
+        nodes = [make_node('Convolution', [x, w], data) for w in ws]
+        outs = {}
+        for blocked_run in (False, True):
+            lead = dict(nodes[0])
+            lead['_f16_mfma'], lead['_fuse_bias'], lead['_fuse_act'] = True, dev.DeviceTensor.from_numpy(bs[0]), ('relu',)
+            lead['_out_c8'] = blocked_run and c8[0]
+            lead['_siblings'] = [{'node': n_, 'inputs': {0: x, 1: w}, 'bias': dev.DeviceTensor.from_numpy(b), 'into': None, 'c8': blocked_run and f}
+                                 for n_, w, b, f in zip(nodes[1:], ws[1:], bs[1:], c8[1:])]
+            y = next(iter(hip_plugin('Convolution').compute(lead, {0: x, 1: ws[0]}).values()))
+            res = [y] + list(lead.get('_sibling_out', []))
+            for t, f in zip(res, c8):
+                assert isinstance(t, dev.BlockedHalf) == bool(blocked_run and f)
+            outs[blocked_run] = [np.asarray(t) for t in res]
+        for dense_out, blocked_out, k, f in zip(outs[False], outs[True], ks, c8):
+            assert dense_out.shape == blocked_out.shape == (xs[0], k, xs[2], xs[3])
+            assert_bit_exact(blocked_out, f16r(dense_out) if f else dense_out, 'sibling member with {} channels, c8 {}'.format(k, f))
+
+
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
     """The reference's own FP16 node fixture (resources/node_args_6.pickle, replayed as test_node_sample.py:1-16 does; cropped)
     in float16 as the reference computes it: the f16-MFMA result is within fp16 tolerance of the reference's float16 output
