@@ -467,22 +467,25 @@ int pvhip_conv2d_f16_c8(const void* xb, const float* wf, float* y, int n, int c,
     const long tiles = (long)n * t.tiles * a.n_mtiles;
     if (tiles > 0x3fffffffL) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_c8: too many tiles");
     a.n_tiles = (int)tiles;
-    // ONE TILE PER WORKGROUP by default, and as many of its stages in flight as LDS holds.  The persistent grid (a workgroup walking
-    // tiles, the producer ahead across tile boundaries) measured 25 % slower: a consumer's stores count in vmcnt like its loads and
-    // retire in order, so the next tile's first weight fragments waited for the previous tile's 64 stores; fresh waves have none.
-    const int    knob  = settings().f16_c8_wgs;                                // PVHIP_CONV_F16_C8_WGS=n > 0: persistent, n workgroups per CU (tuning runs)
+    // Two grids.  ONE TILE PER WORKGROUP, as many of its stages in flight as LDS holds: the short tiles (5x5: C / 16 = 1-3 stages; conv2)
+    // and the 7-wide layers.  PERSISTENT, two workgroups per CU walking tiles with the producer ahead across tile boundaries: 3x3 layers of
+    // six or more stages (scripts/time_f16_c8.py: 3b 0.149 -> 0.131 ms, 4e 0.104 -> 0.087; conv2 and every 5x5 layer 1-40 % slower: a
+    // consumer's stores count in vmcnt like its loads and retire in order, so a tile's first weight fragments wait for the stores of the
+    // tile before -- a price that long tiles earn back, short ones do not).  PVHIP_CONV_F16_C8_WGS=n > 0: persistent with n per CU; -1: never.
+    const int    knob  = settings().f16_c8_wgs;
     const int    ncs   = cb / 2;
+    const int    wgs   = knob > 0 ? knob : ((knob == 0 && kh == 3 && ncs >= 6 && w >= 14) ? 2 : 0);      // 0: one tile per workgroup
     const size_t stage = (size_t)2 * t.rows * 1024;
     const size_t budget = stage > 13 * 1024 ? 72 * 1024 : 52 * 1024;           // two / three workgroups per CU
     int nbuf = (int)(budget / stage);
     if (nbuf > kC8MaxBuf) nbuf = kC8MaxBuf;
-    if (knob <= 0 && nbuf > ncs) nbuf = ncs;
+    if (wgs == 0 && nbuf > ncs) nbuf = ncs;
     if (nbuf < 2) nbuf = 2;
     if ((nbuf - 1) * 2 * t.rows > 62) nbuf = 62 / (2 * t.rows) + 1;           // the producer counts its copies in vmcnt (6 bits)
     a.nbuf = nbuf;
     a.store_vec = ((h * w) % 4 == 0 && (t.R * w) % 4 == 0) ? 4 : (((h * w) % 2 == 0 && (t.R * w) % 2 == 0) ? 2 : 1);
     const size_t lds = stage * nbuf;
-    const long resident = knob > 0 ? (long)kNumCU * knob : tiles;
+    const long resident = wgs > 0 ? (long)kNumCU * wgs : tiles;
     const int  grid = (int)(tiles < resident ? tiles : resident);
     if (kh == 1)      launch_c8<1>(a, grid, t.nb, lds);
     else if (kh == 3) launch_c8<3>(a, grid, t.nb, lds);

@@ -13,7 +13,7 @@ LAYERS = [('conv2/3x3', (256, 64, 56, 56), 192, 3), ('3a/3x3', (256, 96, 28, 28)
           ('4a/3x3', (256, 96, 14, 14), 208, 3), ('4c/3x3', (256, 128, 14, 14), 256, 3), ('4e/3x3', (256, 160, 14, 14), 320, 3),
           ('5b/3x3', (256, 192, 7, 7), 384, 3), ('3a/5x5', (256, 16, 28, 28), 32, 5), ('3b/5x5', (256, 32, 28, 28), 96, 5),
           ('4b/5x5', (256, 24, 14, 14), 64, 5), ('4e/5x5', (256, 32, 14, 14), 128, 5), ('5b/5x5', (256, 48, 7, 7), 128, 5)]
-VARIANTS = [('span (fp32 in)', None), ('c8', '0'), ('c8 3 wg/cu', '3'), ('c8 2 wg/cu', '2')]
+VARIANTS = [('span (fp32 in)', None), ('c8', '0'), ('c8 one tile/wg', '-1'), ('c8 2 wg/cu', '2')]
 dev.init(0)
 only = sys.argv[1] if len(sys.argv) > 1 else ''
 tot = {v[0]: 0.0 for v in VARIANTS}
