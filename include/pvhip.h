@@ -224,7 +224,7 @@ int    pvhip_conv2d_pooled_f16(const float* x, const float* wpack, float* y, int
  * pvhip_conv2d_f32 call.                                                                                            */
 #define PVHIP_MAX_CONV_DESTS 6
 typedef struct pvhip_conv_dest {
-    float* y;
+    float* y;           /* (layout 1: an fp16 tensor behind a float pointer) */
     int    k;
     int    channel_offset;
     int    channels_total;
@@ -300,6 +300,20 @@ int    pvhip_c8_f16_to_f32(const void* xb, float* x, int n, int c, int h, int w)
 int    pvhip_conv2d_f16_c8_supported(int c, int h, int w, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
 size_t pvhip_conv2d_f16_c8_pack_elems(int k_out, int c, int kh, int kw);
 int    pvhip_conv2d_f16_c8_pack(const float* w_oihw, float* wf, int k_out, int c, int kh, int kw);
+/* The module form (ABI v14): one or several 1x1 convolutions of the same c8 input as one launch (n_dest members; wf: _c8_pack of the
+ * members' weights laid one after the other, each padded with zero rows to a multiple of 32 output channels, bias likewise), a 1x1
+ * convolution behind a 3x3 / stride 1 / pad 1 MaxPool (pool = 1: MaxPool.py:41-72 then Convolution.py:57-87, the pooled tensor never
+ * exists), or one 3x3 / 5x5 convolution.  dests[i].layout: 0 = fp32 NCHW (y, channel_offset, channels_total as pvhip_conv2d_multi_f32),
+ * 1 = fp16 c8: a tensor of its own (channels_total = 0: [n][ceil16(k) / 8][h * w][8], zeros past k) or channels [channel_offset,
+ * channel_offset + k) of a c8 tensor of channels_total channels (the module's Concat buffer: k and the offset multiples of 8, the
+ * total a multiple of 16).  pvhip_maxpool3x3_c8: MaxPool.py:41-72 for a 3x3 window on a c8 tensor (any stride, zero padding, the
+ * window clipped at the padded edge; a NaN wins), c8 output.                                                                     */
+int    pvhip_conv2d_f16_c8_multi_supported(int c, int h, int w, int kh, int kw, int pool, int n_dest);
+int    pvhip_conv2d_f16_c8_multi(const void* xb, const float* wf, int n, int c, int h, int w, int kh, int kw, int pool,
+                                 const float* bias, int act, float act_lo, float act_hi,
+                                 int n_dest, const pvhip_conv_dest* dests);
+int    pvhip_maxpool3x3_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
+                           int pad_top, int pad_left, int pad_bottom, int pad_right);
 int    pvhip_conv2d_f16_c8(const void* xb, const float* wf, float* y,
                            int n, int c, int h, int w, int k_out, int kh, int kw,
                            const float* bias, int act,

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kC8Threads, (KS == 5 && NB == 4) ? 3 : 4) void conv
         // stages everything is in flight at once: the copies are HBM / Infinity-Cache latency, a stage is ~1200 cycles of MFMAs
         const int nbuf = a.nbuf;
         const unsigned long long p0 = PVC8_NOW();
+        (void)p0;
         while (s_i < S && s_i < nbuf) issue_next();
         unsigned long long p1 = PVC8_NOW(), tw = 0ull, tb = 0ull;
         PVC8_STAMP(8, p1 - p0);
@@ -185,8 +186,6 @@ __global__ __launch_bounds__(kC8Threads, (KS == 5 && NB == 4) ? 3 : 4) void conv
         pixoff[nb] = (unsigned)(((lh * rows + pr) * 64 + px) * 16);      // tap (0, 0) of the pixel: LDS row pr, column px (= image column px - pad)
     }
     const ActBounds ab = act_bounds(a.act, a.lo, a.hi);
-    typedef const __attribute__((address_space(4))) float* const_float_p;
-    const const_float_p bias_c = (const_float_p)(unsigned long)a.bias;
     const unsigned wlane = (unsigned)lane * 16u + (unsigned)wid * 1024u;
 #define PVC8_LOAD_A(dst_, vo_, mt_, cs_, tap_)                                                                   \
     dst_ = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wr, vo_, (unsigned)(((((mt_) * ncs + (cs_)) * TAPS + (tap_)) * a.tm) * 1024), 0))

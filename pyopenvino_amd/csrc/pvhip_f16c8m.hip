@@ -1,0 +1,468 @@
+// FP16 IRs, second step of the fp16 tensors (the reference holds EVERY tensor of an FP16 IR in float16, common_def.py:13-17):
+// convolutions that read fp16 blocked by eight channels ("c8", pvhip_f16c8.hip) and WRITE it -- the inception modules of GoogLeNet from
+// the module input to the channel Concat without an fp32 tensor in between:
+//   * several 1x1 convolutions of the same input as one launch (the 1x1 / 3x3_reduce / 5x5_reduce arms), each output-channel tile storing
+//     into the tensor of its member: an fp16 c8 tensor of its own, a channel range of the module's c8 Concat buffer, or (fallback) fp32 NCHW;
+//   * the 3x3 / 5x5 convolutions behind the reduce arms, writing their range of the Concat buffer;
+//   * MaxPool 3x3 / stride 1 / pad 1 + pool_proj: the pooled operand is the maximum of the nine shifted LDS reads (v_pk_maximum3_f16: a NaN
+//     wins, as for np.max; the zeros the copy wrote for cells outside the image are the zero padding MaxPool.py:53 pads with).
+// Same roles as conv_f16_c8_kernel (a producer wave copies whole rows by LDS-DMA, four consumer waves own a 32-channel tile each), with
+//   * LDS rows of 8 / 16 / 32 / 64 pixels (the smallest power of two that holds W + 2 pad): one copy instruction moves 8 / 4 / 2 / 1 rows,
+//     a 14-wide stage is 2-3 instructions per channel block instead of 9;
+//   * 1x1 windows: a stage is FOUR 16-channel steps (eight channel blocks), so that a barrier is worth 16 MFMAs;
+//   * the MFMA with the WEIGHT fragment first: an accumulator is [channel][pixel], a lane holds four consecutive channels of its pixel
+//     per register group -- 8 bytes of a c8 piece, which the other lane half completes to 16.
+#include "pvhip_common.h"
+
+using namespace pvhip;
+
+namespace {
+
+typedef float    floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+constexpr int kMMaxThreads = 512;   // four consumer waves + one to four producer waves (C8mArgs.nprod)
+constexpr int kMMaxBuf  = 6;
+constexpr int kMSteps   = 4;        // 16-channel steps per stage of a 1x1 window
+constexpr unsigned kOob = 0x80000000u;
+
+struct C8mSeg {
+    void* y;
+    int   m_begin, k;        // first panel row of the member, its real output channels
+    int   layout;            // 0: fp32 NCHW; 1: fp16 c8
+    int   ctotal, coff;      // channels of the tensor y points into and this member's first channel in it (c8: multiples of 8)
+    int   nblk;              // c8: channel blocks this member writes (a tensor of its own: ceil16(k) / 8, zeros included; a range: k / 8)
+};
+
+struct C8mArgs {
+    const _Float16* xb;      // [N][CB][H*W][8]
+    const _Float16* wf;      // [n_mtiles][CB / 2][taps][tm][64 lanes][8 halves]
+    const float*    bias;    // [Kp] or null
+    int N, CB, H, W, Kp;
+    int tm, n_mtiles, tiles_per_image, n_tiles;
+    int R, rows, rows_pad, stride_sh;      // output rows per tile; LDS rows a stage needs / holds (a multiple of 64 >> stride_sh) per channel block; log2 of the LDS row length in pixels
+    int n_ins, nbuf, stages;               // copy instructions per stage; stage buffers; stages per tile
+    int nprod;                             // producer waves: the copy instructions of a stage are dealt out to them (a wave issues one per ~200 cycles)
+    unsigned x_bytes, wf_bytes;
+    int   act;
+    float lo, hi;
+    int   nseg;
+    C8mSeg seg[PVHIP_MAX_CONV_DESTS];
+};
+
+__device__ __forceinline__ void c8m_wait_vmcnt(int n) {     // until at most n of this wave's copies are in flight (n: wave-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+    switch (n < 62 ? n : 62) {
+#define PVM_CASE(k_) case k_: asm volatile("s_waitcnt vmcnt(" #k_ ")" ::: "memory"); break;
+        PVM_CASE(1) PVM_CASE(2) PVM_CASE(3) PVM_CASE(4) PVM_CASE(5) PVM_CASE(6) PVM_CASE(7) PVM_CASE(8) PVM_CASE(9) PVM_CASE(10) PVM_CASE(11) PVM_CASE(12) PVM_CASE(13) PVM_CASE(14) PVM_CASE(15) PVM_CASE(16) PVM_CASE(17) PVM_CASE(18) PVM_CASE(19) PVM_CASE(20) PVM_CASE(21) PVM_CASE(22) PVM_CASE(23) PVM_CASE(24) PVM_CASE(25) PVM_CASE(26) PVM_CASE(27) PVM_CASE(28) PVM_CASE(29) PVM_CASE(30) PVM_CASE(31) PVM_CASE(32) PVM_CASE(33) PVM_CASE(34) PVM_CASE(35) PVM_CASE(36) PVM_CASE(37) PVM_CASE(38) PVM_CASE(39) PVM_CASE(40) PVM_CASE(41) PVM_CASE(42) PVM_CASE(43) PVM_CASE(44) PVM_CASE(45) PVM_CASE(46) PVM_CASE(47) PVM_CASE(48) PVM_CASE(49) PVM_CASE(50) PVM_CASE(51) PVM_CASE(52) PVM_CASE(53) PVM_CASE(54) PVM_CASE(55) PVM_CASE(56) PVM_CASE(57) PVM_CASE(58) PVM_CASE(59) PVM_CASE(60) PVM_CASE(61) PVM_CASE(62)
+#undef PVM_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#endif
+}
+
+// element-wise maximum of three fp16 x 8 vectors, a NaN in any of them wins (np.max, MaxPool.py:70)
+__device__ __forceinline__ half8 pk_max3_nan(half8 a, half8 b, half8 c) {
+    uint4v x = __builtin_bit_cast(uint4v, a), y = __builtin_bit_cast(uint4v, b), z = __builtin_bit_cast(uint4v, c), d;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned r;
+        asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(x[i]), "v"(y[i]), "v"(z[i]));
+        d[i] = r;
+    }
+#else
+    d = x; (void)y; (void)z;
+#endif
+    return __builtin_bit_cast(half8, d);
+}
+
+// KS: window (1, 3, 5); NB: 32-pixel blocks of a tile (2 / 4); POOL (KS == 1): MaxPool 3x3 / stride 1 / pad 1 in front of the 1x1 window
+template <int KS, int NB, bool POOL>
+__global__ __launch_bounds__(kMMaxThreads, (KS == 5 && NB == 4) ? 3 : 4) void conv_f16_c8m_kernel(C8mArgs a) {
+    static_assert(!POOL || KS == 1, "the pooled form is a 1x1 convolution");
+    constexpr int PADG  = POOL ? 1 : (KS - 1) / 2;                       // halo of the copied rows
+    constexpr int TAPSW = KS * KS;                                       // taps of the window (the fragments' tap axis)
+    constexpr int TAPS  = KS == 1 ? kMSteps : TAPSW;                     // MFMA steps per stage and 32-pixel block
+    constexpr int BLK   = KS == 1 ? 2 * kMSteps : 2;                     // channel blocks per stage
+    constexpr int RING  = KS == 1 ? kMSteps : KS;
+    extern __shared__ __attribute__((aligned(1024))) char c8m_lds[];     // [nbuf][BLK][rows_pad][stride][16 bytes]
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW     = a.H * a.W;
+    const int ncs16  = a.CB >> 1;
+    const int stride = 1 << a.stride_sh;
+    const unsigned blk_bytes = (unsigned)(a.rows_pad * stride) * 16u;
+    const unsigned buf_bytes = blk_bytes * BLK;
+    const int S = a.stages;
+
+    // tile = (channel group, image, row tile), the channel groups of a pixel tile back to back; XCD-aware as in conv_f16_c8_kernel
+    const int G = gridDim.x;
+    int       tile;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = G >> 3, r = G & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt  = tile % a.n_mtiles, pt = tile / a.n_mtiles;
+    const int img = pt / a.tiles_per_image;
+    const int oy0 = (pt - img * a.tiles_per_image) * a.R;
+    const int npx = min(a.R, a.H - oy0) * a.W;
+
+    if (wid >= 4) {
+        // ------------------------------------------------------------------ producers: copy instruction k of a stage (channel block k / q_n,
+        // rows (k % q_n) * rpi ..) belongs to producer k % nprod
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.xb), 0, a.x_bytes, 0x00020000);
+        const int  pw    = wid - 4;
+        const int  rpi   = 64 >> a.stride_sh;                            // rows per copy instruction
+        const int  lrow  = lane >> a.stride_sh;
+        const int  x     = (lane & (stride - 1)) - PADG;
+        const bool colok = x >= 0 && x < a.W;
+        const int  iy0   = oy0 - PADG;
+        const int  q_n   = a.rows_pad / rpi;
+        const int  mine  = (a.n_ins - pw + a.nprod - 1) / a.nprod;       // this wave's copy instructions per stage
+        int s_i = 0;
+        auto issue_next = [&]() {
+            char* const dst = c8m_lds + (unsigned)(s_i % a.nbuf) * buf_bytes;
+            for (int k = pw; k < a.n_ins; k += a.nprod) {
+                const int  b    = k / q_n, q = k - b * q_n;
+                const int  gb   = s_i * BLK + b;
+                const bool bok  = gb < a.CB;
+                const unsigned plane = (unsigned)((img * a.CB + (bok ? gb : 0)) * HW);
+                const int  rr = q * rpi + lrow;
+                const int  iy = iy0 + rr;
+                const bool ok = bok && colok && rr < a.rows && iy >= 0 && iy < a.H;
+                const unsigned vo = ok ? (plane + (unsigned)(iy * a.W + x)) * 16u : kOob;
+                lds_dma_b128(xr, reinterpret_cast<float*>(dst + (unsigned)b * blk_bytes + (unsigned)q * 1024u), vo, 0u);
+            }
+            ++s_i;
+        };
+        while (s_i < S && s_i < a.nbuf) issue_next();
+        for (int s = 0; s < S; ++s) {
+            c8m_wait_vmcnt((s_i - s - 1) * mine);
+            asm volatile("s_barrier" ::: "memory");
+            if (s >= 1 && s_i < S) issue_next();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wf), 0, a.wf_bytes, 0x00020000);
+    const int  row0t = (mt * a.tm + wid) * 32;                           // first panel row of this wave's channel tile
+    const bool have  = wid < a.tm && row0t < a.Kp;
+    if (!have) {
+        for (int s = 0; s < S; ++s) asm volatile("s_barrier" ::: "memory");
+        return;
+    }
+    unsigned pixoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int p  = 32 * nb + l31;
+        const int pc = p < a.R * a.W ? p : 0;
+        const int pr = pc / a.W, px = pc - pr * a.W;
+        pixoff[nb] = (unsigned)lh * blk_bytes + (unsigned)((pr * stride + px) * 16);
+    }
+    floatx16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+    const unsigned wlane = (unsigned)lane * 16u + (unsigned)wid * 1024u;
+    // fragment of MFMA step t of stage cs: window taps (KS > 1): 16-channel step cs, tap t; 1x1: 16-channel step cs * 4 + t (past the
+    // last one: an out-of-range offset, zeros -- the copy wrote zeros for those channel blocks too)
+#define PVM_LOAD_A(dst_, cs_, t_)                                                                                \
+    {                                                                                                            \
+        const int c16_ = KS == 1 ? (cs_) * kMSteps + (t_) : (cs_);                                               \
+        const int tap_ = KS == 1 ? 0 : (t_);                                                                     \
+        const unsigned vo_ = c16_ < ncs16 ? wlane : kOob;                                                        \
+        dst_ = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wr, vo_,                          \
+                   (unsigned)((((mt * ncs16 + min(c16_, ncs16 - 1)) * TAPSW + tap_) * a.tm) * 1024), 0));        \
+    }
+    half8 af[RING];
+#pragma unroll
+    for (int s = 0; s < RING; ++s) PVM_LOAD_A(af[s], 0, s);
+    unsigned sb = 0;
+    for (int cs = 0; cs < S; ++cs) {
+        asm volatile("s_barrier" ::: "memory");
+        const char* const buf = c8m_lds + sb * buf_bytes;
+        sb = sb + 1 == (unsigned)a.nbuf ? 0u : sb + 1;
+        const int cs_x = cs + 1 < S ? cs + 1 : cs;                       // the stage the ring's tail prefetches (the last stage: its own again, unused)
+        half8 b8[2][NB];
+        // pixel operand of MFMA step t: window taps: channel blocks (0, 1), shifted by the tap; 1x1: channel blocks (2 t, 2 t + 1);
+        // pooled: the maximum over the 3x3 window of those
+#define PVM_READ_B(dst_, t_)                                                                                     \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                          \
+        if (POOL) {                                                                                              \
+            const char* const p0_ = buf + pixoff[nb] + (unsigned)(2 * (t_)) * blk_bytes;                         \
+            half8 m_[3];                                                                                         \
+            _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                        \
+                m_[g] = pk_max3_nan(*reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 0) * 16)),   \
+                                    *reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 1) * 16)),   \
+                                    *reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 2) * 16)));  \
+            dst_[nb] = pk_max3_nan(m_[0], m_[1], m_[2]);                                                         \
+        } else if (KS == 1) {                                                                                    \
+            dst_[nb] = *reinterpret_cast<const half8*>(buf + pixoff[nb] + (unsigned)(2 * (t_)) * blk_bytes);     \
+        } else {                                                                                                 \
+            dst_[nb] = *reinterpret_cast<const half8*>(buf + pixoff[nb] + (unsigned)((((t_) / KS) * stride + ((t_) % KS)) * 16)); \
+        }                                                                                                        \
+    }
+        if (!POOL) PVM_READ_B(b8[0], 0);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            // window taps / 1x1: the operands of step t + 1 are read in front of the MFMAs of step t; pooled: step by step (nine reads and
+            // four maxima per operand: two steps of them in flight are registers the four accumulators do not leave)
+            if (POOL) { PVM_READ_B(b8[t & 1], t); }
+            else if (t + 1 < TAPS) { PVM_READ_B(b8[(t + 1) & 1], t + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % RING], b8[t & 1][nb], acc[nb], 0, 0, 0);
+            if (t + RING < TAPS) PVM_LOAD_A(af[t % RING], cs, t + RING)
+            else                 PVM_LOAD_A(af[t % RING], cs_x, t + RING - TAPS)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef PVM_READ_B
+    }
+#undef PVM_LOAD_A
+
+    // ---- epilogue: register 4 g + j of accumulator nb is panel row row0t + 8 g + 4 lh + j of tile pixel 32 nb + l31
+    const ActBounds ab = act_bounds(a.act, a.lo, a.hi);
+    typedef const __attribute__((address_space(4))) float* const_float_p;
+    const const_float_p bias_c = (const_float_p)(unsigned long)a.bias;
+    // the member table is read through the kernarg pointer (indexed as an ordinary argument array it would be copied to scratch)
+    typedef const __attribute__((address_space(4))) C8mArgs* kernarg_p;
+    kernarg_p ka = (kernarg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    int sg = 0;
+    for (int q = 1; q < a.nseg; ++q) sg = row0t >= ka->seg[q].m_begin ? q : sg;
+    const int m_rel = row0t - ka->seg[sg].m_begin;                       // multiple of 32
+    const int kreal = ka->seg[sg].k;
+    const int P0    = oy0 * a.W + l31;
+    if (ka->seg[sg].layout == 1) {
+        _Float16* const yh = static_cast<_Float16*>(ka->seg[sg].y);
+        const int cbt = ka->seg[sg].ctotal >> 3, cb0 = (ka->seg[sg].coff + m_rel) >> 3, nblk = ka->seg[sg].nblk - (m_rel >> 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float bs0[4], bs1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bs0[j] = bs1[j] = -0.0f;
+                if (a.bias != nullptr) {
+                    bs0[j] = bias_c[min(row0t + 8 * g + j, a.Kp - 1)];
+                    bs1[j] = bias_c[min(row0t + 8 * g + 4 + j, a.Kp - 1)];
+                }
+            }
+            if (g >= nblk) continue;
+            _Float16* const yb = yh + (((size_t)img * cbt + cb0 + g) * HW + P0) * 8 + 4 * lh;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                half4 hv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[nb][4 * g + j] + (lh ? bs1[j] : bs0[j]);
+                    if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
+                    if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
+                    hv[j] = (_Float16)v;
+                }
+                if (32 * nb + l31 < npx) *reinterpret_cast<half4*>(yb + (size_t)(32 * nb) * 8) = hv;
+            }
+        }
+    } else {
+        float* const yf = static_cast<float*>(ka->seg[sg].y) + ((size_t)img * ka->seg[sg].ctotal + ka->seg[sg].coff + m_rel) * HW + P0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            float bs0 = -0.0f, bs1 = -0.0f;
+            if (a.bias != nullptr) {
+                bs0 = bias_c[min(row0t + dr, a.Kp - 1)];
+                bs1 = bias_c[min(row0t + dr + 4, a.Kp - 1)];
+            }
+            const int kk = m_rel + dr + 4 * lh;
+            if (kk >= kreal) continue;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float v = acc[nb][r] + (lh ? bs1 : bs0);
+                if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
+                if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
+                if (32 * nb + l31 < npx) conv_store1(yf + (size_t)(dr + 4 * lh) * HW + 32 * nb, v);
+            }
+        }
+    }
+}
+
+// MaxPool 3x3 (any stride / padding, MaxPool.py:41-72) on fp16 c8 tensors: one lane = one (image, channel block, output pixel), nine
+// 16-byte loads (cells of the zero padding: zeros; cells past the padded edge: not in the window), NaN wins, one 16-byte store.
+__global__ __launch_bounds__(kBlock) void maxpool3x3_c8_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int n, int cb, int h, int w,
+                                                               int oh, int ow, int sh, int sw, int pt, int pl, int hp, int wp) {
+    const size_t total = (size_t)n * cb * oh * ow;
+    const half8 zero = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int    ox = (int)(e % ow);
+        size_t       f  = e / ow;
+        const int    oy = (int)(f % oh);
+        const size_t plane = f / oh;                                  // image * cb + block
+        const half8* const xp = reinterpret_cast<const half8*>(x) + plane * (size_t)(h * w);
+        half8 rowm[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int py = oy * sh + r;                               // row in the padded image
+            half8 v[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int px = ox * sw + s;
+                const int iy = py - pt, ix = px - pl;
+                const bool inwin = py < hp && px < wp;                // the window is clipped at the padded edge (MaxPool.py:63-66)
+                const bool inimg = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                // a cell outside the window repeats the window's first cell (always inside: oy * sh < hp), a padding cell is zero
+                const int cy = inwin ? iy : oy * sh - pt, cx = inwin ? ix : ox * sw - pl;
+                const bool cimg = inwin ? inimg : (cy >= 0 && cy < h && cx >= 0 && cx < w);
+                v[s] = cimg ? xp[(size_t)cy * w + cx] : zero;
+            }
+            rowm[r] = pk_max3_nan(v[0], v[1], v[2]);
+        }
+        reinterpret_cast<half8*>(y)[e] = pk_max3_nan(rowm[0], rowm[1], rowm[2]);
+    }
+}
+
+inline int c8m_blocks(int c) { return (c + 15) / 16 * 2; }
+inline int c8m_mtiles(int k) { return (k + 127) / 128; }
+inline int c8m_tm(int k) { const int t32 = (k + 31) / 32, nm = c8m_mtiles(k); return (t32 + nm - 1) / nm; }
+
+struct C8mTile { int R, tiles, rows, rows_pad, stride_sh, nb; };
+inline bool c8m_tile(int h, int w, int padg, C8mTile& t) {
+    if (h <= 0 || w <= 0 || w + 2 * padg > 64) return false;
+    int sh = 3;
+    while ((1 << sh) < w + 2 * padg) ++sh;
+    t.stride_sh = sh;
+    int r = 128 / w;
+    if (r > h) r = h;
+    if (r < 1) return false;
+    t.tiles = (h + r - 1) / r;
+    t.R     = (h + t.tiles - 1) / t.tiles;
+    t.tiles = (h + t.R - 1) / t.R;
+    t.rows  = t.R + 2 * padg;
+    const int rpi = 64 >> sh;
+    t.rows_pad = (t.rows + rpi - 1) / rpi * rpi;
+    t.nb = t.R * w <= 64 ? 2 : 4;
+    return true;
+}
+
+template <int KS, bool POOL>
+void launch_c8m(const C8mArgs& a, int grid, int nb, size_t lds) {
+    const int threads = 64 * (4 + a.nprod);
+    if (nb == 2) hipLaunchKernelGGL((conv_f16_c8m_kernel<KS, 2, POOL>), dim3(grid), dim3(threads), lds, state().stream, a);
+    else         hipLaunchKernelGGL((conv_f16_c8m_kernel<KS, 4, POOL>), dim3(grid), dim3(threads), lds, state().stream, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pvhip_conv2d_f16_c8_multi_supported(int c, int h, int w, int kh, int kw, int pool, int n_dest) {
+    if (c <= 0 || kh != kw || (kh != 1 && kh != 3 && kh != 5) || n_dest < 1 || n_dest > PVHIP_MAX_CONV_DESTS) return 0;
+    if (pool && kh != 1) return 0;
+    if (n_dest > 1 && kh != 1) return 0;
+    C8mTile t;
+    return c8m_tile(h, w, pool ? 1 : (kh - 1) / 2, t) ? 1 : 0;
+}
+
+int pvhip_conv2d_f16_c8_multi(const void* xb, const float* wf, int n, int c, int h, int w, int kh, int kw, int pool,
+                              const float* bias, int act, float act_lo, float act_hi, int n_dest, const pvhip_conv_dest* dests) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && dests != nullptr);
+    if (!pvhip_conv2d_f16_c8_multi_supported(c, h, w, kh, kw, pool, n_dest))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_c8_multi: stride-1 \"same\" 1x1 (one or several members, optionally behind a 3x3 / 1 / 1 MaxPool) / 3x3 / 5x5 windows over short rows");
+    C8mArgs a;
+    int k_panel = 0;
+    unsigned long long out_max = 0;
+    for (int i = 0; i < n_dest; ++i) {
+        const pvhip_conv_dest& d = dests[i];
+        PVHIP_CHECK_ARG(d.y != nullptr && d.k > 0 && (d.layout == 0 || d.layout == 1));
+        PVHIP_CHECK_ARG(d.channels_total == 0 || (d.channel_offset >= 0 && d.channel_offset + d.k <= d.channels_total));
+        C8mSeg& sgm = a.seg[i];
+        sgm.y = d.y; sgm.m_begin = k_panel; sgm.k = d.k; sgm.layout = d.layout;
+        if (d.layout == 1) {
+            PVHIP_CHECK_ARG(act == 0 || act == 1);                      // the zeros of the padding channels must survive the activation
+            if (d.channels_total > 0) {
+                PVHIP_CHECK_ARG(d.k % 8 == 0 && d.channel_offset % 8 == 0 && d.channels_total % 16 == 0);
+                sgm.ctotal = d.channels_total; sgm.coff = d.channel_offset; sgm.nblk = d.k / 8;
+            } else {
+                sgm.ctotal = (d.k + 15) / 16 * 16; sgm.coff = 0; sgm.nblk = sgm.ctotal / 8;
+            }
+        } else {
+            sgm.ctotal = d.channels_total > 0 ? d.channels_total : d.k;
+            sgm.coff   = d.channels_total > 0 ? d.channel_offset : 0;
+            sgm.nblk   = 0;
+        }
+        k_panel += (d.k + 31) / 32 * 32;
+        const unsigned long long oe = (unsigned long long)n * sgm.ctotal * h * w;
+        if (oe > out_max) out_max = oe;
+    }
+    const int cb = c8m_blocks(c);
+    const unsigned long long in_b = (unsigned long long)n * cb * h * w * 16ull;
+    if (in_b >= (1ull << 31) || out_max >= (1ull << 31)) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_c8_multi: input exceeds 2^31 bytes or an output 2^31 elements");
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(xb != nullptr && wf != nullptr);
+    C8mTile t;
+    c8m_tile(h, w, pool ? 1 : (kh - 1) / 2, t);
+    a.xb = static_cast<const _Float16*>(xb); a.wf = reinterpret_cast<const _Float16*>(wf); a.bias = bias;
+    a.N = n; a.CB = cb; a.H = h; a.W = w; a.Kp = k_panel;
+    a.tm = c8m_tm(k_panel); a.n_mtiles = c8m_mtiles(k_panel);
+    a.tiles_per_image = t.tiles;
+    a.R = t.R; a.rows = t.rows; a.rows_pad = t.rows_pad; a.stride_sh = t.stride_sh;
+    const int blk = kh == 1 ? 2 * kMSteps : 2;
+    const int ncs16 = cb / 2;
+    a.stages = kh == 1 ? (ncs16 + kMSteps - 1) / kMSteps : ncs16;
+    a.n_ins  = blk * (t.rows_pad / (64 >> t.stride_sh));
+    const size_t stage = (size_t)blk * t.rows_pad * (1 << t.stride_sh) * 16;
+    int nbuf = (int)(52 * 1024 / stage);
+    if (nbuf > kMMaxBuf) nbuf = kMMaxBuf;
+    if (nbuf > a.stages) nbuf = a.stages;
+    if (nbuf < 1) nbuf = 1;
+    {
+        const int knob = settings().f16_c8_prod;                                // PVHIP_CONV_F16_C8_PROD=1..4 (tuning runs); default: ~3 copy instructions per wave and stage
+        int np = knob > 0 ? knob : (a.n_ins + 2) / 3;                           // (GoogLeNet at batch 256, 1x1 family: one producer 1.51 ms, by sixes 1.08, four 0.98)
+        a.nprod = np < 1 ? 1 : (np > 4 ? 4 : np);
+    }
+    const int per_wave = (a.n_ins + a.nprod - 1) / a.nprod;
+    if ((nbuf - 1) * per_wave > 62) nbuf = 62 / per_wave + 1;
+    if (stage * nbuf > 64 * 1024) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_c8_multi: a stage of %zu bytes does not fit", stage);
+    a.nbuf = nbuf;
+    a.x_bytes  = (unsigned)in_b;
+    a.wf_bytes = (unsigned)(pvhip_conv2d_f16_c8_pack_elems(k_panel, c, kh, kw) * 4);
+    a.act = act; a.lo = act_lo; a.hi = act_hi;
+    a.nseg = n_dest;
+    const long tiles = (long)n * t.tiles * a.n_mtiles;
+    if (tiles > 0x3fffffffL) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_c8_multi: too many tiles");
+    a.n_tiles = (int)tiles;
+    const size_t lds = stage * nbuf;
+    if (pool)         launch_c8m<1, true>(a, (int)tiles, t.nb, lds);
+    else if (kh == 1) launch_c8m<1, false>(a, (int)tiles, t.nb, lds);
+    else if (kh == 3) launch_c8m<3, false>(a, (int)tiles, t.nb, lds);
+    else              launch_c8m<5, false>(a, (int)tiles, t.nb, lds);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_maxpool3x3_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
+                        int pad_top, int pad_left, int pad_bottom, int pad_right) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 && pad_right >= 0);
+    const int hp = h + pad_top + pad_bottom, wp = w + pad_left + pad_right;
+    PVHIP_CHECK_ARG((oh - 1) * sh < hp && (ow - 1) * sw < wp);
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+    const int cb = c8m_blocks(c);
+    const size_t total = (size_t)n * cb * oh * ow;
+    hipLaunchKernelGGL(maxpool3x3_c8_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, static_cast<const _Float16*>(x),
+                       static_cast<_Float16*>(y), n, cb, h, w, oh, ow, sh, sw, pad_top, pad_left, hp, wp);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+}  // extern "C"

@@ -95,6 +95,9 @@ SIGNATURES = {
     'pvhip_conv2d_f16_c8_supported': (_c.c_int, [_c.c_int] * 11),
     'pvhip_conv2d_f16_c8_pack_elems': (_c.c_size_t, [_c.c_int] * 4),
     'pvhip_conv2d_f16_c8_pack': (_c.c_int, [_fp, _fp] + [_c.c_int] * 4),
+    'pvhip_conv2d_f16_c8_multi_supported': (_c.c_int, [_c.c_int] * 7),
+    'pvhip_conv2d_f16_c8_multi': (_c.c_int, [_c.c_void_p, _fp] + [_c.c_int] * 7 + [_fp, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _c.c_void_p]),
+    'pvhip_maxpool3x3_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 12),
     'pvhip_conv2d_f16_c8': (_c.c_int, [_c.c_void_p, _fp, _fp] + [_c.c_int] * 7 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),
@@ -114,7 +117,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -189,7 +192,7 @@ settings_serial = 0      # bumped by every reload: host-side plans that bake ker
 conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'      # Convolution plugin: pad the input of a c-major layer in a pass of its own
 conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'    # Convolution plugin, FP16 IRs: the f16 form of the LDS-DMA kernel where it applies
 conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)  # ... and the span kernel before it: 1 = 3x3 / 5x5 layers, 2 = 1x1 too (slower there), 0 = never
-conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '1') != '0'      # ... and fp16 tensors blocked by eight channels between a 1x1 convolution and the 3x3 / 5x5 behind it
+conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '2') != '0'      # ... and fp16 tensors blocked by eight channels between a 1x1 convolution and the 3x3 / 5x5 behind it
 
 
 def reload_settings():
@@ -200,7 +203,7 @@ def reload_settings():
     conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'
     conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)
-    conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '1') != '0'
+    conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '2') != '0'
     settings_serial += 1
 
 
@@ -441,6 +444,34 @@ class BlockedHalf:
         return a if dtype is None else a.astype(dtype, copy=False)
 
 
+class BlockedChannelSlice:
+    """Channels [coff, coff + k) of a BlockedHalf, as written in place by a producer whose consumer is a channel Concat whose buffer is
+    blocked fp16 (coff and k are multiples of 8).  The ndarray surface of the logical slice; only handed to the Concat it belongs to (which
+    is not dispatched) and to debugging code."""
+    __slots__ = ('base', 'coff', 'shape', 'dtype')
+
+    def __init__(self, base: 'BlockedHalf', coff: int, k: int):
+        self.base, self.coff = base, int(coff)
+        self.shape = (base.shape[0], int(k)) + tuple(base.shape[2:])
+        self.dtype = base.dtype
+
+    @property
+    def ndim(self):
+        return 4
+
+    @property
+    def size(self):
+        n, c, h, w = self.shape
+        return n * c * h * w
+
+    def numpy(self):
+        return np.ascontiguousarray(self.base.numpy()[:, self.coff:self.coff + self.shape[1]])
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+
 def as_device(data, dtype=np.float32) -> DeviceTensor:
     """Accept what a predecessor plugin handed over: a DeviceTensor (ours) or an ndarray (when our
     plugins are mixed with host plugins, e.g. under the reference's own engine)."""
@@ -449,7 +480,9 @@ def as_device(data, dtype=np.float32) -> DeviceTensor:
     if isinstance(data, ChannelSlice):
         return DeviceTensor.from_numpy(data.numpy())     # densify (debug paths only)
     if isinstance(data, BlockedHalf):
-        return data.dense()                              # a reader that does not take the blocked layout (debug paths only)
+        return data.dense()                              # a reader that does not take the blocked layout
+    if isinstance(data, BlockedChannelSlice):
+        return DeviceTensor.from_numpy(data.numpy())     # densify (debug paths only)
     return DeviceTensor.from_numpy(np.asarray(data), dtype=dtype)
 
 

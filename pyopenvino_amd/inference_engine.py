@@ -511,7 +511,7 @@ class Executable_Network:
         ports alias the fused tensor.  Plugins that do not understand the hints (any foreign Convolution
         plugin) never see them because fusion is only planned for this package's plugin."""
         self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pool_conv = {}, set(), {}, {}, {}
-        self._pre_add, self._c8_out = {}, set()
+        self._pre_add, self._c8_out, self._c8_concat, self._c8_entry = {}, set(), set(), set()
         if 'list_schedule' in self.__dict__:
             self.task_list = list(self.list_schedule)
         if not self.fuse_epilogues:
@@ -663,7 +663,7 @@ class Executable_Network:
         # eight (device.BlockedHalf): what the reference holds there is a float16 tensor too (common_def.py:13-17), and the blocked
         # form is the reader's MFMA operand as it stands.  PVHIP_CONV_F16_C8=0: fp32 NCHW everywhere, as before.
         self._c8_out = set()
-        if f16 and os.environ.get('PVHIP_CONV_F16_C8', '1') != '0' and os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0' \
+        if f16 and os.environ.get('PVHIP_CONV_F16_C8', '2') != '0' and os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0' \
                 and getattr(conv_plugin, 'SUPPORTS_C8', False):
             for cid, f in self._fusion.items():
                 if G.nodes[cid]['type'] != 'Convolution' or f['into'] is not None or cid in self._pool_conv or cid in self._pre_add:
@@ -679,7 +679,67 @@ class Executable_Network:
                     continue
                 if conv_plugin.c8_writer_ok(G.nodes[cid]) and conv_plugin.c8_reader_ok(G.nodes[rid]):
                     self._c8_out.add(cid)
+            if os.environ.get('PVHIP_CONV_F16_C8', '2') == '2' and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
+                self.plan_c8_modules(conv_plugin)
         self.order_for_locality()
+
+    def plan_c8_modules(self, conv_plugin):
+        """FP16 IRs, second step (default; PVHIP_CONV_F16_C8=1: only the tensors between a 1x1 convolution and the 3x3 / 5x5 behind it): whole inception modules on blocked fp16 tensors.  A channel Concat whose members are
+        fused convolution chains that all (a) read a tensor that WILL be blocked -- the previous module's blocked Concat, a 3x3 MaxPool of
+        one, a 3x3_reduce / 5x5_reduce tensor (`_c8_out`), or the converted entry tensor -- and (b) run on pvhip_conv2d_f16_c8_multi, gets a
+        blocked buffer (`_c8_concat`).  The tensor the first module reads is converted once (`_c8_entry`).  A reader that does not take
+        the blocked layout densifies by itself (device.as_device): only writers need this plan."""
+        G = self.ienet.G
+        src_of = lambda nid: next((p_ for p_ in G.pred[nid] if G.edges[(p_, nid)]['connection'][3] == 0), None)   # noqa: E731
+        blocked = set()
+        for cid in self._c8_out:
+            f = self._fusion[cid]
+            blocked.add(f['relu'] if f['relu'] is not None else f['add'])
+
+        def data_src(cid):
+            pooled = self._pool_conv.get(cid)
+            return src_of(pooled[0]) if pooled is not None else src_of(cid)
+
+        def member_ok(cid, assume=None):
+            f = self._fusion.get(cid)
+            if f is None or cid in self._pre_add or (f['act'] is not None and f['act'][0] != 'relu'):
+                return False
+            pooled = self._pool_conv.get(cid)
+            src = data_src(cid)
+            if src is None or not (src in blocked or src == assume):
+                return False
+            return conv_plugin.c8_module_member_ok(G.nodes[cid], G.nodes[pooled[0]] if pooled is not None else None)
+
+        members_of = {}
+        for cid, f in self._fusion.items():
+            if f['into'] is not None:
+                members_of.setdefault(f['into'][0], []).append(cid)
+        for nid in self.list_schedule:
+            node = G.nodes[nid]
+            if node['type'] == 'MaxPool':
+                src = src_of(nid)
+                if src in blocked and tuple(common_def.string_to_tuple(node['data']['kernel'])) == (3, 3) and nid not in self._lrn_pool.values():
+                    blocked.add(nid)          # the plugin pools a blocked tensor as it is (a folded pool hands its input on)
+            elif node['type'] == 'Concat' and nid in self._concat_direct:
+                members = members_of.get(nid, [])
+                if not members:
+                    continue
+                # the first module: the tensor its 1x1 arms read is not blocked yet -- it is converted if that makes the module blocked
+                entry = None
+                srcs = {data_src(m) for m in members}
+                outside = [s_ for s_ in srcs if s_ not in blocked]
+                if len(outside) == 1 and G.nodes[outside[0]]['type'] not in ('Convolution', 'Concat', 'Const', 'Parameter'):
+                    entry = outside[0]
+                    readers = list(G.successors(entry))
+                    folded_pools = {p[0] for p in self._pool_conv.values()}
+                    if not all(r in self._fusion or r in folded_pools for r in readers):
+                        entry = None
+                if all(member_ok(m, assume=entry) for m in members):
+                    self._c8_concat.add(nid)
+                    blocked.add(nid)
+                    if entry is not None:
+                        self._c8_entry.add(entry)
+                        blocked.add(entry)
 
     def order_for_locality(self):
         """Another legal order of the same list schedule (round 4; scripts/exp_hoist.py).  The reference's sweep (:218-242) runs the
@@ -1053,6 +1113,11 @@ class Executable_Network:
                 common_def.compare_results(node['name'], next(iter(res.values())), self.expected_result, disp_results=False,
                                            rtol=self.expected_rtol)
             if len(res) > 0:
+                if self._c8_entry and (task in self._c8_entry or (pooled is not None and pooled in self._c8_entry)):
+                    # the tensor the first blocked module reads: converted once, every reader gets the blocked form
+                    from . import device as dev_
+                    res = {port_id: (dev_.BlockedHalf.from_dense(data) if isinstance(data, dev_.DeviceTensor) and data.ndim == 4 else data)
+                           for port_id, data in res.items()}
                 for port_id, data in res.items():
                     node['output'][port_id]['data'] = data
                 if fusion is not None:
@@ -1236,7 +1301,9 @@ class Executable_Network:
         node = self.ienet.G.nodes[cat_id]
         port = next(iter(node['output']))
         if node.get('_buf_serial') != self._infer_serial:
-            node['output'][port]['data'] = device.DeviceTensor.empty(node['output'][port]['dims'])
+            dims = node['output'][port]['dims']
+            # FP16 IRs, module form: the Concat's buffer is fp16 blocked by eight channels and every member writes its range of it
+            node['output'][port]['data'] = device.BlockedHalf(dims) if cat_id in self._c8_concat else device.DeviceTensor.empty(dims)
             node['_buf_serial'] = self._infer_serial
         return node['output'][port]['data']
 

@@ -31,6 +31,9 @@ SUPPORTS_PRE_ADD = True
 # FP16 IRs (node['_f16_mfma']): node['_out_c8'] (a sibling: its dict's 'c8') asks for the output as dev.BlockedHalf -- fp16, channels
 # blocked by eight -- for a reader that c8_reader_ok() accepts; compute() takes such an input through pvhip_conv2d_f16_c8.
 SUPPORTS_C8 = True
+# ... and, second step: a blocked INPUT with blocked outputs (node['_out_into'] = (dev.BlockedHalf, channel offset): the module's blocked
+# Concat buffer), several members, or a MaxPool in front runs as one launch of the module form (launch_c8_multi; c8_module_member_ok()).
+SUPPORTS_C8_MODULES = True
 
 
 # A pass made of such nodes can be recorded into a hipGraph (Executable_Network.infer does so by itself for device-resident inputs):
@@ -150,6 +153,105 @@ def launch_c8(node, xb, w, bias=None, act=None, into=None):
     dev.call('pvhip_conv2d_f16_c8', ctypes.c_void_p(xb.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), n, c, h, wd, kn, kh, kw,
              ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
     return y
+
+
+def c8_multi_ok(x_shape, kh: int, kw: int, pool: bool, n_members: int) -> bool:
+    """True when pvhip_conv2d_f16_c8_multi covers a launch of n_members convolutions with this window over a blocked input of this shape."""
+    n, c, h, wd = x_shape
+    return bool(dev.call('pvhip_conv2d_f16_c8_multi_supported', int(c), int(h), int(wd), int(kh), int(kw), 1 if pool else 0, int(n_members)))
+
+
+def c8_module_member_ok(node: dict, pool_node: dict = None) -> bool:
+    """True when this Convolution node can run on pvhip_conv2d_f16_c8_multi with a blocked input AND a blocked output: a stride-1 "same"
+    1x1 / 3x3 / 5x5 window (a 1x1 optionally behind a 3x3 / 1 / 1 MaxPool), output channels a multiple of 8."""
+    try:
+        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+        st, pb, pe = (common_def.string_to_tuple(attrs[key]) for key in ('strides', 'pads_begin', 'pads_end'))
+        if len(xd) != 4 or len(wd) != 4 or wd[1] != xd[1] or wd[2] != wd[3] or wd[0] % 8 != 0 or tuple(st) != (1, 1):
+            return False
+        pad = (wd[2] - 1) // 2
+        if tuple(pb) != (pad, pad) or tuple(pe) != (pad, pad) or attrs['auto_pad'] not in ('explicit', 'valid'):
+            return False
+        if pool_node is not None:
+            pa = pool_node['data']
+            pk, ps, ppb, ppe = (common_def.string_to_tuple(pa[k]) for k in ('kernel', 'strides', 'pads_begin', 'pads_end'))
+            if wd[2] != 1 or tuple(pk) != (3, 3) or tuple(ps) != (1, 1) or tuple(ppb) != (1, 1) or tuple(ppe) != (1, 1) or pa['auto_pad'] != 'explicit':
+                return False
+            if tuple(pool_node['input'][0]['dims']) != tuple(xd):
+                return False
+        return c8_multi_ok(xd, wd[2], wd[3], pool_node is not None, 1)
+    except (KeyError, ValueError, AssertionError, IndexError):
+        return False
+
+
+def c8_panel(node: dict, ws, biases):
+    """(fp16 MFMA fragments of the members' weights laid one after the other, each padded to whole 32-channel tiles; fused bias or None),
+    built once and kept on the leading node."""
+    key = tuple(w._block for w in ws) + tuple(b._block if b is not None else None for b in biases)
+    cached = node.get('_hip_c8panel')
+    if cached is not None and len(cached[0]) == len(key) and all(a is b for a, b in zip(cached[0], key)):
+        return cached[1]
+    c, kh, kw = ws[0].shape[1:]
+    pads = [-(-w.shape[0] // 32) * 32 for w in ws]
+    host_w = np.zeros((sum(pads), c, kh, kw), dtype=np.float32)
+    host_b = np.zeros((sum(pads),), dtype=np.float32)
+    row = 0
+    for w, b, kp in zip(ws, biases, pads):
+        host_w[row:row + w.shape[0]] = w.numpy()
+        if b is not None:
+            host_b[row:row + w.shape[0]] = b.numpy().reshape(-1)
+        row += kp
+    wf = dev.DeviceTensor.from_numpy(host_w)
+    wpack = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_f16_c8_pack_elems', host_w.shape[0], c, kh, kw)),))
+    dev.call('pvhip_conv2d_f16_c8_pack', ctypes.c_void_p(wf.ptr), ctypes.c_void_p(wpack.ptr), host_w.shape[0], c, kh, kw)
+    packed = (wpack, dev.DeviceTensor.from_numpy(host_b) if any(b is not None for b in biases) else None)
+    node['_hip_c8panel'] = (key, packed)
+    return packed
+
+
+def launch_c8_multi(node, xb, members, pool=False, act=None):
+    """FP16 IRs, the module form: members = [(weights, bias or None, into or None, blocked)] over the blocked input xb, ONE launch
+    (pvhip_conv2d_f16_c8_multi).  into = (tensor, channel offset) with a dev.BlockedHalf (the module's blocked Concat buffer) or a
+    DeviceTensor (an fp32 Concat buffer); without it `blocked` chooses a dev.BlockedHalf or an fp32 tensor of the member's own.
+    pool: a 3x3 / 1 / 1 MaxPool of xb in front (one member).  -> list of outputs."""
+    n, c, h, wd = xb.shape
+    ws = [m[0] for m in members]
+    kh, kw = ws[0].shape[2:]
+    for w in ws:
+        if w.shape[1] != c or tuple(w.shape[2:]) != (kh, kw):
+            raise ValueError('the members of a launch are convolutions of the same {} channels with the same window, got {}'.format(c, w.shape))
+    wpack, bias = c8_panel(node, ws, [m[1] for m in members])
+    act_code, act_lo, act_hi = 0, 0.0, 0.0
+    if act is not None:
+        act_code = 1 if act[0] == 'relu' else 2
+        if act_code == 2:
+            act_lo, act_hi = float(act[1]), float(act[2])
+    dests = (dev.ConvDest * len(members))()
+    outs, keep = [], []
+    for i, (w, _, into, blocked) in enumerate(members):
+        kn = w.shape[0]
+        if into is not None:
+            target, coff = into
+            assert target.shape[0] == n and tuple(target.shape[2:]) == (h, wd) and coff + kn <= target.shape[1]
+            if isinstance(target, dev.BlockedHalf):
+                outs.append(dev.BlockedChannelSlice(target, coff, kn))
+                layout = 1
+            else:
+                outs.append(dev.ChannelSlice(target, coff, kn))
+                layout = 0
+            ctotal = target.shape[1]
+        else:
+            target = dev.BlockedHalf((n, kn, h, wd)) if blocked else dev.DeviceTensor.empty((n, kn, h, wd))
+            outs.append(target)
+            coff, ctotal, layout = 0, 0, 1 if blocked else 0
+        if layout == 1 and act_code == 2:
+            raise ValueError('a blocked fp16 output takes no Clamp')
+        keep.append(target)
+        dests[i].y, dests[i].k, dests[i].channel_offset, dests[i].channels_total, dests[i].layout = target.ptr, kn, int(coff), int(ctotal), layout
+    node['_hip_f16'] = 'c8 module' + (', MaxPool' if pool else '') + (', {} members'.format(len(members)) if len(members) > 1 else '')
+    dev.call('pvhip_conv2d_f16_c8_multi', ctypes.c_void_p(xb.ptr), ctypes.c_void_p(wpack.ptr), n, c, h, wd, kh, kw, 1 if pool else 0,
+             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, act_lo, act_hi, len(members), ctypes.cast(dests, ctypes.c_void_p))
+    return outs
 
 
 def prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16=False) -> bool:
@@ -418,15 +520,46 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
     pads_end = common_def.string_to_tuple(attrs['pads_end'])
     auto_pad = attrs['auto_pad']
-    x = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and node.get('_f16_mfma') and c8_reader_ok(node) else dev.as_device(inputs[0])
     w = dev.as_device(inputs[1])
+    # FP16 IRs: an input that is fp16 blocked by eight channels (dev.BlockedHalf) goes to the module form (blocked outputs, several members,
+    # a MaxPool in front) or to the reader kernel (fp32 output); any other geometry densifies it (the same fp16 values)
+    module_path = reader_path = False
+    if isinstance(inputs[0], dev.BlockedHalf) and node.get('_f16_mfma'):
+        kh_, kw_ = w.shape[2], w.shape[3]
+        pad_ = (kh_ - 1) // 2
+        same = kh_ == kw_ and tuple(strides) == (1, 1) and tuple(pads_begin) == (pad_, pad_) and tuple(pads_end) == (pad_, pad_)
+        into_ = node.get('_out_into')
+        pool_ = node.get('_fuse_pool_in') is not None
+        sibs_ = node.get('_siblings') or ()
+        wants_module = bool(sibs_) or pool_ or bool(node.get('_out_c8')) or (into_ is not None and isinstance(into_[0], dev.BlockedHalf))
+        module_path = same and wants_module and c8_multi_ok(inputs[0].shape, kh_, kw_, pool_, 1 + len(sibs_))
+        reader_path = not module_path and not sibs_ and not pool_ and c8_reader_ok(node)
+    x = inputs[0] if (module_path or reader_path) else dev.as_device(inputs[0])
+    if x is not inputs[0]:
+        inputs = dict(inputs)
+        inputs[0] = x
     bias = node.get('_fuse_bias')
     if bias is not None:
         bias = dev.as_device(bias)
         assert bias.size == w.shape[0]
     siblings = node.get('_siblings')
-    if node.get('_f16_mfma') and isinstance(inputs[0], dev.BlockedHalf) and c8_reader_ok(node):
-        y = launch_c8(node, inputs[0], w, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'))
+    into = node.get('_out_into')
+    pooled = node.get('_fuse_pool_in') is not None
+    if module_path:
+        # the module form: a blocked input, and blocked outputs / several members / a MaxPool in front
+        members = [(w, bias, into, bool(node.get('_out_c8')))]
+        for sib in siblings or ():
+            common_def.validate_inputs(sib['node'], sib['inputs'])
+            sb = sib.get('bias')
+            members.append((dev.as_device(sib['inputs'][1]), dev.as_device(sb) if sb is not None else None, sib.get('into'), bool(sib.get('c8'))))
+        outs = launch_c8_multi(node, inputs[0], members, pool=pooled, act=node.get('_fuse_act'))
+        y, node['_sibling_out'] = outs[0], outs[1:]
+    elif (into is not None and isinstance(into[0], dev.BlockedHalf)) or any(sib.get('into') is not None and isinstance(sib['into'][0], dev.BlockedHalf)
+                                                                            for sib in siblings or ()):
+        raise RuntimeError('{}: a blocked fp16 Concat buffer, but this launch cannot write it (plan_c8_modules promised a blocked input and '
+                           'pvhip_conv2d_f16_c8_multi)'.format(node.get('name')))
+    elif reader_path:
+        y = launch_c8(node, inputs[0], w, bias=bias, act=node.get('_fuse_act'), into=into)
     elif node.get('_f16_mfma') and (siblings or node.get('_out_c8')) and dev.conv_f16_dma:
         members = [(w, bias, node.get('_out_into'), bool(node.get('_out_c8')))]
         for sib in siblings or ():

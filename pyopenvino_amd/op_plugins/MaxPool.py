@@ -61,13 +61,23 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
     pads_end = common_def.string_to_tuple(attrs['pads_end'])
     kernel = common_def.string_to_tuple(attrs['kernel'])
-    x = dev.as_device(inputs[0])
+    blocked = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and tuple(kernel) == (3, 3) and node.get('_fuse_lrn') is None else None
+    x = blocked if blocked is not None else dev.as_device(inputs[0])
     n, c, h, w = x.shape
     oh, ow = calc_output_shape((h, w), kernel, strides, pads_begin, pads_end, attrs['rounding_type'], attrs['auto_pad'])
     hp, wp = h + pads_begin[0] + pads_end[0], w + pads_begin[1] + pads_end[1]
     if oh > 0 and ow > 0 and ((oh - 1) * strides[0] >= hp or (ow - 1) * strides[1] >= wp):
         # np.max over an empty patch (MaxPool.py:69-70)
         raise ValueError('zero-size array to reduction operation maximum which has no identity')
+    if blocked is not None and oh > 0 and ow > 0:
+        # FP16 IRs: the input is fp16 blocked by eight channels (dev.BlockedHalf, what the reference holds here is a float16 tensor):
+        # pooled as it is, the output is blocked too
+        yb = dev.BlockedHalf((n, c, oh, ow))
+        dev.call('pvhip_maxpool3x3_c8', ctypes.c_void_p(blocked.ptr), ctypes.c_void_p(yb.ptr), n, c, h, w, oh, ow, strides[0], strides[1],
+                 pads_begin[0], pads_begin[1], pads_end[0], pads_end[1])
+        return {common_def.first_output_port(node): yb}
+    if blocked is not None:
+        x = dev.as_device(blocked)
     y = dev.DeviceTensor.empty((n, c, oh, ow))
     lrn_node = node.get('_fuse_lrn')
     if lrn_node is not None:

@@ -606,7 +606,11 @@ def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp
     from pyopenvino_amd import synth
     z = np.load(os.path.join(GOLDEN, 'googlenet_fp16_rows2.npz'))
     images = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
-    prob16, logits16, net16 = _googlenet_fp16_logits(HIP, False, images, tmp_path)
+    os.environ['PVHIP_CONV_F16_C8'] = '1'         # the first step only: the tensors between a 1x1 convolution and the 3x3 / 5x5 behind it
+    try:
+        prob16, logits16, net16 = _googlenet_fp16_logits(HIP, False, images, tmp_path)
+    finally:
+        del os.environ['PVHIP_CONV_F16_C8']
     assert net16.f16_mfma and all('_hip_f16' in net16.G.nodes[n] for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution')
     # the 3x3_reduce / 5x5_reduce tensors are fp16 in HBM (blocked by eight channels) and every 3x3 / 5x5 convolution reads them so
     spatial = [n for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution' and net16.G.nodes[n]['input'][1]['dims'][2] in (3, 5)]
@@ -628,6 +632,41 @@ def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp
     assert helpers.rel_err(logits32, z['logits']) <= 3e-3
     assert_close(logits16, logits32, 5e-3, 'f16 MFMA vs fp32 arithmetic, GoogLeNet FP16 IR', elementwise=False)
     assert np.abs(prob16.sum(axis=1) - 1).max() <= 1e-4
+
+
+def test_googlenet_fp16_ir_whole_modules_on_blocked_fp16_tensors(hip, tmp_path, monkeypatch):
+    """PVHIP_CONV_F16_C8=2: the inception modules of the FP16 IR from the module input to the channel Concat on fp16 tensors blocked by eight
+    channels (pvhip_conv2d_f16_c8_multi, pvhip_maxpool3x3_c8): every Concat buffer is blocked, the tensor module 3a reads is converted once.
+    Against the reference's float16 run of the same IR (1e-2 of the logits' maximum, the same classes) and against the default mode
+    (fp32 Concat buffers; 2e-3: the same arithmetic, one more fp16 rounding per module output -- which the reference does too)."""
+    from pyopenvino_amd import device, synth
+    z = np.load(os.path.join(GOLDEN, 'googlenet_fp16_rows2.npz'))
+    images = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
+    monkeypatch.setenv('PVHIP_CONV_F16_C8', '1')
+    _, logits1, _ = _googlenet_fp16_logits(HIP, False, images, tmp_path)
+    monkeypatch.delenv('PVHIP_CONV_F16_C8')         # the default
+    from pyopenvino_amd import IECore
+    xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    xml16, blob16 = synth.fp16_ir(xml, synth.synth_weights(xml, 1234), str(tmp_path))
+    ie = IECore(plugin_package=HIP)
+    net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+    net.set_batch(len(images))
+    ex = ie.load_network(net)
+    prob = helpers.infer_one(ex, net, images)
+    assert len(ex._c8_concat) == 9 and len(ex._c8_entry) == 1
+    kinds = [net.G.nodes[n].get('_hip_f16', '') for n in net.G.nodes if net.G.nodes[n]['type'] == 'Convolution' and n not in ex._fused_away]
+    assert sum('c8 module' in k for k in kinds) >= 9 * 4, kinds
+    cat = next(n for n in ex._c8_concat)
+    assert isinstance(next(iter(net.G.nodes[cat]['output'].values()))['data'], device.BlockedHalf)
+    soft = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'SoftMax')
+    logits2 = np.asarray(next(iter(net.G.nodes[next(iter(net.G.pred[soft]))]['output'].values()))['data'])
+    err_ref, err_1 = helpers.rel_err(logits2, z['logits']), helpers.rel_err(logits2, logits1)
+    print('GoogLeNet FP16 IR, blocked modules: logits {:.2e} from the reference float16 run, {:.2e} from the default mode'.format(err_ref, err_1))
+    assert np.isfinite(prob).all() and np.array_equal(logits2.argmax(axis=1), z['logits'].argmax(axis=1))
+    assert err_ref <= 1e-2, err_ref
+    assert err_1 <= 2e-3, err_1
+    # a second pass (fresh Concat buffers) gives the same bits
+    helpers.assert_bit_exact(helpers.infer_one(ex, net, images), prob, 'second pass')
 
 
 def test_infer_replays_a_hipgraph_by_itself_for_device_resident_inputs(hip, monkeypatch):

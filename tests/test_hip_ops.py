@@ -3,6 +3,7 @@ larger seeded shapes.  GPU only."""
 import importlib
 import os
 
+import ctypes
 import numpy as np
 import pytest
 
@@ -1269,6 +1270,84 @@ def test_conv_f16_c8_blocked_fp16_tensors_between_two_convolutions(hip):
         for dense_out, blocked_out, k, f in zip(outs[False], outs[True], ks, c8):
             assert dense_out.shape == blocked_out.shape == (xs[0], k, xs[2], xs[3])
             assert_bit_exact(blocked_out, f16r(dense_out) if f else dense_out, 'sibling member with {} channels, c8 {}'.format(k, f))
+
+
+def test_conv_f16_c8_module_form_blocked_in_blocked_out(hip):
+    """FP16 IRs, second step: pvhip_conv2d_f16_c8_multi reads AND writes fp16 blocked by eight channels.  Each output against the oracle
+    on fp16-rounded operands, rounded to fp16 where the destination is blocked (2e-3: one fp16 rounding of a 1e-5-accurate value), 1e-5
+    where it is fp32: (1) the 1x1 arms of a module as one launch -- a range of a blocked Concat buffer, blocked tensors of their own
+    (channel counts that are not multiples of 16 or 32), an fp32 tensor beside them; (2) 3x3 / 5x5 into a blocked Concat range; (3) MaxPool
+    3x3 / 1 / 1 + 1x1 (odd widths too) against the MaxPool plugin followed by the convolution; channel counts whose last stage of four
+    16-channel steps is partly empty (480, 528); (4) pvhip_maxpool3x3_c8 against the MaxPool plugin: strides, ceil / floor, padding, NaN."""
+    from pyopenvino_amd import device as dev
+    plugin, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
+
+    def oracle_conv(x, w, b, pad):
+        node = make_node('Convolution', [x, w], conv_data((1, 1), (pad, pad), (pad, pad)))
+        return np.maximum(first_out(oracle_plugin('Convolution').compute(node, {0: f16r(x), 1: f16r(w)}, kernel_type='special')) + b, 0).astype(np.float32)
+
+    # (1) several 1x1 members
+    for xs, ks in [((3, 192, 28, 28), (64, 96, 16)), ((2, 480, 14, 14), (192, 96, 16)), ((2, 528, 14, 14), (256, 160, 32)), ((5, 832, 7, 7), (384, 192, 48)),
+                   ((1, 64, 56, 56), (64,)), ((2, 40, 6, 10), (24, 8, 40))]:
+        x = rnd(11, xs)
+        xb = dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))
+        ws = [rnd(20 + i, (k, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5) for i, k in enumerate(ks)]
+        bs = [rnd(40 + i, (1, k, 1, 1), 0.1) for i, k in enumerate(ks)]
+        ctot = -(-(ks[0] + 24) // 16) * 16
+        cat = dev.BlockedHalf((xs[0], ctot, xs[2], xs[3]))
+        dev.call('pvhip_memset', ctypes.c_void_p(cat.ptr), 0, cat.buf.nbytes)
+        # the first member: a range of a blocked Concat buffer; the second: a blocked tensor of its own; the third: an fp32 tensor of its own
+        members = [(dev.DeviceTensor.from_numpy(ws[i]), dev.DeviceTensor.from_numpy(bs[i]), (cat, 8) if i == 0 else None, i == 1) for i in range(len(ks))]
+        node = {}
+        outs = plugin.launch_c8_multi(node, xb, members, act=('relu',))
+        assert 'c8 module' in node['_hip_f16']
+        got_cat = np.asarray(cat)
+        assert np.all(got_cat[:, :8] == 0) and np.all(got_cat[:, 8 + ks[0]:] == 0)
+        for i, (o, w, b) in enumerate(zip(outs, ws, bs)):
+            want = oracle_conv(x, w, b, 0)
+            blocked_out = isinstance(o, (dev.BlockedHalf, dev.BlockedChannelSlice))
+            assert blocked_out == (i < 2)
+            got = np.asarray(o)
+            assert got.shape == want.shape
+            if blocked_out:
+                assert_bit_exact(got, f16r(got), 'a blocked output holds fp16 values')
+                assert_close(got, want, 2e-3, 'module form, 1x1 member {} of {} {}'.format(i, xs, ks), elementwise=False)
+            else:
+                assert_close(got, want, 1e-5, 'module form, fp32 member {} of {} {}'.format(i, xs, ks))
+    # (2) windows into a blocked Concat range, (3) the pooled 1x1
+    for xs, k, kk, pooled in [((2, 96, 28, 28), 128, 3, False), ((1, 64, 56, 56), 192, 3, False), ((2, 16, 28, 28), 32, 5, False), ((2, 24, 14, 14), 64, 5, False),
+                              ((2, 192, 7, 7), 384, 3, False), ((1, 160, 14, 14), 320, 3, False), ((3, 192, 28, 28), 32, 1, True), ((2, 480, 14, 14), 64, 1, True),
+                              ((2, 832, 7, 7), 128, 1, True), ((1, 48, 5, 9), 24, 1, True)]:
+        pad = (kk - 1) // 2
+        x = rnd(7, xs)
+        xb = dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))
+        w, b = rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5), rnd(3, (1, k, 1, 1), 0.1)
+        cat = dev.BlockedHalf((xs[0], k + 24, xs[2], xs[3])) if (k + 24) % 16 == 0 else dev.BlockedHalf((xs[0], k + 32, xs[2], xs[3]))
+        dev.call('pvhip_memset', ctypes.c_void_p(cat.ptr), 0, cat.buf.nbytes)
+        node = {}
+        (o,) = plugin.launch_c8_multi(node, xb, [(dev.DeviceTensor.from_numpy(w), dev.DeviceTensor.from_numpy(b), (cat, 16), False)], pool=pooled, act=('relu',))
+        src = f16r(x)
+        if pooled:
+            pnode = make_node('MaxPool', [src], pool_data((3, 3), (1, 1), (1, 1), (1, 1), 'ceil'))
+            pnode['output'][1]['dims'] = tuple(xs)
+            src = np.asarray(pool.compute(pnode, {0: src})[1])
+        want = oracle_conv(src, w, b, pad)
+        got = np.asarray(cat)
+        assert np.all(got[:, :16] == 0) and np.all(got[:, 16 + k:] == 0)
+        assert_close(np.ascontiguousarray(got[:, 16:16 + k]), want, 2e-3, 'module form {} k{} {}x{} pooled {}'.format(xs, k, kk, kk, pooled), elementwise=False)
+        assert_bit_exact(np.asarray(o), np.ascontiguousarray(got[:, 16:16 + k]), 'the slice object')
+    # (4) MaxPool on blocked tensors
+    for xs, st, pb, pe, rounding in [((2, 40, 28, 28), (2, 2), (0, 0), (0, 0), 'ceil'), ((1, 16, 14, 14), (2, 2), (0, 0), (0, 0), 'ceil'), ((2, 24, 7, 7), (1, 1), (1, 1), (1, 1), 'ceil'),
+                                     ((1, 8, 9, 12), (2, 3), (1, 0), (0, 2), 'floor'), ((1, 16, 6, 6), (2, 2), (1, 1), (1, 1), 'ceil')]:
+        x = f16r(rnd(5, xs))
+        if xs[1] == 24:
+            x[0, 3, 2, 2], x[1, 5, 0, 6] = np.nan, -np.nan
+        pnode = make_node('MaxPool', [x], pool_data((3, 3), st, pb, pe, rounding))
+        want = np.asarray(pool.compute(dict(pnode), {0: x})[1])
+        pnode['output'][1]['dims'] = want.shape
+        got = pool.compute(dict(pnode), {0: dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))})[1]
+        assert isinstance(got, dev.BlockedHalf) and got.shape == want.shape
+        assert_bit_exact(np.asarray(got), want, 'MaxPool on a blocked tensor {} stride {} pads {} {} {}'.format(xs, st, pb, pe, rounding))
 
 
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
