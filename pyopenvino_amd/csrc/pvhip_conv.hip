@@ -544,7 +544,6 @@ template <int BM, bool kRS, bool kPW = false, bool kValid = false, bool kF16 = f
 __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     static_assert(!kPW || kRS, "the pointwise copy uses the (r,s)-major panel");
     static_assert(!kValid || !kRS, "the test-free gather is the c-major one");
-    static_assert(!kF16 || kRS, "the f16 form takes whole 16-channel stages");
     constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
     constexpr int A_PIECES = kBK * BM * 4 / 1024;          // 1-KiB wave-instructions per weight tile
     constexpr int A_PER_WAVE = (A_PIECES + 3) / 4;
@@ -688,7 +687,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
     // c-major: the LAST stage is taken out of the loop.  Its rows past C*kh*kw are zero rows of the panel: only the k-steps that hold
     // a real row are multiplied (conv1 of GoogLeNet: 147 rows = 9 stages + 3 rows, 2 of the last stage's 8 k-steps -- 148 of 160
     // MFMA steps), and nothing is copied for a stage behind it.
-    const int nk_loop = kRS ? nk : nk - 1;
+    const int nk_loop = (kRS || kF16) ? nk : nk - 1;          // (the f16 form: a stage is ONE matrix instruction, nothing to skip)
     for (int kt = 0; kt < nk_loop; ++kt) {
         const int buf = kt & 1;
         if (kF16) {
@@ -736,7 +735,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_dma_kernel(ConvArgs a) {
         dma_wait_all();
         __syncthreads();
     }
-    if (!kRS) {
+    if (!kRS && !kF16) {
         const int buf   = (nk - 1) & 1;
         const int steps = min(KK, (a.C * nrs - (nk - 1) * kBK + 1) >> 1);     // k-steps of the last stage with a real reduction row
         for (int kk = 0; kk < steps; ++kk) {
@@ -1025,9 +1024,14 @@ void launch_conv(const ConvArgs& a, int n_ptiles) {
         const size_t dyn = (size_t)settings().conv_lds_pad_kb * 1024;     // tuning: extra dynamic LDS caps workgroups per CU
         const bool pw = rs_major(a.C, a.kh, a.kw) && a.kh == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 &&
                         a.OH == a.H && a.OW == a.W && (a.H * a.W) % 4 == 0 && !settings().conv_nopw;
-        if (kF16) {           // conv2d_impl sends only (r,s)-major layers here
+        if (kF16) {           // (r,s)-major layers, and c-major ones (conv1: C = 3) -- through the padding pass without a window test
             if (pw) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, true, false, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
-            else    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, false, false, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
+            else if (rs_major(a.C, a.kh, a.kw))
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, true, false, false, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
+            else if (a.pt == 0 && a.pl == 0 && (a.OH - 1) * a.sh + a.kh <= a.H && (a.OW - 1) * a.sw + a.kw <= a.W && !settings().conv_novalid)
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, false, false, true, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
+            else
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, false, false, false, true>), dim3(a.n_mtiles * n_ptiles), dim3(kBlock), dyn, state().stream, a);
             return;
         }
         if (pw)
@@ -1145,8 +1149,8 @@ static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int 
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
 
     if (f16) {      // pvhip_conv2d_f16_dma: every layer on the LDS-DMA kernel's f16 form (the matrix work is 16x cheaper: no Winograd, 64-channel tiles)
-        if (!rs_major(c, kh, kw) || !dma_enabled())
-            return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_dma: C %% 16 == 0 and a window of fewer than 64 taps required (C=%d, %dx%d)", c, kh, kw);
+        if (!(rs_major(c, kh, kw) || kh * kw < 64) || !dma_enabled())
+            return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_dma: C %% 16 == 0 or a window of fewer than 64 taps required (C=%d, %dx%d)", c, kh, kw);
         // the activation tile of a stage is re-read once per channel tile (through L2, which is what this form is bound by): wide tiles
         int bm = k_out > 64 ? 128 : (k_out > 32 ? 64 : 32);
         if (settings().f16_bm) bm = settings().f16_bm;          // PVHIP_CONV_F16_BM: tuning runs
@@ -1265,7 +1269,7 @@ int pvhip_conv2d_f32(const float* x, const float* wpack, float* y, int n, int c,
                        out_channels_total, act_lo, act_hi);
 }
 
-int pvhip_conv2d_f16_dma_supported(int c, int kh, int kw) { return (c > 0 && kh > 0 && kw > 0 && rs_major(c, kh, kw) && dma_enabled()) ? 1 : 0; }
+int pvhip_conv2d_f16_dma_supported(int c, int kh, int kw) { return (c > 0 && kh > 0 && kw > 0 && (rs_major(c, kh, kw) || kh * kw < 64) && dma_enabled()) ? 1 : 0; }
 
 int pvhip_conv2d_f16_dma(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh, int kw,
                          int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,

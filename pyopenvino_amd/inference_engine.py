@@ -622,7 +622,7 @@ class Executable_Network:
                     self._fused_away.add(src)
         # An Add of a per-INPUT-channel Const whose only consumer is a convolution that pads its input in a pass of its own (GoogLeNet:
         # data/mean -> conv1): the padding pass adds the constant on the way and the Add is not dispatched (same fp32 add: same bits).
-        if not f16 and getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False):
+        if getattr(conv_plugin, 'SUPPORTS_PRE_ADD', False):
             for cid in G.nodes:
                 if G.nodes[cid]['type'] != 'Convolution' or cid in self._pool_conv:
                     continue
@@ -634,7 +634,8 @@ class Executable_Network:
                 others = [p_ for p_ in preds if G.nodes[p_]['type'] != 'Const']
                 if len(preds) != 2 or len(consts) != 1 or len(others) != 1:
                     continue
-                if conv_plugin.pre_add_fusable(G.nodes[cid], G.nodes[src], G.nodes[consts[0]]):
+                if (conv_plugin.pre_add_fusable(G.nodes[cid], G.nodes[src], G.nodes[consts[0]], True) if f16
+                        else conv_plugin.pre_add_fusable(G.nodes[cid], G.nodes[src], G.nodes[consts[0]])):
                     self._pre_add[cid] = (src, consts[0], others[0])
                     self._fused_away.add(src)
         # Third peephole: fused convolution chains that read the SAME tensor with the same geometry and activation (the

@@ -257,12 +257,14 @@ def launch_c8_multi(node, xb, members, pool=False, act=None):
 def prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16=False) -> bool:
     """True for a padded layer that libpvhip runs on the c-major form of the LDS-DMA kernel (C % 16 != 0, not a Winograd or pointwise
     layer): its gather tests every tap against the window unless no window leaves the tensor (PVHIP_CONV_PREPAD=0: never)."""
-    if f16 or not dev.conv_prepad or c % 16 == 0 or not (any(pads_begin) or any(pads_end)) or oh <= 0 or ow <= 0 or kh * kw >= 64:
+    if not dev.conv_prepad or c % 16 == 0 or not (any(pads_begin) or any(pads_end)) or oh <= 0 or ow <= 0 or kh * kw >= 64:
         return False
+    if f16:         # FP16 IRs: the c-major f16 form of the LDS-DMA kernel (every such layer: there is no Winograd or pointwise form in front of it)
+        return dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
     return int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) == 0
 
 
-def pre_add_fusable(node: dict, add_node: dict, const_node: dict) -> bool:
+def pre_add_fusable(node: dict, add_node: dict, const_node: dict, f16: bool = False) -> bool:
     """True when this layer pads its input in a pass of its own (prepad_wanted) and the Add in front of it adds one fp32 constant per
     input channel: the padding pass then does the Add (IR attributes and port dims; no device needed)."""
     try:
@@ -276,7 +278,7 @@ def pre_add_fusable(node: dict, add_node: dict, const_node: dict) -> bool:
         if tuple(add_out) != tuple(xd) or not all(tuple(p_['dims']) in (tuple(xd), (1, int(xd[1]), 1, 1)) for p_ in add_node['input'].values()):
             return False
         oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
-        return prepad_wanted(int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3]), oh, ow, strides, pb, pe)
+        return prepad_wanted(int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3]), oh, ow, strides, pb, pe, f16)
     except (KeyError, ValueError, AssertionError, IndexError, TypeError):
         return False
 

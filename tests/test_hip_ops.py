@@ -1058,7 +1058,11 @@ def test_conv_f16_dma_form_vs_oracle_and_first_f16_kernel(hip, monkeypatch):
     cases = [((2, 16, 12, 12), 40, 3, (1, 1), (1, 1), (1, 1)), ((3, 64, 14, 14), 96, 1, (1, 1), (0, 0), (0, 0)),
              ((2, 32, 7, 7), 16, 1, (1, 1), (0, 0), (0, 0)), ((1, 48, 9, 11), 208, 3, (2, 2), (1, 1), (1, 1)),
              ((2, 16, 13, 13), 33, 5, (1, 1), (2, 2), (2, 2)), ((5, 32, 6, 6), 70, 7, (1, 1), (3, 3), (3, 3)),
-             ((1, 160, 7, 7), 320, 3, (1, 1), (1, 1), (1, 1)), ((2, 16, 28, 28), 32, 5, (1, 1), (2, 2), (2, 2))]
+             ((1, 160, 7, 7), 320, 3, (1, 1), (1, 1), (1, 1)), ((2, 16, 28, 28), 32, 5, (1, 1), (2, 2), (2, 2)),
+             # c-major (C % 16 != 0; round 4: GoogLeNet's conv1 as an FP16 layer): through the padding pass without a window test, with the
+             # window test where the plugin does not pad (no padding at all; PVHIP_CONV_PREPAD=0 below), reductions that end inside a stage
+             ((2, 3, 37, 37), 64, 7, (2, 2), (3, 3), (3, 3)), ((1, 3, 20, 20), 32, 3, (2, 2), (0, 0), (1, 1)), ((3, 20, 13, 11), 70, 3, (1, 1), (1, 1), (1, 1)),
+             ((2, 33, 9, 9), 5, 3, (1, 1), (0, 0), (0, 0)), ((2, 24, 10, 6), 40, 5, (1, 1), (2, 2), (2, 2))]
     for xs, k, kk, st, pb, pe in cases:
         x, w = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5)
         assert dev.call('pvhip_conv2d_f16_dma_supported', xs[1], kk, kk)
@@ -1077,7 +1081,19 @@ def test_conv_f16_dma_form_vs_oracle_and_first_f16_kernel(hip, monkeypatch):
         assert_close(outs['1'], outs['0'], 1e-5, 'f16 LDS-DMA form vs the first f16 kernel {} k{}'.format(xs, k))
     monkeypatch.delenv('PVHIP_CONV_F16_DMA', raising=False)
     dev.reload_settings()
-    assert not dev.call('pvhip_conv2d_f16_dma_supported', 3, 7, 7) and not dev.call('pvhip_conv2d_f16_dma_supported', 16, 8, 8)
+    assert dev.call('pvhip_conv2d_f16_dma_supported', 3, 7, 7) and not dev.call('pvhip_conv2d_f16_dma_supported', 3, 8, 8)
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_PREPAD', '0')          # the c-major form with its window test (no padding pass)
+    dev.reload_settings()
+    x, w = rnd(9, (2, 3, 21, 17)), rnd(10, (24, 3, 5, 5), 0.2)
+    node = make_node('Convolution', [x, w], conv_data((2, 1), (2, 2), (1, 2)))
+    node['_f16_mfma'] = True
+    got = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w})))
+    assert node['_hip_f16'] == 'lds-dma'
+    want = first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [x, w], conv_data((2, 1), (2, 2), (1, 2))), {0: f16r(x), 1: f16r(w)},
+                                                          kernel_type='special'))
+    assert_close(got, want, 1e-5, 'f16 LDS-DMA form, c-major with the window test')
+    monkeypatch.delenv('PVHIP_CONV_PREPAD', raising=False)
+    dev.reload_settings()
     x, w, b = np.abs(rnd(1, (2, 32, 10, 6))), rnd(2, (40, 32, 3, 3), 0.1), rnd(3, (1, 40, 1, 1), 0.3)
     node = make_node('Convolution', [x, w], conv_data((1, 1), (1, 1), (1, 1)))
     node['_f16_mfma'] = True
