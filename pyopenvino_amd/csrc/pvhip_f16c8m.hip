@@ -44,6 +44,7 @@ struct C8mArgs {
     int tm, n_mtiles, tiles_per_image, n_tiles;
     int R, rows, rows_pad, stride_sh;      // output rows per tile; LDS rows a stage needs / holds (a multiple of 64 >> stride_sh) per channel block; log2 of the LDS row length in pixels
     int n_ins, nbuf, stages;               // copy instructions per stage; stage buffers; stages per tile
+    int reg_copy;                          // producers copy through registers (global load + ds_write) instead of LDS-DMA
     int nprod;                             // producer waves: the copy instructions of a stage are dealt out to them (a wave issues one per ~200 cycles)
     unsigned x_bytes, wf_bytes;
     int   act;
@@ -142,6 +143,49 @@ __global__ __launch_bounds__(kMMaxThreads, (KS == 5 && NB == 4) ? 3 : 4) void co
             }
             ++s_i;
         };
+        if (a.reg_copy != 0) {
+            // The other copy path (PVHIP_CONV_F16_C8_REG=1, up to eight copy instructions per wave and stage): global -> registers ->
+            // ds_write_b128.  Loads of stage s + 1 fly while the consumers work on stage s, the writes go to the other buffer before
+            // B(s + 1).  Ordinary loads leave a wave faster than LDS-DMA instructions do; they hold registers and lgkm slots instead.
+            constexpr int MAXI = 8;
+            uint4v regs[MAXI];
+            auto load_stage = [&](int st) {
+#pragma unroll
+                for (int i = 0; i < MAXI; ++i) {
+                    const int  k    = pw + i * a.nprod;
+                    const int  kc   = k < a.n_ins ? k : 0;
+                    const int  b    = kc / q_n, q = kc - b * q_n;
+                    const int  gb   = st * BLK + b;
+                    const bool bok  = gb < a.CB && k < a.n_ins;
+                    const unsigned plane = (unsigned)((img * a.CB + (bok ? gb : 0)) * HW);
+                    const int  rr = q * rpi + lrow;
+                    const int  iy = iy0 + rr;
+                    const bool ok = bok && colok && rr < a.rows && iy >= 0 && iy < a.H;
+                    const unsigned vo = ok ? (plane + (unsigned)(iy * a.W + x)) * 16u : kOob;
+                    regs[i] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0u, 0));
+                }
+            };
+            auto write_stage = [&](int st) {
+                char* const dst = c8m_lds + (unsigned)(st % a.nbuf) * buf_bytes + (unsigned)lane * 16u;
+#pragma unroll
+                for (int i = 0; i < MAXI; ++i) {
+                    const int k = pw + i * a.nprod;
+                    if (k < a.n_ins) {
+                        const int b = k / q_n, q = k - b * q_n;
+                        *reinterpret_cast<uint4v*>(dst + (unsigned)b * blk_bytes + (unsigned)q * 1024u) = regs[i];
+                    }
+                }
+            };
+            load_stage(0);
+            write_stage(0);
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) load_stage(s + 1);
+                __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's LDS writes of stage s are done
+                asm volatile("s_barrier" ::: "memory");              // B(s)
+                if (s + 1 < S) write_stage(s + 1);
+            }
+            return;
+        }
         while (s_i < S && s_i < a.nbuf) issue_next();
         for (int s = 0; s < S; ++s) {
             c8m_wait_vmcnt((s_i - s - 1) * mine);
@@ -424,12 +468,14 @@ int pvhip_conv2d_f16_c8_multi(const void* xb, const float* wf, int n, int c, int
     if (nbuf > kMMaxBuf) nbuf = kMMaxBuf;
     if (nbuf > a.stages) nbuf = a.stages;
     if (nbuf < 1) nbuf = 1;
+    if (settings().f16_c8_reg != 0 && nbuf < 2) nbuf = 2;
     {
         const int knob = settings().f16_c8_prod;                                // PVHIP_CONV_F16_C8_PROD=1..4 (tuning runs); default: ~3 copy instructions per wave and stage
         int np = knob > 0 ? knob : (a.n_ins + 2) / 3;                           // (GoogLeNet at batch 256, 1x1 family: one producer 1.51 ms, by sixes 1.08, four 0.98)
         a.nprod = np < 1 ? 1 : (np > 4 ? 4 : np);
     }
     const int per_wave = (a.n_ins + a.nprod - 1) / a.nprod;
+    a.reg_copy = (settings().f16_c8_reg != 0 && per_wave <= 8) ? 1 : 0;
     if ((nbuf - 1) * per_wave > 62) nbuf = 62 / per_wave + 1;
     if (stage * nbuf > 64 * 1024) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_c8_multi: a stage of %zu bytes does not fit", stage);
     a.nbuf = nbuf;
