@@ -443,6 +443,167 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_kernel(LrnPoolArgs a, F
 #undef PV_PUSH_EMIT
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LRN + MaxPool 3x3 / stride 2 / no padding, WITHOUT A BARRIER (round 4; GoogLeNet's conv2/norm2 -> pool2/3x3_s2).  The workgroup form
+// above spends a third of its time in its pooling phase and 0.076 of its 0.184 ms in the loop and its two barriers per eight channels
+// (scripts/time_lrnpool_abl.py); its loads alone take 0.112 ms.  Here a WAVE is the unit: it owns four pooled rows of one image and a
+// group of channels, i.e. nine input rows of W pixels as W / 8 lanes per row with eight adjacent pixels each (W = 56: 63 lanes), walks
+// the channel axis in steps of four (the five-channel window in registers, squares summed in ascending channel order: the arithmetic of
+// lrn_window_kernel -- the same bits), leaves four normalised planes in ITS OWN 8 KB of LDS, and pools them itself: a lane owns two
+// adjacent outputs of a row, whose windows are five columns of three rows = three 16-byte and three 4-byte LDS reads instead of
+// eighteen.  LDS executes a wave's instructions in order: no barrier, no counter, the other waves of the workgroup are strangers.
+// The channel groups overlap by the window's reach (two channels each side: 52 loads per 48 channels).
+// MEASURED, NOT THE DEFAULT (PVHIP_LRNPOOL_WAVE=1): 0.180 ms against 0.171 for the workgroup form on the same box, the same bits (scripts/
+// time_lrnpool.py) -- 140 registers (three waves per SIMD) and ~20 issue slots of LRN arithmetic per element: the barriers were not it.
+struct LrnPoolWaveArgs {
+    const float* x;
+    float*       y;
+    int   n, c, h, w, oh, ow;
+    int   R, n_bands, rows_in;     // pooled rows per wave, bands per image, input rows of a band (2 R + 1)
+    int   cg, n_groups;            // channels per wave (a multiple of four), groups per image
+    int   lpr, op;                 // lanes per input row (w / 8); output pairs per pooled row (ceil(ow / 2))
+    long  n_items;
+    float alpha, beta, bias;
+};
+
+template <int BETA_MODE>
+__global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_wave_kernel(LrnPoolWaveArgs a) {
+    constexpr int T = 4;
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    struct V8 { vec4 lo, hi; };
+    extern __shared__ __attribute__((aligned(16))) float wave_planes[];              // [4 waves][T][rows_in][w]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid  = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const long item = (long)blockIdx.x * (kBlock / kWave) + wid;
+    if (item >= a.n_items) return;
+    // item -> (image, band, channel group): the groups of a band back to back (they share the input rows' neighbourhood in L2)
+    const int g    = (int)(item % a.n_groups);
+    const long ib  = item / a.n_groups;
+    const int band = (int)(ib % a.n_bands), img = (int)(ib / a.n_bands);
+    const int oy0  = band * a.R;
+    const int iy0  = 2 * oy0;
+    const int c0   = g * a.cg;
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+    const int plane_l = a.rows_in * a.w;
+    float* const lds = wave_planes + (size_t)wid * T * plane_l;
+
+    // ---- load side: lane -> (input row of the band, eight columns)
+    const int  lrow = lane / a.lpr, lcol = (lane - lrow * a.lpr) * 8;
+    const bool lact = lrow < a.rows_in && iy0 + lrow < a.h;               // a row past the image: zeros (never pooled: the windows are clipped)
+    const float* const xl = a.x + (size_t)img * a.c * hw + (size_t)(lact ? (iy0 + lrow) * a.w + lcol : 0);
+    float* const lmine = lds + lrow * a.w + lcol;
+    const bool lwrite = lrow < a.rows_in;
+
+    // ---- pool side: lane -> (pooled row of the band, two adjacent outputs)
+    const int  prow = lane / a.op, pj = lane - prow * a.op;
+    const int  oy = oy0 + prow, ox = 2 * pj;
+    const bool pact = prow < a.R && oy < a.oh && ox < a.ow;
+    const bool second = ox + 1 < a.ow;
+    // window rows 2 prow + k (clipped at the image: a row past it repeats the first), columns 4 pj .. 4 pj + 4 (the fifth may be past the row)
+    unsigned roff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int r = 2 * prow + k;
+        roff[k] = (unsigned)(((pact && iy0 + r < a.h) ? r : 2 * (pact ? prow : 0)) * a.w + 4 * (pact ? pj : 0));
+    }
+    const bool col4 = 4 * pj + 4 < a.w;                                   // the fifth column exists
+    float* const yout = a.y + ((size_t)img * a.c) * ohw + (size_t)(pact ? oy * a.ow + ox : 0);
+
+    auto load8 = [&](int ch) -> V8 {
+        V8 v;
+        if (lact && ch >= 0 && ch < a.c) {
+            const vec4* p = reinterpret_cast<const vec4*>(xl + (size_t)ch * hw);
+            v.lo = ldnt(p); v.hi = ldnt(p + 1);
+        } else {
+            v.lo = (vec4)(0.0f); v.hi = (vec4)(0.0f);
+        }
+        return v;
+    };
+    V8 win[5], nxt[T];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { win[q].lo = (vec4)(0.0f); win[q].hi = (vec4)(0.0f); }
+    const int n_chunks = a.cg / T + 1;                                    // incoming chunks of four channels: c0 - 2 + 4 i ..; chunk i >= 1 completes channels c0 + 4 (i - 1) ..
+#pragma unroll
+    for (int j = 0; j < T; ++j) nxt[j] = load8(c0 - 2 + j);
+    for (int i = 0; i < n_chunks; ++i) {
+        V8 cur[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) cur[j] = nxt[j];
+        if (i + 1 < n_chunks) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) nxt[j] = load8(c0 - 2 + T * (i + 1) + j);
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            // channel c0 - 2 + 4 i + j enters the window; the window is then centred on the channel two below it
+#pragma unroll
+            for (int q = 0; q < 4; ++q) win[q] = win[q + 1];
+            win[4] = cur[j];
+            if (i >= 1) {
+                vec4 slo = win[0].lo * win[0].lo, shi = win[0].hi * win[0].hi;
+#pragma unroll
+                for (int q = 1; q < 5; ++q) { slo = slo + win[q].lo * win[q].lo; shi = shi + win[q].hi * win[q].hi; }
+                vec4 olo, ohi;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    olo[v] = lrn_div(win[2].lo[v], a.bias + a.alpha * slo[v], a.beta, BETA_MODE);
+                    ohi[v] = lrn_div(win[2].hi[v], a.bias + a.alpha * shi[v], a.beta, BETA_MODE);
+                }
+                if (lwrite) {
+                    *reinterpret_cast<vec4*>(lmine + j * plane_l) = olo;
+                    *reinterpret_cast<vec4*>(lmine + j * plane_l + 4) = ohi;
+                }
+            }
+        }
+        if (i == 0) continue;
+        __builtin_amdgcn_wave_barrier();                                  // (a scheduling fence: LDS runs this wave's writes before its reads)
+        const int ch0 = c0 + T * (i - 1);
+        if (pact) {
+#pragma unroll
+            for (int p = 0; p < T; ++p) {
+                const float* const pl = lds + p * plane_l;
+                float m0[3], m1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const vec4  v  = *reinterpret_cast<const vec4*>(pl + roff[k]);
+                    const float v4 = col4 ? pl[roff[k] + 4] : v[3];
+                    m0[k] = max3_nan(v[0], v[1], v[2]);
+                    m1[k] = max3_nan(v[2], v[3], v4);
+                }
+                const float r0 = max3_nan(m0[0], m0[1], m0[2]), r1 = max3_nan(m1[0], m1[1], m1[2]);
+                float* const yo = yout + (size_t)(ch0 + p) * ohw;
+                if (second && (a.ow & 1) == 0) *reinterpret_cast<float2*>(yo) = make_float2(r0, r1);
+                else { yo[0] = r0; if (second) yo[1] = r1; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Geometry of the wave form, or false when the pair is outside it (then the workgroup form above is asked).
+bool plan_lrn_pool_wave(int n, int c, int h, int w, int size, float beta, float bias, int oh, int ow, int kh, int kw, int sh, int sw, int pt, int pl,
+                        int pb, int pr, LrnPoolWaveArgs& a, int& bm) {
+    if (n <= 0 || c < 8 || c % 4 != 0 || h < 3 || w < 8 || w % 8 != 0 || oh <= 0 || ow <= 0) return false;
+    if (size != 5 || kh != 3 || kw != 3 || sh != 2 || sw != 2 || pt != 0 || pl != 0 || pb != 0 || pr != 0) return false;
+    if (2 * (oh - 1) > h - 1 || 2 * (ow - 1) > w - 1 || 2 * (ow - 1) + 2 > w) return false;      // the first cell of every window is in the image; at most the third column / row is clipped
+    if ((unsigned long long)n * c * h * w >= (1ull << 31)) return false;
+    bm = lrn_beta_mode(beta, bias);
+    if (bm != 4 && bm != 1) return false;
+    const int lpr = w / 8;
+    const int R = (kWave / lpr - 1) / 2;                  // rows_in = 2 R + 1 input rows in 64 lanes
+    const int op = (ow + 1) / 2;
+    if (R < 1 || R * op > kWave) return false;
+    int cg = 0;
+    for (int cand = 64; cand >= 16; cand -= 4)            // the largest group of at most 64 channels that divides C (48 for C = 192)
+        if (c % cand == 0) { cg = cand; break; }
+    if (cg == 0) return false;
+    a.n = n; a.c = c; a.h = h; a.w = w; a.oh = oh; a.ow = ow;
+    a.R = R; a.n_bands = (oh + R - 1) / R; a.rows_in = 2 * R + 1;
+    a.cg = cg; a.n_groups = c / cg; a.lpr = lpr; a.op = op;
+    a.n_items = (long)n * a.n_bands * a.n_groups;
+    return (size_t)4 * 4 * a.rows_in * w * sizeof(float) <= 64 * 1024;
+}
+
 // Geometry of the fused launch, or false when the pair is outside what lrn_maxpool3x3_kernel covers.
 bool plan_lrn_pool(int n, int c, int h, int w, int size, float beta, float bias, int oh, int ow, int kh, int kw, int sh, int sw,
                    int pt, int pl, int pb, int pr, LrnPoolArgs& a, int& vec, int& bm, size_t& lds) {
@@ -570,6 +731,22 @@ int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, 
                           int oh, int ow, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int pad_bottom,
                           int pad_right) {
     PVHIP_REQUIRE_INIT();
+    {
+        LrnPoolWaveArgs wa{};
+        int wbm = 0;
+        if (settings().lrnpool_wave && plan_lrn_pool_wave(n, c, h, w, size, beta, bias, oh, ow, kh, kw, sh, sw, pad_top, pad_left, pad_bottom, pad_right, wa, wbm)) {
+            PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+            wa.x = x; wa.y = y; wa.alpha = alpha; wa.beta = beta; wa.bias = bias;
+            const long blocks = (wa.n_items + kBlock / kWave - 1) / (kBlock / kWave);
+            if (blocks <= 0x7fffffffL) {
+                const size_t wlds = (size_t)(kBlock / kWave) * 4 * wa.rows_in * w * sizeof(float);
+                if (wbm == 4) hipLaunchKernelGGL((lrn_maxpool3x3_wave_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), wlds, state().stream, wa);
+                else          hipLaunchKernelGGL((lrn_maxpool3x3_wave_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), wlds, state().stream, wa);
+                PVHIP_LAUNCH_CHECK();
+                return PVHIP_OK;
+            }
+        }
+    }
     LrnPoolArgs a{};
     int vec = 0, bm = 0;
     size_t lds = 0;

@@ -14,11 +14,15 @@ y = dev.DeviceTensor.empty((n, c, oh, ow), np.float32)
 t = dev.DeviceTensor.empty((n, c, h, w), np.float32)
 y2 = dev.DeviceTensor.empty((n, c, oh, ow), np.float32)
 def fused():
-    dev.call("pvhip_lrn_maxpool_f32", _c.c_void_p(x.ptr), _c.c_void_p(y.ptr), n, c, h, w, 5, _c.c_float(1e-4 / 5 * 5), _c.c_float(0.75), _c.c_float(1.0), oh, ow, 3, 3, 2, 2, 0, 0, 1, 1)
+    dev.call("pvhip_lrn_maxpool_f32", _c.c_void_p(x.ptr), _c.c_void_p(y.ptr), n, c, h, w, 5, _c.c_float(1e-4 / 5 * 5), _c.c_float(0.75), _c.c_float(1.0), oh, ow, 3, 3, 2, 2, 0, 0, 0, 0)
+def fused_wg():
+    fused()
 def two():
     dev.call("pvhip_lrn_f32", _c.c_void_p(x.ptr), _c.c_void_p(t.ptr), n, c, h * w, 5, _c.c_float(1e-4 / 5 * 5), _c.c_float(0.75), _c.c_float(1.0))
-    dev.call("pvhip_maxpool2d_f32", _c.c_void_p(t.ptr), _c.c_void_p(y2.ptr), n, c, h, w, oh, ow, 3, 3, 2, 2, 0, 0, 1, 1)
-for name, f in (('one launch', fused), ('two launches', two)):
+    dev.call("pvhip_maxpool2d_f32", _c.c_void_p(t.ptr), _c.c_void_p(y2.ptr), n, c, h, w, oh, ow, 3, 3, 2, 2, 0, 0, 0, 0)
+for name, f in (('wave form', fused), ('workgroup form', fused_wg), ('two launches', two), ('wave form', fused)):
+    os.environ['PVHIP_LRNPOOL_WAVE'] = '1' if name == 'wave form' else '0'
+    dev.reload_settings()
     for _ in range(3):
         f()
     dev.synchronize()
@@ -28,6 +32,6 @@ for name, f in (('one launch', fused), ('two launches', two)):
     e1 = dev.Event().record(); e1.synchronize()
     ms = e0.elapsed_ms(e1) / 10
     mb = (x.nbytes + y.nbytes) / 1e6
-    print('{:13s} {:.3f} ms  {:.0f} GB/s of input + output'.format(name, ms, mb / ms))
+    print('{:15s} {:.3f} ms  {:.0f} GB/s of input + output'.format(name, ms, mb / ms))
 a, b = np.asarray(y), np.asarray(y2)
 print('same bits:', bool((a.view(np.uint32) == b.view(np.uint32)).all()))
