@@ -814,6 +814,23 @@ def test_fused_lrn_maxpool_has_the_bits_of_the_two_launches(hip, xs, st, pb, pe,
     got = first_out(lrn_plugin.compute(fused_node, {0: x, 1: axes}))
     assert_close(got, want, helpers.REL_TOL, 'fused LRN+MaxPool {}'.format(xs))
     assert_bit_exact(got, two, 'fused LRN+MaxPool vs two launches {}'.format(xs))
+    if tuple(st) == (2, 2) and tuple(pb) == (0, 0) and tuple(pe) == (0, 0) and xs[3] % 8 == 0:
+        # the barrier-free wave form (opt-in: measured no faster), where it applies: the same bits (floor rounding and NaNs included below)
+        from pyopenvino_amd import device as dev
+        os.environ['PVHIP_LRNPOOL_WAVE'] = '1'
+        try:
+            dev.reload_settings()
+            for xv, rnd_mode in ((x, rounding), (np.where(rnd(5, xs) > 2.2, np.nan, x).astype(np.float32), 'floor')):
+                pn = make_node('MaxPool', [xv], pool_data((3, 3), st, pb, pe, rnd_mode))
+                ref_a = lrn_plugin.compute(dict(make_node('LRN', [xv, axes], lrn_data)), {0: xv, 1: axes})[2]
+                ref = first_out(hip_plugin('MaxPool').compute(pn, {0: ref_a}))
+                pn['output'][1]['dims'] = tuple(ref.shape)
+                fn = dict(make_node('LRN', [xv, axes], lrn_data))
+                fn['_fuse_pool'] = pn
+                assert_bit_exact(first_out(lrn_plugin.compute(fn, {0: xv, 1: axes})), ref, 'wave form {} {}'.format(xs, rnd_mode))
+        finally:
+            del os.environ['PVHIP_LRNPOOL_WAVE']
+            dev.reload_settings()
 
 
 @pytest.mark.parametrize('xs,st,pb,pe,rounding', [((2, 64, 112, 112), (2, 2), (0, 0), (0, 0), 'ceil'),     # GoogLeNet pool1 -> norm1
