@@ -314,6 +314,15 @@ int    pvhip_conv2d_f16_c8_multi(const void* xb, const float* wf, int n, int c, 
                                  int n_dest, const pvhip_conv_dest* dests);
 int    pvhip_maxpool3x3_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
                            int pad_top, int pad_left, int pad_bottom, int pad_right);
+/* The stem of an FP16 IR on blocked fp16 tensors (ABI v14): pvhip_conv2d_f16_dma_c8 = pvhip_conv2d_f16_dma with the output stored as fp16 c8
+ * ([n][ceil16(k_out) / 8][oh * ow][8]; act none or ReLU); pvhip_maxpool3x3_lrn_c8 = MaxPool 3x3 (MaxPool.py:41-72) followed by LRN over
+ * five channels (LRN.py:10-22) on a c8 tensor as one launch, c8 output.                                                            */
+int    pvhip_conv2d_f16_dma_c8(const float* x, const float* wpack, void* yb,
+                               int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
+                               int sh, int sw, int pad_top, int pad_left, const float* bias, int act);
+int    pvhip_maxpool3x3_lrn_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
+                               int pad_top, int pad_left, int pad_bottom, int pad_right,
+                               int size, float alpha, float beta, float bias);
 int    pvhip_conv2d_f16_c8(const void* xb, const float* wf, float* y,
                            int n, int c, int h, int w, int k_out, int kh, int kw,
                            const float* bias, int act,

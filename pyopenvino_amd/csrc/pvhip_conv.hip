@@ -1113,7 +1113,7 @@ int pvhip_conv2d_pack_f32(const float* w_oihw, float* wpack, int k_out, int c, i
 
 static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int c, int h, int w, int k_out, int kh,
                        int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int relu,
-                       int out_channel_offset, int out_channels_total, float act_lo, float act_hi, bool f16 = false) {
+                       int out_channel_offset, int out_channels_total, float act_lo, float act_hi, bool f16 = false, bool c8_out = false) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && k_out > 0 && kh > 0 && kw > 0 && oh >= 0 && ow >= 0);
     PVHIP_CHECK_ARG(sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0);
@@ -1145,6 +1145,11 @@ static int conv2d_impl(const float* x, const float* wpack, float* y, int n, int 
     a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
     a.nseg     = 0;
+    if (c8_out) {        // pvhip_conv2d_f16_dma_c8: the output as fp16 blocked by eight channels (one range: the whole panel)
+        PVHIP_CHECK_ARG(f16 && out_channels_total == 0 && (relu == 0 || relu == 1));
+        a.nseg = 1;
+        a.seg[0].y = y; a.seg[0].m_begin = 0; a.seg[0].k = k_out; a.seg[0].ctotal = k_out; a.seg[0].coff = 0; a.seg[0].layout = 1;
+    }
 
     a.wp_bytes = (unsigned)((size_t)(a.kred_pad + kPanelSpare) * a.kout_pad * sizeof(float));
 
@@ -1276,6 +1281,12 @@ int pvhip_conv2d_f16_dma(const float* x, const float* wpack, float* y, int n, in
                          int out_channel_offset, int out_channels_total, float act_lo, float act_hi) {
     return conv2d_impl(x, wpack, y, n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, relu, out_channel_offset,
                        out_channels_total, act_lo, act_hi, true);
+}
+
+int pvhip_conv2d_f16_dma_c8(const float* x, const float* wpack, void* yb, int n, int c, int h, int w, int k_out, int kh, int kw,
+                            int oh, int ow, int sh, int sw, int pad_top, int pad_left, const float* bias, int act) {
+    return conv2d_impl(x, wpack, static_cast<float*>(yb), n, c, h, w, k_out, kh, kw, oh, ow, sh, sw, pad_top, pad_left, bias, act, 0, 0, 0.0f, 0.0f,
+                       true, true);
 }
 
 int pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow, int sh, int sw, int pad_top, int pad_left) {

@@ -373,6 +373,73 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_c8_kernel(const _Float16* _
     }
 }
 
+// MaxPool 3x3 followed by LRN over five channels (MaxPool.py:41-72 then LRN.py:10-22; GoogLeNet's pool1/3x3_s2 -> pool1/norm1) on fp16 c8
+// tensors, one launch: a lane owns one output pixel and walks the channel blocks -- nine 16-byte loads and the NaN-propagating maxima per
+// block (the pooled tensor never exists), the pooled values of three consecutive blocks in registers as fp32, because the window of
+// channel 8 b + q reaches two channels into the neighbour blocks; squares summed in ascending channel order, d^-beta as in lrn_div.
+template <int BETA_MODE>
+__global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_c8_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int n, int cb, int c, int h, int w,
+                                                                   int oh, int ow, int sh, int sw, int pt, int pl, int hp, int wp, float alpha,
+                                                                   float beta, float bias) {
+    const size_t total = (size_t)n * oh * ow;
+    const half8 zero = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(e % ow);
+        const size_t f = e / ow;
+        const int oy = (int)(f % oh), im = (int)(f / oh);
+        // the nine cells of the window: offsets inside a plane, or -1 for a zero cell of the padding; a cell past the padded edge repeats the first
+        int off[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                const int py = oy * sh + r, px = ox * sw + s2;
+                const bool inwin = py < hp && px < wp;
+                const int cy = (inwin ? py : oy * sh) - pt, cx = (inwin ? px : ox * sw) - pl;
+                off[3 * r + s2] = (cy >= 0 && cy < h && cx >= 0 && cx < w) ? cy * w + cx : -1;
+            }
+        const half8* const xi = reinterpret_cast<const half8*>(x) + (size_t)im * cb * (h * w);
+        half8* const yo = reinterpret_cast<half8*>(y) + (size_t)im * cb * (oh * ow) + (size_t)oy * ow + ox;
+        auto pooled = [&](int b, float (&dst)[8]) {
+            if (b < 0 || b >= cb) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dst[q] = 0.0f;
+                return;
+            }
+            const half8* const xp = xi + (size_t)b * (h * w);
+            half8 v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = off[t] >= 0 ? xp[off[t]] : zero;
+            const half8 m = pk_max3_nan(pk_max3_nan(v[0], v[1], v[2]), pk_max3_nan(v[3], v[4], v[5]), pk_max3_nan(v[6], v[7], v[8]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = (8 * b + q < c) ? (float)m[q] : 0.0f;
+        };
+        float prev[8], cur[8], nxt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) prev[q] = 0.0f;
+        pooled(0, cur);
+        for (int b = 0; b < cb; ++b) {
+            pooled(b + 1, nxt);
+            float ext[12];                        // channels 8 b - 2 .. 8 b + 9
+            ext[0] = prev[6]; ext[1] = prev[7];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ext[2 + q] = cur[q];
+            ext[10] = nxt[0]; ext[11] = nxt[1];
+            half8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s_ = ext[q] * ext[q];
+#pragma unroll
+                for (int t = 1; t < 5; ++t) s_ = s_ + ext[q + t] * ext[q + t];
+                o[q] = (_Float16)lrn_div(ext[q + 2], bias + alpha * s_, beta, BETA_MODE);
+            }
+            yo[(size_t)b * (oh * ow)] = o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { prev[q] = cur[q]; cur[q] = nxt[q]; }
+        }
+    }
+}
+
 inline int c8m_blocks(int c) { return (c + 15) / 16 * 2; }
 inline int c8m_mtiles(int k) { return (k + 127) / 128; }
 inline int c8m_tm(int k) { const int t32 = (k + 31) / 32, nm = c8m_mtiles(k); return (t32 + nm - 1) / nm; }
@@ -507,6 +574,32 @@ int pvhip_maxpool3x3_c8(const void* x, void* y, int n, int c, int h, int w, int 
     const size_t total = (size_t)n * cb * oh * ow;
     hipLaunchKernelGGL(maxpool3x3_c8_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, static_cast<const _Float16*>(x),
                        static_cast<_Float16*>(y), n, cb, h, w, oh, ow, sh, sw, pad_top, pad_left, hp, wp);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_maxpool3x3_lrn_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
+                            int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha, float beta, float bias) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 && pad_right >= 0);
+    if (size != 5) return fail(PVHIP_EUNSUPPORTED, "pvhip_maxpool3x3_lrn_c8: a window of five channels");
+    const int hp = h + pad_top + pad_bottom, wp = w + pad_left + pad_right;
+    PVHIP_CHECK_ARG((oh - 1) * sh < hp && (ow - 1) * sw < wp);
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+    const int cb = c8m_blocks(c);
+    const int bm = lrn_beta_mode(beta, bias);
+    const size_t total = (size_t)n * oh * ow;
+#define PVM_PL(BM_) hipLaunchKernelGGL((maxpool3x3_lrn_c8_kernel<BM_>), dim3(grid_for(total)), dim3(kBlock), 0, state().stream, static_cast<const _Float16*>(x), \
+                                       static_cast<_Float16*>(y), n, cb, c, h, w, oh, ow, sh, sw, pad_top, pad_left, hp, wp, alpha, beta, bias)
+    switch (bm) {
+        case 4: PVM_PL(4); break;
+        case 1: PVM_PL(1); break;
+        case 2: PVM_PL(2); break;
+        case 3: PVM_PL(3); break;
+        default: PVM_PL(0); break;
+    }
+#undef PVM_PL
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

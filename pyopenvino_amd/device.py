@@ -98,6 +98,8 @@ SIGNATURES = {
     'pvhip_conv2d_f16_c8_multi_supported': (_c.c_int, [_c.c_int] * 7),
     'pvhip_conv2d_f16_c8_multi': (_c.c_int, [_c.c_void_p, _fp] + [_c.c_int] * 7 + [_fp, _c.c_int, _c.c_float, _c.c_float, _c.c_int, _c.c_void_p]),
     'pvhip_maxpool3x3_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 12),
+    'pvhip_maxpool3x3_lrn_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 13 + [_c.c_float] * 3),
+    'pvhip_conv2d_f16_dma_c8': (_c.c_int, [_fp, _fp, _c.c_void_p] + [_c.c_int] * 13 + [_fp, _c.c_int]),
     'pvhip_conv2d_f16_c8': (_c.c_int, [_c.c_void_p, _fp, _fp] + [_c.c_int] * 7 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),

@@ -680,6 +680,30 @@ class Executable_Network:
                     continue
                 if conv_plugin.c8_writer_ok(G.nodes[cid]) and conv_plugin.c8_reader_ok(G.nodes[rid]):
                     self._c8_out.add(cid)
+            # ... and the stem: a convolution whose only reader is a 3x3 MaxPool (with its LRN folded in: GoogLeNet's conv1 -> pool1 -> norm1)
+            # whose readers are convolutions that take a blocked input: the MaxPool plugin pools a blocked tensor as it is
+            if os.environ.get('PVHIP_CONV_F16_C8', '2') == '2' and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
+                for cid, f in self._fusion.items():
+                    if G.nodes[cid]['type'] != 'Convolution' or f['into'] is not None or cid in self._pool_conv or cid in self._siblings or cid in self._fused_away:
+                        continue
+                    if f['act'] is not None and f['act'][0] != 'relu':
+                        continue
+                    tail = f['relu'] if f['relu'] is not None else f['add']
+                    readers = list(G.successors(tail))
+                    if len(readers) != 1 or G.nodes[readers[0]]['type'] != 'MaxPool' or readers[0] in self._fused_away:
+                        continue
+                    pid = readers[0]
+                    if tuple(common_def.string_to_tuple(G.nodes[pid]['data']['kernel'])) != (3, 3):
+                        continue
+                    out_node = self._lrn_pool.get(pid, pid)          # the LRN folded into the MaxPool carries the tensor
+                    if out_node != pid and int(G.nodes[out_node]['data'].get('size', 0)) != 5:
+                        continue
+                    after = list(G.successors(out_node))
+                    if not after or not all(r in self._fusion and G.nodes[r]['type'] == 'Convolution' and conv_plugin.c8_module_member_ok(G.nodes[r]) and
+                                            (r in self._c8_out or r in self._siblings) for r in after):
+                        continue
+                    if conv_plugin.c8_writer_ok(G.nodes[cid]) or conv_plugin.c8_dma_writer_ok(G.nodes[cid]):
+                        self._c8_out.add(cid)
             if os.environ.get('PVHIP_CONV_F16_C8', '2') == '2' and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
                 self.plan_c8_modules(conv_plugin)
         self.order_for_locality()

@@ -283,7 +283,18 @@ def pre_add_fusable(node: dict, add_node: dict, const_node: dict, f16: bool = Fa
         return False
 
 
-def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, f16=False):
+def c8_dma_writer_ok(node: dict) -> bool:
+    """True when the f16 form of the LDS-DMA kernel runs this Convolution node and can therefore store its output as dev.BlockedHalf
+    (pvhip_conv2d_f16_dma_c8): any window of fewer than 64 taps or C % 16 == 0 (GoogLeNet's conv1)."""
+    try:
+        xd, wd = node['input'][0]['dims'], node['input'][1]['dims']
+        return len(xd) == 4 and len(wd) == 4 and wd[1] == xd[1] and dev.conv_f16_dma and \
+            bool(dev.call('pvhip_conv2d_f16_dma_supported', int(xd[1]), int(wd[2]), int(wd[3])))
+    except (KeyError, ValueError, AssertionError, IndexError):
+        return False
+
+
+def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=None, into=None, f16=False, out_c8=False):
     n, c, h, wd = x.shape
     kn, kc, kh, kw = w.shape
     if kc != c:
@@ -338,6 +349,13 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
             ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, int(coff), int(ctotal), act_lo, act_hi)
     if f16:
         node['_hip_f16'] = 'span' if f16_span else ('lds-dma' if f16_dma else 'gather')      # which f16 kernel ran (tests)
+    if out_c8 and f16_dma and into is None and act_code in (0, 1):
+        # FP16 IRs: the reader takes fp16 blocked by eight channels (a MaxPool (+ LRN) on blocked tensors in front of a convolution)
+        yb = dev.BlockedHalf((n, kn, oh, ow))
+        node['_hip_f16'] = 'lds-dma, blocked output'
+        dev.call('pvhip_conv2d_f16_dma_c8', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(yb.ptr), n, c, h, wd, kn, kh, kw, oh, ow,
+                 strides[0], strides[1], pads_begin[0], pads_begin[1], ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code)
+        return yb
     if f16_span:
         dev.call('pvhip_conv2d_f16_span', ctypes.c_void_p(x.ptr), ctypes.c_void_p(wpack.ptr), ctypes.c_void_p(target.ptr), *tail)
     elif f16_dma:
@@ -562,6 +580,8 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
                            'pvhip_conv2d_f16_c8_multi)'.format(node.get('name')))
     elif reader_path:
         y = launch_c8(node, inputs[0], w, bias=bias, act=node.get('_fuse_act'), into=into)
+    elif node.get('_f16_mfma') and node.get('_out_c8') and not siblings and not c8_writer_ok(node) and dev.conv_f16_dma:
+        y = launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=bias, act=node.get('_fuse_act'), into=node.get('_out_into'), f16=True, out_c8=True)
     elif node.get('_f16_mfma') and (siblings or node.get('_out_c8')) and dev.conv_f16_dma:
         members = [(w, bias, node.get('_out_into'), bool(node.get('_out_c8')))]
         for sib in siblings or ():

@@ -61,7 +61,8 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
     pads_end = common_def.string_to_tuple(attrs['pads_end'])
     kernel = common_def.string_to_tuple(attrs['kernel'])
-    blocked = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and tuple(kernel) == (3, 3) and node.get('_fuse_lrn') is None else None
+    lrn_in = node.get('_fuse_lrn')
+    blocked = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and tuple(kernel) == (3, 3) and (lrn_in is None or int(lrn_in['data']['size']) == 5) else None
     x = blocked if blocked is not None else dev.as_device(inputs[0])
     n, c, h, w = x.shape
     oh, ow = calc_output_shape((h, w), kernel, strides, pads_begin, pads_end, attrs['rounding_type'], attrs['auto_pad'])
@@ -73,6 +74,11 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         # FP16 IRs: the input is fp16 blocked by eight channels (dev.BlockedHalf, what the reference holds here is a float16 tensor):
         # pooled as it is, the output is blocked too
         yb = dev.BlockedHalf((n, c, oh, ow))
+        if lrn_in is not None:       # MaxPool + LRN as one launch, on the blocked tensor
+            la = lrn_in['data']
+            dev.call('pvhip_maxpool3x3_lrn_c8', ctypes.c_void_p(blocked.ptr), ctypes.c_void_p(yb.ptr), n, c, h, w, oh, ow, strides[0], strides[1],
+                     pads_begin[0], pads_begin[1], pads_end[0], pads_end[1], int(la['size']), float(la['alpha']), float(la['beta']), float(la['bias']))
+            return {common_def.first_output_port(node): yb}
         dev.call('pvhip_maxpool3x3_c8', ctypes.c_void_p(blocked.ptr), ctypes.c_void_p(yb.ptr), n, c, h, w, oh, ow, strides[0], strides[1],
                  pads_begin[0], pads_begin[1], pads_end[0], pads_end[1])
         return {common_def.first_output_port(node): yb}

@@ -1383,6 +1383,47 @@ def test_conv_f16_c8_module_form_blocked_in_blocked_out(hip):
         assert_bit_exact(np.asarray(got), want, 'MaxPool on a blocked tensor {} stride {} pads {} {} {}'.format(xs, st, pb, pe, rounding))
 
 
+def test_fp16_stem_on_blocked_tensors(hip):
+    """FP16 IRs: (1) a convolution on the f16 form of the LDS-DMA kernel stores its output as fp16 blocked by eight channels
+    (pvhip_conv2d_f16_dma_c8: node['_out_c8'] on a layer the 1x1 launch does not cover -- GoogLeNet's conv1, through the padding pass with
+    the per-channel constant): exactly the fp16 rounding of what the same launch stores as fp32; (2) MaxPool 3x3 + LRN on a blocked tensor
+    as one launch (pvhip_maxpool3x3_lrn_c8) against the fp32 launch on the same fp16 values: one fp16 rounding of the output (1e-3),
+    channel counts that are not multiples of 8 or 16, strides, padding, ceil / floor, a NaN."""
+    from pyopenvino_amd import device as dev
+    plugin, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
+    for xs, k, kk, st, pb, pe in [((2, 3, 37, 37), 64, 7, (2, 2), (3, 3), (3, 3)), ((1, 20, 13, 11), 24, 3, (1, 1), (1, 1), (1, 1)), ((2, 32, 9, 9), 40, 3, (2, 2), (0, 0), (1, 1))]:
+        x, w, b = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5), rnd(3, (1, k, 1, 1), 0.2)
+        outs = {}
+        for blocked in (False, True):
+            node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+            node['_f16_mfma'], node['_fuse_bias'], node['_fuse_act'], node['_out_c8'] = True, dev.DeviceTensor.from_numpy(b), ('relu',), blocked
+            if xs[1] == 3:
+                node['_pre_add'] = dev.DeviceTensor.from_numpy(np.array([-104.0, -117.0, -123.0], dtype=np.float32).reshape(1, 3, 1, 1))
+            y = next(iter(plugin.compute(node, {0: x, 1: w}).values()))
+            assert isinstance(y, dev.BlockedHalf) == blocked, node.get('_hip_f16')
+            outs[blocked] = np.asarray(y)
+        assert_bit_exact(outs[True], f16r(outs[False]), 'blocked output of the f16 LDS-DMA form {} k{}'.format(xs, k))
+    lrn_data = {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'}
+    axes = np.array([1], dtype=np.int64)
+    for xs, st, pb, pe, rounding in [((2, 64, 112, 112), (2, 2), (0, 0), (0, 0), 'ceil'), ((1, 20, 13, 11), (2, 2), (0, 0), (0, 0), 'ceil'),
+                                     ((3, 8, 9, 20), (1, 1), (1, 1), (1, 1), 'floor'), ((2, 40, 14, 14), (2, 2), (1, 0), (0, 1), 'floor')]:
+        x = f16r(rnd(sum(xs), xs, 40.0))
+        if xs[1] == 20:
+            x[0, 5, 4, 4] = np.nan
+        pnode = make_node('MaxPool', [x], pool_data((3, 3), st, pb, pe, rounding))
+        pooled = np.asarray(pool.compute(dict(pnode), {0: x})[1])
+        lnode = make_node('LRN', [pooled, axes], lrn_data)
+        want = np.asarray(hip_plugin('LRN').compute(dict(lnode), {0: pooled, 1: axes})[2])
+        fused = dict(pnode)
+        fused['output'] = {1: {'precision': 'FP32', 'dims': tuple(want.shape)}}
+        fused['_fuse_lrn'] = lnode
+        got = pool.compute(fused, {0: dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))})[1]
+        assert isinstance(got, dev.BlockedHalf) and got.shape == want.shape
+        g = np.asarray(got)
+        assert np.array_equal(np.isnan(g), np.isnan(want))
+        assert_close(np.nan_to_num(g), np.nan_to_num(want), 1e-3, 'MaxPool + LRN on a blocked tensor {}'.format(xs), elementwise=False)
+
+
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
     """The reference's own FP16 node fixture (resources/node_args_6.pickle, replayed as test_node_sample.py:1-16 does; cropped)
     in float16 as the reference computes it: the f16-MFMA result is within fp16 tolerance of the reference's float16 output
