@@ -323,6 +323,11 @@ int    pvhip_conv2d_f16_dma_c8(const float* x, const float* wpack, void* yb,
 int    pvhip_maxpool3x3_lrn_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
                                int pad_top, int pad_left, int pad_bottom, int pad_right,
                                int size, float alpha, float beta, float bias);
+/* ... and the other order: LRN over five channels followed by MaxPool 3x3 on a c8 tensor as one launch (LRN.py:10-22 then MaxPool.py:41-72;
+ * the LRN tensor never exists).  _supported: pooled rows per workgroup (0: outside the kernel).                                        */
+int    pvhip_lrn_maxpool3x3_c8_supported(int h, int w, int oh, int ow, int sh, int sw, int pad_top, int pad_left, int size);
+int    pvhip_lrn_maxpool3x3_c8(const void* x, void* y, int n, int c, int h, int w, int size, float alpha, float beta, float bias,
+                               int oh, int ow, int sh, int sw, int pad_top, int pad_left, int pad_bottom, int pad_right);
 int    pvhip_conv2d_f16_c8(const void* xb, const float* wf, float* y,
                            int n, int c, int h, int w, int k_out, int kh, int kw,
                            const float* bias, int act,

@@ -440,6 +440,94 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_c8_kernel(const _Float1
     }
 }
 
+// LRN over five channels followed by MaxPool 3x3 (LRN.py:10-22 then MaxPool.py:41-72; GoogLeNet's conv2/norm2 -> pool2/3x3_s2) on fp16 c8
+// tensors, one launch: the LRN tensor never exists.  A workgroup owns one image and a band of pooled rows, i.e. the input rows those
+// windows touch; a lane owns up to PPT pixels of the band and walks the channel blocks with the values of three consecutive blocks in
+// registers as fp32 (the window of channel 8 b + q reaches two channels into the neighbour blocks; squares summed in ascending channel
+// order), leaves the normalised block of its pixels in LDS as fp16 (16 bytes per pixel: the fp16 rounding the reference's float16 LRN
+// tensor has too), and after a barrier the workgroup pools the block: nine 16-byte LDS reads per output (a cell of the padding: zeros; a
+// cell past the padded edge repeats the first), a NaN wins.
+template <int BETA_MODE, int PPT>
+__global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_c8_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int n, int cb, int c, int h, int w,
+                                                                   int oh, int ow, int sh, int sw, int pt, int pl, int hp, int wp, int R, int n_bands,
+                                                                   float alpha, float beta, float bias) {
+    extern __shared__ __attribute__((aligned(16))) char lp_lds[];
+    half8* const tile = reinterpret_cast<half8*>(lp_lds);                // [band pixels]
+    const half8 zero = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    const int tid  = threadIdx.x;
+    const int img  = blockIdx.x / n_bands, band = blockIdx.x - img * n_bands;
+    const int oy0  = band * R, oy1 = min(oh, oy0 + R);
+    const int iy_lo = max(0, oy0 * sh - pt), iy_hi = min(h, (oy1 - 1) * sh + 3 - pt);
+    const int band_px = (iy_hi - iy_lo) * w;
+    const int hw = h * w, ohw = oh * ow;
+    const half8* const xi = reinterpret_cast<const half8*>(x) + (size_t)img * cb * hw + (size_t)iy_lo * w;
+    // ---- pooling geometry of this lane's output (one per lane: R * ow <= 256)
+    const int  oyl = tid / ow, ox = tid - oyl * ow;
+    const bool pact = oyl < oy1 - oy0;
+    int off[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int oy = oy0 + (pact ? oyl : 0), oxx = pact ? ox : 0;
+            const int py = oy * sh + r, px = oxx * sw + s2;
+            const bool inwin = py < hp && px < wp;
+            const int cy = (inwin ? py : oy * sh) - pt, cx = (inwin ? px : oxx * sw) - pl;
+            off[3 * r + s2] = (cy >= 0 && cy < h && cx >= 0 && cx < w) ? (cy - iy_lo) * w + cx : -1;
+        }
+    half8* const yo = reinterpret_cast<half8*>(y) + (size_t)img * cb * ohw + (size_t)(oy0 + (pact ? oyl : 0)) * ow + (pact ? ox : 0);
+
+    float prev[PPT][8], cur[PPT][8], nxt[PPT][8];
+    auto load_block = [&](int b, float (&dst)[PPT][8]) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = tid + i * kBlock;
+            half8 v = zero;
+            if (b < cb && p < band_px) v = xi[(size_t)b * hw + p];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[i][q] = (8 * b + q < c) ? (float)v[q] : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) prev[i][q] = 0.0f;
+    load_block(0, cur);
+    for (int b = 0; b < cb; ++b) {
+        load_block(b + 1, nxt);
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = tid + i * kBlock;
+            float ext[12];
+            ext[0] = prev[i][6]; ext[1] = prev[i][7];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ext[2 + q] = cur[i][q];
+            ext[10] = nxt[i][0]; ext[11] = nxt[i][1];
+            half8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s_ = ext[q] * ext[q];
+#pragma unroll
+                for (int t = 1; t < 5; ++t) s_ = s_ + ext[q + t] * ext[q + t];
+                o[q] = (_Float16)lrn_div(ext[q + 2], bias + alpha * s_, beta, BETA_MODE);
+            }
+            if (p < band_px) tile[p] = o;
+        }
+        __syncthreads();
+        if (pact) {
+            half8 v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = off[t] >= 0 ? tile[off[t]] : zero;
+            yo[(size_t)b * ohw] = pk_max3_nan(pk_max3_nan(v[0], v[1], v[2]), pk_max3_nan(v[3], v[4], v[5]), pk_max3_nan(v[6], v[7], v[8]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { prev[i][q] = cur[i][q]; cur[i][q] = nxt[i][q]; }
+    }
+}
+
 inline int c8m_blocks(int c) { return (c + 15) / 16 * 2; }
 inline int c8m_mtiles(int k) { return (k + 127) / 128; }
 inline int c8m_tm(int k) { const int t32 = (k + 31) / 32, nm = c8m_mtiles(k); return (t32 + nm - 1) / nm; }
@@ -600,6 +688,41 @@ int pvhip_maxpool3x3_lrn_c8(const void* x, void* y, int n, int c, int h, int w, 
         default: PVM_PL(0); break;
     }
 #undef PVM_PL
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_lrn_maxpool3x3_c8_supported(int h, int w, int oh, int ow, int sh, int sw, int pad_top, int pad_left, int size) {
+    if (size != 5 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || sh <= 0 || sw <= 0 || ow > kBlock) return 0;
+    int R = kBlock / ow;                                     // one pooled output per lane
+    if (R > oh) R = oh;
+    while (R > 1 && ((R - 1) * sh + 3) * w > 4 * kBlock) --R;        // and at most four band pixels per lane
+    return (((R - 1) * sh + 3) * w <= 4 * kBlock) ? R : 0;
+}
+
+int pvhip_lrn_maxpool3x3_c8(const void* x, void* y, int n, int c, int h, int w, int size, float alpha, float beta, float bias,
+                            int oh, int ow, int sh, int sw, int pad_top, int pad_left, int pad_bottom, int pad_right) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && c > 0 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 && pad_right >= 0);
+    const int R = pvhip_lrn_maxpool3x3_c8_supported(h, w, oh, ow, sh, sw, pad_top, pad_left, size);
+    if (R == 0) return fail(PVHIP_EUNSUPPORTED, "pvhip_lrn_maxpool3x3_c8: a window of five channels, pooled rows of at most %d outputs, bands of at most %d pixels", kBlock, 4 * kBlock);
+    const int hp = h + pad_top + pad_bottom, wp = w + pad_left + pad_right;
+    PVHIP_CHECK_ARG((oh - 1) * sh < hp && (ow - 1) * sw < wp);
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+    const int cb = c8m_blocks(c);
+    const int n_bands = (oh + R - 1) / R;
+    const int rows_in = (R - 1) * sh + 3;
+    const int ppt = (rows_in * w + kBlock - 1) / kBlock;
+    const size_t lds = (size_t)rows_in * w * 16;
+    const int bm = lrn_beta_mode(beta, bias) == 4 ? 4 : (lrn_beta_mode(beta, bias) == 1 ? 1 : 0);
+    const dim3 grid((unsigned)(n * n_bands));
+#define PVM_LP(BM_, PPT_) hipLaunchKernelGGL((lrn_maxpool3x3_c8_kernel<BM_, PPT_>), grid, dim3(kBlock), lds, state().stream, static_cast<const _Float16*>(x), \
+                                             static_cast<_Float16*>(y), n, cb, c, h, w, oh, ow, sh, sw, pad_top, pad_left, hp, wp, R, n_bands, alpha, beta, bias)
+#define PVM_LP_P(BM_) { if (ppt <= 1) PVM_LP(BM_, 1); else if (ppt <= 2) PVM_LP(BM_, 2); else PVM_LP(BM_, 4); }
+    if (bm == 4) PVM_LP_P(4) else if (bm == 1) PVM_LP_P(1) else PVM_LP_P(0)
+#undef PVM_LP_P
+#undef PVM_LP
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -690,19 +690,35 @@ class Executable_Network:
                         continue
                     tail = f['relu'] if f['relu'] is not None else f['add']
                     readers = list(G.successors(tail))
-                    if len(readers) != 1 or G.nodes[readers[0]]['type'] != 'MaxPool' or readers[0] in self._fused_away:
+                    if len(readers) != 1 or G.nodes[readers[0]]['type'] not in ('MaxPool', 'LRN') or readers[0] in self._fused_away:
                         continue
-                    pid = readers[0]
-                    if tuple(common_def.string_to_tuple(G.nodes[pid]['data']['kernel'])) != (3, 3):
+                    pid = readers[0]                                 # a 3x3 MaxPool (alone, or leading MaxPool + LRN), or an LRN leading LRN + MaxPool
+                    folded = self._lrn_pool.get(pid)
+                    if G.nodes[pid]['type'] == 'LRN' and folded is None:
                         continue
-                    out_node = self._lrn_pool.get(pid, pid)          # the LRN folded into the MaxPool carries the tensor
-                    if out_node != pid and int(G.nodes[out_node]['data'].get('size', 0)) != 5:
+                    pool_id, lrn_id = (pid, folded) if G.nodes[pid]['type'] == 'MaxPool' else (folded, pid)
+                    if tuple(common_def.string_to_tuple(G.nodes[pool_id]['data']['kernel'])) != (3, 3):
                         continue
+                    if lrn_id is not None and int(G.nodes[lrn_id]['data'].get('size', 0)) != 5:
+                        continue
+                    out_node = folded if folded is not None else pid   # the node folded into the leading one carries the tensor
                     after = list(G.successors(out_node))
-                    if not after or not all(r in self._fusion and G.nodes[r]['type'] == 'Convolution' and conv_plugin.c8_module_member_ok(G.nodes[r]) and
-                                            (r in self._c8_out or r in self._siblings) for r in after):
+                    folded_pools = {p[0] for p in self._pool_conv.values()}
+
+                    def takes_blocked(r):
+                        if r in folded_pools:                        # a MaxPool folded into its pool_proj convolution
+                            pc = next(c_ for c_, p_ in self._pool_conv.items() if p_[0] == r)
+                            return conv_plugin.c8_module_member_ok(G.nodes[pc], G.nodes[r])
+                        return r in self._fusion and G.nodes[r]['type'] == 'Convolution' and conv_plugin.c8_module_member_ok(G.nodes[r]) and \
+                            (r in self._c8_out or r in self._siblings)
+                    if not after or not all(takes_blocked(r) for r in after):
                         continue
-                    if conv_plugin.c8_writer_ok(G.nodes[cid]) or conv_plugin.c8_dma_writer_ok(G.nodes[cid]):
+                        # the writer: the f16 1x1 launch, the f16 form of the LDS-DMA kernel (conv1), or -- its own input being blocked -- the module form
+                    own_src = next((p_ for p_ in G.pred[cid] if G.edges[(p_, cid)]['connection'][3] == 0), None)
+                    own_blocked = any(own_src == (self._fusion[c_]['relu'] if self._fusion[c_]['relu'] is not None else self._fusion[c_]['add'])
+                                      for c_ in self._c8_out)
+                    if conv_plugin.c8_writer_ok(G.nodes[cid]) or conv_plugin.c8_dma_writer_ok(G.nodes[cid]) or \
+                            (own_blocked and conv_plugin.c8_module_member_ok(G.nodes[cid])):
                         self._c8_out.add(cid)
             if os.environ.get('PVHIP_CONV_F16_C8', '2') == '2' and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
                 self.plan_c8_modules(conv_plugin)
@@ -745,6 +761,10 @@ class Executable_Network:
                 src = src_of(nid)
                 if src in blocked and tuple(common_def.string_to_tuple(node['data']['kernel'])) == (3, 3) and nid not in self._lrn_pool.values():
                     blocked.add(nid)          # the plugin pools a blocked tensor as it is (a folded pool hands its input on)
+                    if nid in self._lrn_pool:
+                        blocked.add(self._lrn_pool[nid])      # MaxPool + LRN on the blocked tensor: the folded LRN carries it
+            elif node['type'] == 'LRN' and nid in self._lrn_pool and src_of(nid) in blocked:
+                blocked.add(self._lrn_pool[nid])              # LRN + MaxPool on a blocked tensor: the folded MaxPool carries it
             elif node['type'] == 'Concat' and nid in self._concat_direct:
                 members = members_of.get(nid, [])
                 if not members:

@@ -57,9 +57,21 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     beta = float(attrs['beta'])
     bias = float(attrs['bias'])
     size = int(attrs['size'])
+    pool_node = node.get('_fuse_pool')
+    if pool_node is not None and isinstance(inputs[0], dev.BlockedHalf) and size == 5:
+        # FP16 IRs: the input is fp16 blocked by eight channels (what the reference holds here is a float16 tensor): LRN + MaxPool on it as it
+        # is, the output is blocked too
+        xb = inputs[0]
+        n, c, h, w = xb.shape
+        kernel, strides, pads_begin, pads_end, oh, ow = _pool_geometry(pool_node, h, w)
+        if tuple(kernel) == (3, 3) and oh > 0 and ow > 0 and dev.call('pvhip_lrn_maxpool3x3_c8_supported', h, w, oh, ow, strides[0], strides[1],
+                                                                     pads_begin[0], pads_begin[1], size):
+            yb = dev.BlockedHalf((n, c, oh, ow))
+            dev.call('pvhip_lrn_maxpool3x3_c8', ctypes.c_void_p(xb.ptr), ctypes.c_void_p(yb.ptr), n, c, h, w, size, alpha, beta, bias, oh, ow,
+                     strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1])
+            return {common_def.first_output_port(node): yb}
     x = dev.as_device(inputs[0])
     n, c, h, w = x.shape
-    pool_node = node.get('_fuse_pool')
     if pool_node is not None:
         kernel, strides, pads_begin, pads_end, oh, ow = _pool_geometry(pool_node, h, w)
         y = dev.DeviceTensor.empty((n, c, oh, ow))

@@ -1422,6 +1422,24 @@ def test_fp16_stem_on_blocked_tensors(hip):
         g = np.asarray(got)
         assert np.array_equal(np.isnan(g), np.isnan(want))
         assert_close(np.nan_to_num(g), np.nan_to_num(want), 1e-3, 'MaxPool + LRN on a blocked tensor {}'.format(xs), elementwise=False)
+    # (3) the other order: LRN + MaxPool on a blocked tensor (pvhip_lrn_maxpool3x3_c8) against the fp32 launch on the same fp16 values
+    for xs, st, pb, pe, rounding in [((2, 192, 56, 56), (2, 2), (0, 0), (0, 0), 'ceil'), ((1, 20, 13, 11), (2, 2), (0, 0), (0, 0), 'ceil'),
+                                     ((3, 8, 9, 20), (1, 1), (1, 1), (1, 1), 'floor'), ((2, 40, 14, 14), (2, 2), (1, 0), (0, 1), 'floor'), ((1, 16, 40, 112), (2, 2), (0, 0), (0, 0), 'ceil')]:
+        x = f16r(rnd(sum(xs), xs, 40.0))
+        if xs[1] == 20:
+            x[0, 5, 4, 4] = np.nan
+        lnode = make_node('LRN', [x, axes], lrn_data)
+        pnode = make_node('MaxPool', [x], pool_data((3, 3), st, pb, pe, rounding))
+        normed = np.asarray(hip_plugin('LRN').compute(dict(lnode), {0: x, 1: axes})[2])
+        want = np.asarray(pool.compute(dict(pnode), {0: normed})[1])
+        pnode['output'][1]['dims'] = tuple(want.shape)
+        fused = dict(lnode)
+        fused['_fuse_pool'] = pnode
+        got = hip_plugin('LRN').compute(fused, {0: dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x)), 1: axes})[2]
+        assert isinstance(got, dev.BlockedHalf) and got.shape == want.shape, (type(got), xs)
+        g = np.asarray(got)
+        assert np.array_equal(np.isnan(g), np.isnan(want))
+        assert_close(np.nan_to_num(g), np.nan_to_num(want), 1e-3, 'LRN + MaxPool on a blocked tensor {}'.format(xs), elementwise=False)
 
 
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
