@@ -271,7 +271,7 @@ def extra_configs(blob=None):
         conv_fl = sum(fl for nid, (fl, _) in work.items() if net.G.nodes[nid]['type'] == 'Convolution')
         out.append({'workload': 'models/googlenet-v1.xml as an FP16 IR, batch 256: fp16 operands on the f16 matrix cores (v_mfma_f32_32x32x16_f16), fp32 '
                                 'accumulation; the inception modules on fp16 tensors in HBM (channels blocked by eight: module inputs, reduce tensors, '
-                                'Concat buffers, and the stem from conv1's output on), the classifier fp32; one synchronous infer() at a time',
+                                'Concat buffers, and the stem from the output of conv1 on), the classifier fp32; one synchronous infer() at a time',
                     'dtype': 'f16 operands / f32 accumulate', 'images_per_sec': round(rate, 1), 'ms_per_infer': round(ms, 3),
                     'convolution_ms': round(conv_ms, 3), 'convolution_TFLOPs_algorithmic': round(conv_fl / (conv_ms * 1e-3) / 1e12, 1),
                     'note': 'pvhip_conv2d_f16_c8_multi on the inception modules (blocked fp16 in and out: the 1x1 arms as one launch, 3x3 / 5x5, '
