@@ -767,8 +767,8 @@ class Executable_Network:
                 blocked.add(self._lrn_pool[nid])              # LRN + MaxPool on a blocked tensor: the folded MaxPool carries it
             elif node['type'] == 'Concat' and nid in self._concat_direct:
                 members = members_of.get(nid, [])
-                if not members:
-                    continue
+                if not members or int(next(iter(node['output'].values()))['dims'][1]) % 16 != 0:
+                    continue          # (a blocked tensor holds whole 16-channel stages; its members write whole 8-channel blocks: c8_module_member_ok)
                 # the first module: the tensor its 1x1 arms read is not blocked yet -- it is converted if that makes the module blocked
                 entry = None
                 srcs = {data_src(m) for m in members}

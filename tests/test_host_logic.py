@@ -188,7 +188,8 @@ def test_bench_work_model_matches_survey_totals():
 
 def test_plan_folds_the_mean_add_into_conv1s_padding_pass():
     """GoogLeNet: data/mean (Add of one constant per input channel) feeds only conv1, a padded layer with C = 3: the Add is not
-    dispatched, conv1 reads the Parameter and its padding pass adds the constant.  Unfused plans and the FP16 form keep the Add."""
+    dispatched, conv1 reads the Parameter and its padding pass adds the constant (the FP16 form too: test_plan_of_an_fp16_ir_...).  Unfused
+    plans keep the Add."""
     _, net, ex = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=True)
     G = net.G
     assert len(ex._pre_add) == 1
@@ -197,6 +198,52 @@ def test_plan_folds_the_mean_add_into_conv1s_padding_pass():
     assert G.nodes[sid]['type'] == 'Parameter' and aid in ex._fused_away
     _, _, ex2 = helpers.build_network('pyopenvino_amd.op_plugins', 'googlenet-v1', weights=bytes(28 << 20), batch=2, fuse=False)
     assert ex2._pre_add == {}
+
+
+def test_plan_of_an_fp16_ir_keeps_googlenet_on_blocked_fp16_tensors(monkeypatch):
+    """GoogLeNet as an FP16 IR read with fp16_as_fp32=False (no device needed: the plan asks libpvhip's _supported queries only).  Default:
+    every one of the nine channel Concats gets a blocked fp16 buffer, 21 fused convolution chains hand their output over blocked (the
+    eighteen 3x3_reduce / 5x5_reduce arms, conv2/3x3_reduce, and the stem's conv1 and conv2/3x3, whose readers are MaxPool + LRN and LRN +
+    MaxPool on blocked tensors), nothing is converted on the way, data/mean rides in conv1's padding pass.  PVHIP_CONV_F16_C8=1: only the 19
+    tensors between a 1x1 convolution and the 3x3 / 5x5 behind it; =0: none.  An FP32 IR never gets any of it."""
+    import tempfile
+    from pyopenvino_amd import IECore, synth
+    xml = os.path.join(MODELS, 'googlenet-v1.xml')
+    blob = synth.synth_weights(xml, 1234)
+
+    def plan(mode, fp16=True):
+        if mode is None:
+            monkeypatch.delenv('PVHIP_CONV_F16_C8', raising=False)
+        else:
+            monkeypatch.setenv('PVHIP_CONV_F16_C8', mode)
+        ie = IECore(plugin_package='pyopenvino_amd.op_plugins')
+        if fp16:
+            with tempfile.TemporaryDirectory() as tmp:
+                xml16, blob16 = synth.fp16_ir(xml, blob, tmp)
+                net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+        else:
+            net = ie.read_network(xml, weights=blob)
+        net.set_batch(4)
+        return net, ie.load_network(net)
+
+    net, ex = plan(None)
+    G = net.G
+    names = sorted(G.nodes[c]['name'].replace('/WithoutBiases', '') for c in ex._c8_out)
+    assert len(ex._c8_concat) == 9 and all(G.nodes[n]['type'] == 'Concat' for n in ex._c8_concat)
+    assert len(ex._c8_out) == 21 and 'conv1/7x7_s2' in names and 'conv2/3x3' in names and 'conv2/3x3_reduce' in names, names
+    assert sum(n.endswith('_reduce') for n in names) == 19
+    assert ex._c8_entry == set() and len(ex._pre_add) == 1
+    # every member of a blocked Concat is a fused convolution chain that writes whole 8-channel blocks at an offset that is a multiple of 8
+    for cat in ex._c8_concat:
+        offs = [(ex._fusion[c]['into'][1], next(iter(G.nodes[c]['output'].values()))['dims'][1]) for c in ex._fusion if ex._fusion[c]['into'] is not None and ex._fusion[c]['into'][0] == cat]
+        assert len(offs) == 4 and all(o % 8 == 0 and k % 8 == 0 for o, k in offs)
+        assert sum(k for _, k in offs) == next(iter(G.nodes[cat]['output'].values()))['dims'][1]
+    _, ex1 = plan('1')
+    assert len(ex1._c8_out) == 19 and ex1._c8_concat == set() and ex1._c8_entry == set()
+    _, ex0 = plan('0')
+    assert ex0._c8_out == set() and ex0._c8_concat == set()
+    _, ex32 = plan(None, fp16=False)
+    assert ex32._c8_out == set() and ex32._c8_concat == set() and ex32._c8_entry == set()
 
 
 def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):
