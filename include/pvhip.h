@@ -323,6 +323,16 @@ int    pvhip_conv2d_f16_dma_c8(const float* x, const float* wpack, void* yb,
 int    pvhip_maxpool3x3_lrn_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
                                int pad_top, int pad_left, int pad_bottom, int pad_right,
                                int size, float alpha, float beta, float bias);
+/* The first convolution of an image network as an FP16 layer, from row spans (ABI v14): 7x7 / stride 2 / pad 3 over three channels, at most 64
+ * output channels (GoogLeNet's conv1).  _supported: 0, or the floats per row the padded input must have (w + 3 rounded up so that every
+ * tap of the last output column exists, whole 16-byte pieces); xp: that padded input (n, 3, hp, wp), e.g. from pvhip_pad2d_f32 with
+ * pad_top = pad_left = 3, pad_bottom = 3, pad_right = wp - w - 3 (and the per-channel constant of a folded Add); wf: _stem_pack of the
+ * (k_out, 3, 7, 7) weights (_stem_pack_elems FLOATS); yb: fp16 c8 output (n, k_out, oh, ow); act: none or ReLU.                        */
+int    pvhip_conv2d_f16_stem_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
+size_t pvhip_conv2d_f16_stem_pack_elems(int k_out);
+int    pvhip_conv2d_f16_stem_pack(const float* w_oihw, float* wf, int k_out);
+int    pvhip_conv2d_f16_stem(const float* xp, const float* wf, void* yb, int n, int hp, int wp, int k_out, int oh, int ow,
+                             const float* bias, int act);
 /* ... and the other order: LRN over five channels followed by MaxPool 3x3 on a c8 tensor as one launch (LRN.py:10-22 then MaxPool.py:41-72;
  * the LRN tensor never exists).  _supported: pooled rows per workgroup (0: outside the kernel).                                        */
 int    pvhip_lrn_maxpool3x3_c8_supported(int h, int w, int oh, int ow, int sh, int sw, int pad_top, int pad_left, int size);

@@ -101,6 +101,10 @@ SIGNATURES = {
     'pvhip_lrn_maxpool3x3_c8_supported': (_c.c_int, [_c.c_int] * 9),
     'pvhip_lrn_maxpool3x3_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_float] * 3 + [_c.c_int] * 8),
     'pvhip_maxpool3x3_lrn_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 13 + [_c.c_float] * 3),
+    'pvhip_conv2d_f16_stem_supported': (_c.c_int, [_c.c_int] * 12),
+    'pvhip_conv2d_f16_stem_pack_elems': (_c.c_size_t, [_c.c_int]),
+    'pvhip_conv2d_f16_stem_pack': (_c.c_int, [_fp, _fp, _c.c_int]),
+    'pvhip_conv2d_f16_stem': (_c.c_int, [_fp, _fp, _c.c_void_p] + [_c.c_int] * 6 + [_fp, _c.c_int]),
     'pvhip_conv2d_f16_dma_c8': (_c.c_int, [_fp, _fp, _c.c_void_p] + [_c.c_int] * 13 + [_fp, _c.c_int]),
     'pvhip_conv2d_f16_c8': (_c.c_int, [_c.c_void_p, _fp, _fp] + [_c.c_int] * 7 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_kernel_kind': (_c.c_int, [_c.c_int] * 13),
@@ -121,7 +125,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -196,18 +200,20 @@ settings_serial = 0      # bumped by every reload: host-side plans that bake ker
 conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'      # Convolution plugin: pad the input of a c-major layer in a pass of its own
 conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'    # Convolution plugin, FP16 IRs: the f16 form of the LDS-DMA kernel where it applies
 conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)  # ... and the span kernel before it: 1 = 3x3 / 5x5 layers, 2 = 1x1 too (slower there), 0 = never
+conv_f16_stem = os.environ.get('PVHIP_CONV_F16_STEM', '1') != '0'  # ... and the row-span kernel for a 7x7 / 2 first convolution over three channels with a blocked output
 conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '2') != '0'      # ... and fp16 tensors blocked by eight channels between a 1x1 convolution and the 3x3 / 5x5 behind it
 
 
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
-    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8
+    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8, conv_f16_stem
     call('pvhip_settings_reload')
     conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'
     conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)
     conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '2') != '0'
+    conv_f16_stem = os.environ.get('PVHIP_CONV_F16_STEM', '1') != '0'
     settings_serial += 1
 
 

@@ -309,6 +309,23 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     if pre_add is not None:
         pre_add = dev.as_device(pre_add)
         assert pre_add.size == c
+    if f16 and out_c8 and into is None and (act is None or act[0] == 'relu') and dev.conv_f16_stem and tuple(pads_begin) == tuple(pads_end):
+        # FP16 IRs: a 7x7 / 2 convolution over three channels with a blocked fp16 output (GoogLeNet's conv1) from row spans of the padded image
+        wps = int(dev.call('pvhip_conv2d_f16_stem_supported', c, h, wd, kn, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
+        if wps > 0:
+            xp = dev.DeviceTensor.empty((n, c, hp, wps))
+            dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
+                     pads_end[0], wps - wd - pads_begin[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
+            cached = node.get('_hip_wpack_stem')
+            if cached is None or cached[0] is not w._block:
+                wf = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_f16_stem_pack_elems', kn)),))
+                dev.call('pvhip_conv2d_f16_stem_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wf.ptr), kn)
+                cached = node['_hip_wpack_stem'] = (w._block, wf)
+            yb = dev.BlockedHalf((n, kn, oh, ow))
+            node['_hip_f16'] = 'row spans, blocked output'
+            dev.call('pvhip_conv2d_f16_stem', ctypes.c_void_p(xp.ptr), ctypes.c_void_p(cached[1].ptr), ctypes.c_void_p(yb.ptr), n, hp, wps, kn, oh, ow,
+                     ctypes.c_void_p(bias.ptr if bias is not None else 0), 1 if act is not None else 0)
+            return yb
     # which kernel forms the library offers for this geometry: asked once per node and settings (not on every launch)
     route_key = (dev.settings_serial, x.shape, w.shape, tuple(strides), tuple(pads_begin), tuple(pads_end), bool(f16))
     route = node.get('_hip_route')

@@ -655,7 +655,7 @@ def test_googlenet_fp16_ir_whole_modules_on_blocked_fp16_tensors(hip, tmp_path, 
     prob = helpers.infer_one(ex, net, images)
     assert len(ex._c8_concat) == 9 and len(ex._c8_entry) == 0          # (no conversion: the stem hands module 3a a blocked tensor)
     conv1 = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'Convolution' and net.G.nodes[n]['input'][1]['dims'][2] == 7)
-    assert net.G.nodes[conv1]['_hip_f16'] == 'lds-dma, blocked output'          # the stem: conv1 -> (MaxPool + LRN on the blocked tensor) -> conv2/3x3_reduce
+    assert net.G.nodes[conv1]['_hip_f16'] == 'row spans, blocked output'        # the stem: conv1 -> (MaxPool + LRN on the blocked tensor) -> conv2/3x3_reduce
     pool1 = next(iter(net.G.successors(ex._fusion[conv1]['relu'])))
     assert isinstance(next(iter(net.G.nodes[pool1]['output'].values()))['data'], device.BlockedHalf)
     pool2 = next(n for n in net.G.nodes if net.G.nodes[n]['name'] == 'pool2/3x3_s2')

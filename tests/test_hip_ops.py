@@ -1391,9 +1391,31 @@ def test_fp16_stem_on_blocked_tensors(hip):
     channel counts that are not multiples of 8 or 16, strides, padding, ceil / floor, a NaN."""
     from pyopenvino_amd import device as dev
     plugin, pool = hip_plugin('Convolution'), hip_plugin('MaxPool')
+    # (0) the row-span kernel (pvhip_conv2d_f16_stem: 7x7 / 2 / pad 3 over three channels, blocked output) against the oracle on fp16-rounded
+    # operands: GoogLeNet's conv1 at its own size, odd and small extents (a last tile of one row, rows that do not fill a pixel block),
+    # 64 / 40 / 24 output channels, with and without the folded per-channel constant
+    assert not dev.call('pvhip_conv2d_f16_stem_supported', 3, 9, 252, 64, 7, 7, 2, 2, 3, 3, 5, 126)          # (a padded row of more than 256 floats)
+    assert not dev.call('pvhip_conv2d_f16_stem_supported', 4, 30, 30, 64, 7, 7, 2, 2, 3, 3, 15, 15) and not dev.call('pvhip_conv2d_f16_stem_supported', 3, 30, 30, 96, 7, 7, 2, 2, 3, 3, 15, 15)
+    for xs, k, add in [((2, 3, 224, 224), 64, True), ((1, 3, 37, 41), 40, False), ((3, 3, 30, 18), 24, True), ((1, 3, 9, 250), 64, False)]:
+        x, w, b = np.round(rnd(sum(xs), xs, 60.0)), rnd(k, (k, 3, 7, 7), (2.0 / 147) ** 0.5), rnd(3, (1, k, 1, 1), 0.2)
+        mean = np.array([-104.0, -117.0, -123.0], dtype=np.float32).reshape(1, 3, 1, 1)
+        node = make_node('Convolution', [x, w], conv_data((2, 2), (3, 3), (3, 3)))
+        node['_f16_mfma'], node['_fuse_bias'], node['_fuse_act'], node['_out_c8'] = True, dev.DeviceTensor.from_numpy(b), ('relu',), True
+        if add:
+            node['_pre_add'] = dev.DeviceTensor.from_numpy(mean)
+        y = next(iter(plugin.compute(node, {0: x, 1: w}).values()))
+        assert isinstance(y, dev.BlockedHalf) and node['_hip_f16'] == 'row spans, blocked output', node['_hip_f16']
+        xin = (x + mean).astype(np.float32) if add else x
+        want = np.maximum(first_out(oracle_plugin('Convolution').compute(make_node('Convolution', [xin, w], conv_data((2, 2), (3, 3), (3, 3))),
+                                                                        {0: f16r(xin), 1: f16r(w)}, kernel_type='special')) + b, 0).astype(np.float32)
+        got = np.asarray(y)
+        assert_bit_exact(got, f16r(got), 'a blocked output holds fp16 values')
+        assert_close(got, want, 2e-3, 'row-span conv1 {} k{}'.format(xs, k), elementwise=False)
     for xs, k, kk, st, pb, pe in [((2, 3, 37, 37), 64, 7, (2, 2), (3, 3), (3, 3)), ((1, 20, 13, 11), 24, 3, (1, 1), (1, 1), (1, 1)), ((2, 32, 9, 9), 40, 3, (2, 2), (0, 0), (1, 1))]:
         x, w, b = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5), rnd(3, (1, k, 1, 1), 0.2)
         outs = {}
+        os.environ['PVHIP_CONV_F16_STEM'] = '0'          # (this part: the f16 form of the LDS-DMA kernel)
+        dev.reload_settings()
         for blocked in (False, True):
             node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
             node['_f16_mfma'], node['_fuse_bias'], node['_fuse_act'], node['_out_c8'] = True, dev.DeviceTensor.from_numpy(b), ('relu',), blocked
@@ -1403,6 +1425,8 @@ def test_fp16_stem_on_blocked_tensors(hip):
             assert isinstance(y, dev.BlockedHalf) == blocked, node.get('_hip_f16')
             outs[blocked] = np.asarray(y)
         assert_bit_exact(outs[True], f16r(outs[False]), 'blocked output of the f16 LDS-DMA form {} k{}'.format(xs, k))
+        del os.environ['PVHIP_CONV_F16_STEM']
+        dev.reload_settings()
     lrn_data = {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'}
     axes = np.array([1], dtype=np.int64)
     for xs, st, pb, pe, rounding in [((2, 64, 112, 112), (2, 2), (0, 0), (0, 0), 'ceil'), ((1, 20, 13, 11), (2, 2), (0, 0), (0, 0), 'ceil'),
