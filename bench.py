@@ -276,9 +276,9 @@ def extra_configs(blob=None):
                     'convolution_ms': round(conv_ms, 3), 'convolution_TFLOPs_algorithmic': round(conv_fl / (conv_ms * 1e-3) / 1e12, 1),
                     'note': 'pvhip_conv2d_f16_c8_multi on the inception modules (blocked fp16 in and out: the 1x1 arms as one launch, 3x3 / 5x5, '
                             'MaxPool + pool_proj with the pooling in the operand read; producer waves + LDS-DMA of whole rows, weights from L2: '
-                            'bound by the copy-instruction rate of the producers and the L2 -> CU path), pvhip_conv2d_f16_c8 on conv2/3x3, conv1 on the '
-                            'c-major f16 form of the LDS-DMA kernel (blocked fp16 output), MaxPool + LRN and LRN + MaxPool on blocked tensors.  Far from '
-                            'the 2.5 PFLOP/s f16 MFMA peak'})
+                            'bound by the copy-instruction rate of the producers and the L2 -> CU path), conv2 on the same kernel, conv1 from row spans of '
+                            'the padded image (pvhip_conv2d_f16_stem, blocked fp16 output), MaxPool + LRN and LRN + MaxPool on blocked tensors.  Far '
+                            'from the 2.5 PFLOP/s f16 MFMA peak'})
     return out
 
 
