@@ -333,6 +333,8 @@ size_t pvhip_conv2d_f16_stem_pack_elems(int k_out);
 int    pvhip_conv2d_f16_stem_pack(const float* w_oihw, float* wf, int k_out);
 int    pvhip_conv2d_f16_stem(const float* xp, const float* wf, void* yb, int n, int hp, int wp, int k_out, int oh, int ow,
                              const float* bias, int act);
+/* AvgPool.py:41-59 on a c8 tensor (the window rule of pvhip_avgpool2d_f32); the output is fp32 NCHW. */
+int    pvhip_avgpool_c8(const void* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw);
 /* ... and the other order: LRN over five channels followed by MaxPool 3x3 on a c8 tensor as one launch (LRN.py:10-22 then MaxPool.py:41-72;
  * the LRN tensor never exists).  _supported: pooled rows per workgroup (0: outside the kernel).                                        */
 int    pvhip_lrn_maxpool3x3_c8_supported(int h, int w, int oh, int ow, int sh, int sw, int pad_top, int pad_left, int size);

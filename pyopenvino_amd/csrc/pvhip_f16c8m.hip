@@ -528,6 +528,37 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_c8_kernel(const _Float1
     }
 }
 
+// AvgPool (AvgPool.py:41-59: the mean of in[y s : min(h - 1, y s + kh), x s : min(w - 1, x s + kw)], no padding -- GoogLeNet's 7x7 pool
+// averages the top-left 6x6) on an fp16 c8 tensor; the output is fp32 NCHW (the classifier behind it is dense): one lane per (image,
+// channel block, output pixel), a sequential fp32 sum in the window's row-major order, as avgpool2d_kernel.
+__global__ __launch_bounds__(kBlock) void avgpool_c8_kernel(const _Float16* __restrict__ x, float* __restrict__ y, int n, int cb, int c, int h, int w, int oh,
+                                                            int ow, int kh, int kw, int sh, int sw) {
+    const size_t total = (size_t)n * cb * oh * ow;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(e % ow);
+        size_t    f  = e / ow;
+        const int oy = (int)(f % oh); f /= oh;
+        const int b = (int)(f % cb), im = (int)(f / cb);
+        const half8* const xp = reinterpret_cast<const half8*>(x) + ((size_t)im * cb + b) * (size_t)(h * w);
+        const int y0 = oy * sh, x0 = ox * sw;
+        const int y1 = min(y0 + kh, h - 1), x1 = min(x0 + kw, w - 1);
+        float sum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int   cnt = 0;
+        for (int iy = y0; iy < y1; ++iy)
+            for (int ix = x0; ix < x1; ++ix) {
+                const half8 v = xp[iy * w + ix];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum[q] += (float)v[q];
+                ++cnt;
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ch = 8 * b + q;
+            if (ch < c) y[(((size_t)im * c + ch) * oh + oy) * ow + ox] = cnt > 0 ? sum[q] / (float)cnt : NAN;
+        }
+    }
+}
+
 inline int c8m_blocks(int c) { return (c + 15) / 16 * 2; }
 inline int c8m_mtiles(int k) { return (k + 127) / 128; }
 inline int c8m_tm(int k) { const int t32 = (k + 31) / 32, nm = c8m_mtiles(k); return (t32 + nm - 1) / nm; }
@@ -688,6 +719,18 @@ int pvhip_maxpool3x3_lrn_c8(const void* x, void* y, int n, int c, int h, int w, 
         default: PVM_PL(0); break;
     }
 #undef PVM_PL
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+int pvhip_avgpool_c8(const void* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0);
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr);
+    const int cb = c8m_blocks(c);
+    hipLaunchKernelGGL(avgpool_c8_kernel, dim3(grid_for((size_t)n * cb * oh * ow)), dim3(kBlock), 0, state().stream, static_cast<const _Float16*>(x), y, n, cb, c,
+                       h, w, oh, ow, kh, kw, sh, sw);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -100,6 +100,7 @@ SIGNATURES = {
     'pvhip_maxpool3x3_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 12),
     'pvhip_lrn_maxpool3x3_c8_supported': (_c.c_int, [_c.c_int] * 9),
     'pvhip_lrn_maxpool3x3_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_float] * 3 + [_c.c_int] * 8),
+    'pvhip_avgpool_c8': (_c.c_int, [_c.c_void_p, _fp] + [_c.c_int] * 10),
     'pvhip_maxpool3x3_lrn_c8': (_c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 13 + [_c.c_float] * 3),
     'pvhip_conv2d_f16_stem_supported': (_c.c_int, [_c.c_int] * 12),
     'pvhip_conv2d_f16_stem_pack_elems': (_c.c_size_t, [_c.c_int]),

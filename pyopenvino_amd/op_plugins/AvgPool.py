@@ -29,10 +29,16 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     pads_begin = common_def.string_to_tuple(attrs['pads_begin'])
     pads_end = common_def.string_to_tuple(attrs['pads_end'])
     kernel = common_def.string_to_tuple(attrs['kernel'])
-    x = dev.as_device(inputs[0])
+    blocked = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) else None      # FP16 IRs: fp16 blocked by eight channels, averaged as it is
+    x = blocked if blocked is not None else dev.as_device(inputs[0])
     n, c, h, w = x.shape
     oh, ow = calc_output_shape((h, w), kernel, strides, pads_begin, pads_end, attrs['rounding_type'], attrs['auto_pad'])
     y = dev.DeviceTensor.empty((n, c, oh, ow))
+    if blocked is not None and oh > 0 and ow > 0:
+        dev.call('pvhip_avgpool_c8', ctypes.c_void_p(blocked.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, oh, ow, kernel[0], kernel[1], strides[0], strides[1])
+        return {common_def.first_output_port(node): y}
+    if blocked is not None:
+        x = dev.as_device(blocked)
     dev.call('pvhip_avgpool2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, oh, ow,
              kernel[0], kernel[1], strides[0], strides[1])
     return {common_def.first_output_port(node): y}

@@ -1466,6 +1466,20 @@ def test_fp16_stem_on_blocked_tensors(hip):
         assert_close(np.nan_to_num(g), np.nan_to_num(want), 1e-3, 'LRN + MaxPool on a blocked tensor {}'.format(xs), elementwise=False)
 
 
+def test_avgpool_on_a_blocked_tensor(hip):
+    """AvgPool (the reference's window rule: the 7x7 pool averages the top-left 6x6) on fp16 blocked by eight channels, fp32 output:
+    1e-6 from the fp32 launch on the same fp16 values (the same sequential sum)."""
+    from pyopenvino_amd import device as dev
+    for xs, kern, st in [((3, 1024, 7, 7), (7, 7), (1, 1)), ((2, 20, 9, 12), (3, 3), (2, 2)), ((1, 8, 5, 5), (2, 2), (1, 1))]:
+        x = f16r(rnd(sum(xs), xs))
+        node = make_node('AvgPool', [x], {'kernel': '{}, {}'.format(*kern), 'strides': '{}, {}'.format(*st), 'pads_begin': '0, 0', 'pads_end': '0, 0',
+                                          'rounding_type': 'floor', 'auto_pad': 'valid', 'exclude-pad': 'true'})
+        want = first_out(hip_plugin('AvgPool').compute(dict(node), {0: x}))
+        node['output'] = {1: {'precision': 'FP32', 'dims': tuple(want.shape)}}
+        got = first_out(hip_plugin('AvgPool').compute(dict(node), {0: dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))}))
+        assert_close(got, want, 1e-6, 'AvgPool on a blocked tensor {}'.format(xs))
+
+
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
     """The reference's own FP16 node fixture (resources/node_args_6.pickle, replayed as test_node_sample.py:1-16 does; cropped)
     in float16 as the reference computes it: the f16-MFMA result is within fp16 tolerance of the reference's float16 output
