@@ -45,6 +45,8 @@ struct C8mArgs {
     int R, rows, rows_pad, stride_sh;      // output rows per tile; LDS rows a stage needs / holds (a multiple of 64 >> stride_sh) per channel block; log2 of the LDS row length in pixels
     int n_ins, nbuf, stages;               // copy instructions per stage; stage buffers; stages per tile
     int reg_copy;                          // producers copy through registers (global load + ds_write) instead of LDS-DMA
+    int abl;                               // diagnostic build (PVHIP_CONV_ABLATE bits; wrong results on purpose): 1 every consumer loads channel tile 0's weight fragments (one
+                                           // set of lines per workgroup: how much is the L2 -> CU traffic of the weights?), 2 no weight loads at all, 4 no stores
     int nprod;                             // producer waves: the copy instructions of a stage are dealt out to them (a wave issues one per ~200 cycles)
     unsigned x_bytes, wf_bytes;
     int   act;
@@ -217,7 +219,12 @@ __global__ __launch_bounds__(kMMaxThreads, (KS == 5 && NB == 4) ? 3 : 4) void co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
 
-    const unsigned wlane = (unsigned)lane * 16u + (unsigned)wid * 1024u;
+#ifdef PVHIP_DIAG
+    const int abl = a.abl;
+#else
+    constexpr int abl = 0;
+#endif
+    const unsigned wlane = (abl & 2) ? kOob : (unsigned)lane * 16u + ((abl & 1) ? 0u : (unsigned)wid * 1024u);
     // fragment of MFMA step t of stage cs: window taps (KS > 1): 16-channel step cs, tap t; 1x1: 16-channel step cs * 4 + t (past the
     // last one: an out-of-range offset, zeros -- the copy wrote zeros for those channel blocks too)
 #define PVM_LOAD_A(dst_, cs_, t_)                                                                                \
@@ -290,30 +297,49 @@ __global__ __launch_bounds__(kMMaxThreads, (KS == 5 && NB == 4) ? 3 : 4) void co
     if (ka->seg[sg].layout == 1) {
         _Float16* const yh = static_cast<_Float16*>(ka->seg[sg].y);
         const int cbt = ka->seg[sg].ctotal >> 3, cb0 = (ka->seg[sg].coff + m_rel) >> 3, nblk = ka->seg[sg].nblk - (m_rel >> 3);
+        // Two register groups at a time: group g0 = 2 gp holds channels 8 g0 + 4 lh .. + 3 of the lane's pixel, g1 = g0 + 1 the next block's.
+        // v_permlane32_swap exchanges the upper lane half of one register with the lower half of another: afterwards a lane of the lower
+        // half holds ALL EIGHT channels of block g0 and its partner in the upper half all eight of block g1 -- one 16-byte store per
+        // lane instead of two 8-byte ones (a wave's stores leave at ~170 cycles apiece whatever their width: lesson 53).
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float bs0[4], bs1[4];
+        for (int gp = 0; gp < 2; ++gp) {
+            float bs0[2][4], bs1[2][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bs0[j] = bs1[j] = -0.0f;
-                if (a.bias != nullptr) {
-                    bs0[j] = bias_c[min(row0t + 8 * g + j, a.Kp - 1)];
-                    bs1[j] = bias_c[min(row0t + 8 * g + 4 + j, a.Kp - 1)];
-                }
-            }
-            if (g >= nblk) continue;
-            _Float16* const yb = yh + (((size_t)img * cbt + cb0 + g) * HW + P0) * 8 + 4 * lh;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                half4 hv;
+            for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = acc[nb][4 * g + j] + (lh ? bs1[j] : bs0[j]);
-                    if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
-                    if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
-                    hv[j] = (_Float16)v;
+                    bs0[h2][j] = bs1[h2][j] = -0.0f;
+                    if (a.bias != nullptr) {
+                        bs0[h2][j] = bias_c[min(row0t + 8 * (2 * gp + h2) + j, a.Kp - 1)];
+                        bs1[h2][j] = bias_c[min(row0t + 8 * (2 * gp + h2) + 4 + j, a.Kp - 1)];
+                    }
                 }
-                if (32 * nb + l31 < npx) *reinterpret_cast<half4*>(yb + (size_t)(32 * nb) * 8) = hv;
+            const int  g_mine = 2 * gp + lh;
+            const bool g_ok   = g_mine < nblk;
+            _Float16* const yb = yh + (((size_t)img * cbt + cb0 + g_mine) * HW + P0) * 8;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                unsigned w0[2], w1[2];                                    // the lane's four channels of block g0 (w0) and g1 (w1) as two dwords each
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    half4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[nb][4 * (2 * gp + h2) + j] + (lh ? bs1[h2][j] : bs0[h2][j]);
+                        if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
+                        if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
+                        hv[j] = (_Float16)v;
+                    }
+                    const uint2 u = __builtin_bit_cast(uint2, hv);
+                    if (h2 == 0) { w0[0] = u.x; w0[1] = u.y; } else { w1[0] = u.x; w1[1] = u.y; }
+                }
+                uint4v piece;
+                {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(w0[0], w1[0], false, false);       // s0[0]: lower half own g0, upper half partner's g1; s0[1]: lower half partner's g0, upper half own g1
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(w0[1], w1[1], false, false);
+                    piece[0] = s0[0]; piece[1] = s1[0]; piece[2] = s0[1]; piece[3] = s1[1];             // channels 0-3 (two dwords), then 4-7
+                }
+                if (g_ok && 32 * nb + l31 < npx && !(abl & 4)) *reinterpret_cast<uint4v*>(yb + (size_t)(32 * nb) * 8) = piece;
             }
         }
     } else {
@@ -669,6 +695,10 @@ int pvhip_conv2d_f16_c8_multi(const void* xb, const float* wf, int n, int c, int
     a.wf_bytes = (unsigned)(pvhip_conv2d_f16_c8_pack_elems(k_panel, c, kh, kw) * 4);
     a.act = act; a.lo = act_lo; a.hi = act_hi;
     a.nseg = n_dest;
+    a.abl = 0;
+#ifdef PVHIP_DIAG
+    a.abl = settings().conv_ablate;
+#endif
     const long tiles = (long)n * t.tiles * a.n_mtiles;
     if (tiles > 0x3fffffffL) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_c8_multi: too many tiles");
     a.n_tiles = (int)tiles;

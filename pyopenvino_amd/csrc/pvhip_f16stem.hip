@@ -121,31 +121,46 @@ __global__ __launch_bounds__(kBlock, 4) void conv_f16_stem_kernel(StemArgs a) {
     const const_float_p bias_c = (const_float_p)(unsigned long)a.bias;
     const int cbt = (a.K + 15) / 16 * 2;
     const int P0  = oy0 * a.OW + l31;
+    // two register groups at a time, v_permlane32_swap between the lane halves: a lane of the lower half ends up with all eight channels of
+    // block 4 ct + 2 gp, its partner in the upper half with those of the next block -- one 16-byte store per lane (see conv_f16_c8m_kernel)
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float bs0[4], bs1[4];
+    for (int gp = 0; gp < 2; ++gp) {
+        float bs0[2][4], bs1[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bs0[j] = bs1[j] = -0.0f;
-            if (a.bias != nullptr) {
-                const int k0 = 32 * ct + 8 * g + j;
-                bs0[j] = k0 < a.K ? bias_c[k0] : 0.0f;
-                bs1[j] = k0 + 4 < a.K ? bias_c[min(k0 + 4, a.K - 1)] : 0.0f;
-            }
-        }
-        const int blk = 4 * ct + g;
-        if (blk >= cbt) continue;
-        _Float16* const yb = a.yb + (((size_t)img * cbt + blk) * ohw + P0) * 8 + 4 * lh;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            half4 hv;
+        for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = acc[jb][4 * g + j] + (lh ? bs1[j] : bs0[j]);
-                if (a.act != 0) v = (v < 0.0f) ? 0.0f : v;
-                hv[j] = (_Float16)v;
+                bs0[h2][j] = bs1[h2][j] = -0.0f;
+                if (a.bias != nullptr) {
+                    const int k0 = 32 * ct + 8 * (2 * gp + h2) + j;
+                    bs0[h2][j] = k0 < a.K ? bias_c[k0] : 0.0f;
+                    bs1[h2][j] = k0 + 4 < a.K ? bias_c[min(k0 + 4, a.K - 1)] : 0.0f;
+                }
             }
-            if (live[jb]) *reinterpret_cast<half4*>(yb + (size_t)(32 * ((wid >> 1) + 2 * jb)) * 8) = hv;
+        const int  blk  = 4 * ct + 2 * gp + lh;
+        const bool b_ok = blk < cbt;
+        _Float16* const yb = a.yb + (((size_t)img * cbt + (b_ok ? blk : 0)) * ohw + P0) * 8;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            unsigned w0[2], w1[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                half4 hv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[jb][4 * (2 * gp + h2) + j] + (lh ? bs1[h2][j] : bs0[h2][j]);
+                    if (a.act != 0) v = (v < 0.0f) ? 0.0f : v;
+                    hv[j] = (_Float16)v;
+                }
+                const uint2 u = __builtin_bit_cast(uint2, hv);
+                if (h2 == 0) { w0[0] = u.x; w0[1] = u.y; } else { w1[0] = u.x; w1[1] = u.y; }
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(w0[0], w1[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(w0[1], w1[1], false, false);
+            uint4v piece;
+            piece[0] = s0[0]; piece[1] = s1[0]; piece[2] = s0[1]; piece[3] = s1[1];
+            if (b_ok && live[jb]) *reinterpret_cast<uint4v*>(yb + (size_t)(32 * ((wid >> 1) + 2 * jb)) * 8) = piece;
         }
     }
 }
