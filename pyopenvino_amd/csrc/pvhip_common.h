@@ -46,6 +46,7 @@ struct Settings {
     int  f16_c8_wgs = 0;                   // PVHIP_CONV_F16_C8_WGS=n: pvhip_conv2d_f16_c8 on a persistent grid of n workgroups per CU (0: by layer shape; -1: one tile per workgroup)
     int  f16_c8_prod = 0;                  // PVHIP_CONV_F16_C8_PROD=1..4: producer waves of pvhip_conv2d_f16_c8_multi (0: by the stage's copy instructions)
     int  f16_c8_reg = 0;                   // PVHIP_CONV_F16_C8_REG=1: the producers of pvhip_conv2d_f16_c8_multi copy through registers (tuning runs)
+    int  f16_c8_tpw = 0;                   // PVHIP_CONV_F16_C8_TPW=2: pvhip_conv2d_f16_c8_multi's 1x1 launches with two channel tiles per consumer wave (measured slower: off)
     bool lrnpool_wave = false;             // PVHIP_LRNPOOL_WAVE=1: LRN + MaxPool 3x3 / 2 on the barrier-free wave form (measured: 0.180 ms against 0.171 for the workgroup form; same bits)
     int  dwconv_cols = 1;                  // PVHIP_DWCONV_COLS=0: depthwise 3x3 on the one-shot LDS kernel, 2: with an output stage (A/B)
     bool conv_novalid = false;             // PVHIP_CONV_NOVALID: c-major gather with the window test even where no window leaves the tensor (A/B)

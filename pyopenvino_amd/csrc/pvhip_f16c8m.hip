@@ -45,8 +45,11 @@ struct C8mArgs {
     int R, rows, rows_pad, stride_sh;      // output rows per tile; LDS rows a stage needs / holds (a multiple of 64 >> stride_sh) per channel block; log2 of the LDS row length in pixels
     int n_ins, nbuf, stages;               // copy instructions per stage; stage buffers; stages per tile
     int reg_copy;                          // producers copy through registers (global load + ds_write) instead of LDS-DMA
+    int tpw2;                              // consumers own two channel tiles and half the pixel blocks each (groups of three or four tiles)
     int abl;                               // diagnostic build (PVHIP_CONV_ABLATE bits; wrong results on purpose): 1 every consumer loads channel tile 0's weight fragments (one
-                                           // set of lines per workgroup: how much is the L2 -> CU traffic of the weights?), 2 no weight loads at all, 4 no stores
+                                           // set of lines per workgroup: how much is the L2 -> CU traffic of the weights?), 2 no weight loads at all, 4 no stores,
+                                           // 16 no copies  (nothing inside the tap loop: a uniform branch there costs a vmcnt(0) per tap, lesson 51 -- an ablation of the
+                                           // LDS reads that way made the whole launch 25 % slower and measured itself)
     int nprod;                             // producer waves: the copy instructions of a stage are dealt out to them (a wave issues one per ~200 cycles)
     unsigned x_bytes, wf_bytes;
     int   act;
@@ -82,23 +85,206 @@ __device__ __forceinline__ half8 pk_max3_nan(half8 a, half8 b, half8 c) {
     return __builtin_bit_cast(half8, d);
 }
 
+// The consumer side of conv_f16_c8m_kernel: TW channel tiles (tile0 ..) x NBW pixel blocks (blk0 ..) of the workgroup's tile.
+template <int KS, int NBW, bool POOL, int TW>
+__device__ __forceinline__ void c8m_consume(const C8mArgs& a, const char* const c8m_lds, const int lane, const int tile0, const int blk0, const int mt,
+                                            const int img, const int oy0, const int npx) {
+    constexpr int TAPSW = KS * KS;
+    constexpr int TAPS  = KS == 1 ? kMSteps : TAPSW;
+    constexpr int BLK   = KS == 1 ? 2 * kMSteps : 2;
+    constexpr int RING  = KS == 1 ? kMSteps : KS;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW     = a.H * a.W;
+    const int ncs16  = a.CB >> 1;
+    const int stride = 1 << a.stride_sh;
+    const unsigned blk_bytes = (unsigned)(a.rows_pad * stride) * 16u;
+    const unsigned buf_bytes = blk_bytes * BLK;
+    const int S = a.stages;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wf), 0, a.wf_bytes, 0x00020000);
+
+    unsigned pixoff[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int p  = 32 * (blk0 + nb) + l31;
+        const int pc = p < a.R * a.W ? p : 0;
+        const int pr = pc / a.W, px = pc - pr * a.W;
+        pixoff[nb] = (unsigned)lh * blk_bytes + (unsigned)((pr * stride + px) * 16);
+    }
+    floatx16 acc[TW][NBW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.0f;
+
+#ifdef PVHIP_DIAG
+    const int abl = a.abl;
+#else
+    constexpr int abl = 0;
+#endif
+    unsigned wlane[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) wlane[i] = (abl & 2) ? kOob : (unsigned)lane * 16u + ((abl & 1) ? 0u : (unsigned)(tile0 + i) * 1024u);
+    // fragment of MFMA step t of stage cs: window taps (KS > 1): 16-channel step cs, tap t; 1x1: 16-channel step cs * 4 + t (past the
+    // last one: an out-of-range offset, zeros -- the copy wrote zeros for those channel blocks too)
+#define PVM_LOAD_A(dst_, cs_, t_)                                                                                \
+    {                                                                                                            \
+        const int c16_ = KS == 1 ? (cs_) * kMSteps + (t_) : (cs_);                                               \
+        const int tap_ = KS == 1 ? 0 : (t_);                                                                     \
+        const unsigned so_ = (unsigned)((((mt * ncs16 + min(c16_, ncs16 - 1)) * TAPSW + tap_) * a.tm) * 1024);   \
+        _Pragma("unroll") for (int i = 0; i < TW; ++i)                                                           \
+            dst_[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wr, c16_ < ncs16 ? wlane[i] : kOob, so_, 0)); \
+    }
+    half8 af[RING][TW];
+#pragma unroll
+    for (int s = 0; s < RING; ++s) PVM_LOAD_A(af[s], 0, s);
+    unsigned sb = 0;
+    for (int cs = 0; cs < S; ++cs) {
+        asm volatile("s_barrier" ::: "memory");
+        const char* const buf = c8m_lds + sb * buf_bytes;
+        sb = sb + 1 == (unsigned)a.nbuf ? 0u : sb + 1;
+        const int cs_x = cs + 1 < S ? cs + 1 : cs;                       // the stage the ring's tail prefetches (the last stage: its own again, unused)
+        half8 b8[2][NBW];
+        // pixel operand of MFMA step t: window taps: channel blocks (0, 1), shifted by the tap; 1x1: channel blocks (2 t, 2 t + 1);
+        // pooled: the maximum over the 3x3 window of those
+#define PVM_READ_B(dst_, t_)                                                                                     \
+    _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb) {                                                         \
+        if (POOL) {                                                                                              \
+            const char* const p0_ = buf + pixoff[nb] + (unsigned)(2 * (t_)) * blk_bytes;                         \
+            half8 m_[3];                                                                                         \
+            _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                        \
+                m_[g] = pk_max3_nan(*reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 0) * 16)),   \
+                                    *reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 1) * 16)),   \
+                                    *reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 2) * 16)));  \
+            dst_[nb] = pk_max3_nan(m_[0], m_[1], m_[2]);                                                         \
+        } else if (KS == 1) {                                                                                    \
+            dst_[nb] = *reinterpret_cast<const half8*>(buf + pixoff[nb] + (unsigned)(2 * (t_)) * blk_bytes);     \
+        } else {                                                                                                 \
+            dst_[nb] = *reinterpret_cast<const half8*>(buf + pixoff[nb] + (unsigned)((((t_) / KS) * stride + ((t_) % KS)) * 16)); \
+        }                                                                                                        \
+    }
+        if (!POOL) PVM_READ_B(b8[0], 0);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            // window taps / 1x1: the operands of step t + 1 are read in front of the MFMAs of step t; pooled: step by step (nine reads and
+            // four maxima per operand: two steps of them in flight are registers the accumulators do not leave)
+            if (POOL) { PVM_READ_B(b8[t & 1], t); }
+            else if (t + 1 < TAPS) { PVM_READ_B(b8[(t + 1) & 1], t + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % RING][i], b8[t & 1][nb], acc[i][nb], 0, 0, 0);
+            if (t + RING < TAPS) PVM_LOAD_A(af[t % RING], cs, t + RING)
+            else                 PVM_LOAD_A(af[t % RING], cs_x, t + RING - TAPS)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef PVM_READ_B
+    }
+#undef PVM_LOAD_A
+
+    // ---- epilogue: register 4 g + j of accumulator (i, nb) is panel row row0t + 8 g + 4 lh + j of tile pixel 32 (blk0 + nb) + l31
+    const ActBounds ab = act_bounds(a.act, a.lo, a.hi);
+    typedef const __attribute__((address_space(4))) float* const_float_p;
+    const const_float_p bias_c = (const_float_p)(unsigned long)a.bias;
+    // the member table is read through the kernarg pointer (indexed as an ordinary argument array it would be copied to scratch)
+    typedef const __attribute__((address_space(4))) C8mArgs* kernarg_p;
+    kernarg_p ka = (kernarg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const int P0 = oy0 * a.W + 32 * blk0 + l31;
+    const int p0 = 32 * blk0 + l31;                                      // the lane's pixel of block 0 inside the tile
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        const int row0t = (mt * a.tm + tile0 + i) * 32;                  // first panel row of this channel tile
+        int sg = 0;
+        for (int q = 1; q < a.nseg; ++q) sg = row0t >= ka->seg[q].m_begin ? q : sg;
+        const int m_rel = row0t - ka->seg[sg].m_begin;                   // multiple of 32
+        const int kreal = ka->seg[sg].k;
+        if (ka->seg[sg].layout == 1) {
+            _Float16* const yh = static_cast<_Float16*>(ka->seg[sg].y);
+            const int cbt = ka->seg[sg].ctotal >> 3, cb0 = (ka->seg[sg].coff + m_rel) >> 3, nblk = ka->seg[sg].nblk - (m_rel >> 3);
+            // Two register groups at a time: group g0 = 2 gp holds channels 8 g0 + 4 lh .. + 3 of the lane's pixel, g1 = g0 + 1 the next block's.
+            // v_permlane32_swap exchanges the upper lane half of one register with the lower half of another: afterwards a lane of the lower
+            // half holds ALL EIGHT channels of block g0 and its partner in the upper half all eight of block g1 -- one 16-byte store per
+            // lane instead of two 8-byte ones (a wave's stores leave at ~170 cycles apiece whatever their width: lesson 53).
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                float bs0[2][4], bs1[2][4];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bs0[h2][j] = bs1[h2][j] = -0.0f;
+                        if (a.bias != nullptr) {
+                            bs0[h2][j] = bias_c[min(row0t + 8 * (2 * gp + h2) + j, a.Kp - 1)];
+                            bs1[h2][j] = bias_c[min(row0t + 8 * (2 * gp + h2) + 4 + j, a.Kp - 1)];
+                        }
+                    }
+                const int  g_mine = 2 * gp + lh;
+                const bool g_ok   = g_mine < nblk;
+                _Float16* const yb = yh + (((size_t)img * cbt + cb0 + g_mine) * HW + P0) * 8;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    unsigned w0[2], w1[2];                                // the lane's four channels of block g0 (w0) and g1 (w1) as two dwords each
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        half4 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[i][nb][4 * (2 * gp + h2) + j] + (lh ? bs1[h2][j] : bs0[h2][j]);
+                            if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
+                            if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
+                            hv[j] = (_Float16)v;
+                        }
+                        const uint2 u = __builtin_bit_cast(uint2, hv);
+                        if (h2 == 0) { w0[0] = u.x; w0[1] = u.y; } else { w1[0] = u.x; w1[1] = u.y; }
+                    }
+                    uint4v piece;
+                    {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(w0[0], w1[0], false, false);   // s0[0]: lower half own g0, upper half partner's g1; s0[1]: lower half partner's g0, upper half own g1
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(w0[1], w1[1], false, false);
+                        piece[0] = s0[0]; piece[1] = s1[0]; piece[2] = s0[1]; piece[3] = s1[1];         // channels 0-3 (two dwords), then 4-7
+                    }
+                    if (g_ok && p0 + 32 * nb < npx && !(abl & 4)) *reinterpret_cast<uint4v*>(yb + (size_t)(32 * nb) * 8) = piece;
+                }
+            }
+        } else {
+            float* const yf = static_cast<float*>(ka->seg[sg].y) + ((size_t)img * ka->seg[sg].ctotal + ka->seg[sg].coff + m_rel) * HW + P0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                float bs0 = -0.0f, bs1 = -0.0f;
+                if (a.bias != nullptr) {
+                    bs0 = bias_c[min(row0t + dr, a.Kp - 1)];
+                    bs1 = bias_c[min(row0t + dr + 4, a.Kp - 1)];
+                }
+                const int kk = m_rel + dr + 4 * lh;
+                if (kk >= kreal) continue;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    float v = acc[i][nb][r] + (lh ? bs1 : bs0);
+                    if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
+                    if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
+                    if (p0 + 32 * nb < npx) conv_store1(yf + (size_t)(dr + 4 * lh) * HW + 32 * nb, v);
+                }
+            }
+        }
+    }
+}
+
 // KS: window (1, 3, 5); NB: 32-pixel blocks of a tile (2 / 4); POOL (KS == 1): MaxPool 3x3 / stride 1 / pad 1 in front of the 1x1 window
 template <int KS, int NB, bool POOL>
 __global__ __launch_bounds__(kMMaxThreads, (KS == 5 && NB == 4) ? 3 : 4) void conv_f16_c8m_kernel(C8mArgs a) {
     static_assert(!POOL || KS == 1, "the pooled form is a 1x1 convolution");
     constexpr int PADG  = POOL ? 1 : (KS - 1) / 2;                       // halo of the copied rows
-    constexpr int TAPSW = KS * KS;                                       // taps of the window (the fragments' tap axis)
-    constexpr int TAPS  = KS == 1 ? kMSteps : TAPSW;                     // MFMA steps per stage and 32-pixel block
     constexpr int BLK   = KS == 1 ? 2 * kMSteps : 2;                     // channel blocks per stage
-    constexpr int RING  = KS == 1 ? kMSteps : KS;
     extern __shared__ __attribute__((aligned(1024))) char c8m_lds[];     // [nbuf][BLK][rows_pad][stride][16 bytes]
 
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const int l31 = lane & 31, lh = lane >> 5;
     const int HW     = a.H * a.W;
-    const int ncs16  = a.CB >> 1;
     const int stride = 1 << a.stride_sh;
     const unsigned blk_bytes = (unsigned)(a.rows_pad * stride) * 16u;
     const unsigned buf_bytes = blk_bytes * BLK;
@@ -133,6 +319,9 @@ __global__ __launch_bounds__(kMMaxThreads, (KS == 5 && NB == 4) ? 3 : 4) void co
         auto issue_next = [&]() {
             char* const dst = c8m_lds + (unsigned)(s_i % a.nbuf) * buf_bytes;
             for (int k = pw; k < a.n_ins; k += a.nprod) {
+#ifdef PVHIP_DIAG
+                if (a.abl & 16) continue;
+#endif
                 const int  b    = k / q_n, q = k - b * q_n;
                 const int  gb   = s_i * BLK + b;
                 const bool bok  = gb < a.CB;
@@ -198,171 +387,23 @@ __global__ __launch_bounds__(kMMaxThreads, (KS == 5 && NB == 4) ? 3 : 4) void co
     }
 
     // ---------------------------------------------------------------------- consumers
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wf), 0, a.wf_bytes, 0x00020000);
-    const int  row0t = (mt * a.tm + wid) * 32;                           // first panel row of this wave's channel tile
-    const bool have  = wid < a.tm && row0t < a.Kp;
-    if (!have) {
-        for (int s = 0; s < S; ++s) asm volatile("s_barrier" ::: "memory");
+    // One channel tile and NB pixel blocks per wave -- or (C8mArgs.tpw2: PVHIP_CONV_F16_C8_TPW=2, 1x1 windows) TWO channel tiles and NB / 2
+    // pixel blocks: a pixel operand read from LDS then feeds two MFMAs, for a second weight fragment per step.  MEASURED, NOT KEPT: same
+    // box, alternating, whole FP16 pass: the nine sibling launches 0.67 -> 0.71 ms (3b 0.109 -> 0.120), with the 3x3 / 5x5 layers in that
+    // form too 0.887 -> 0.923 / 0.190 -> 0.200 -- half the LDS reads per MFMA buy nothing: the consumers' LDS reads are not what these
+    // launches wait for (lesson 54).
+    if (KS == 1 && !POOL && a.tpw2 != 0) {
+        constexpr int NBH = NB / 2;
+        const int tile0 = 2 * (wid & 1), blk0 = (wid >> 1) * NBH;
+        int nt = 0;
+        if (tile0 < a.tm && (mt * a.tm + tile0) * 32 < a.Kp) nt = (tile0 + 1 < a.tm && (mt * a.tm + tile0 + 1) * 32 < a.Kp) ? 2 : 1;
+        if (nt == 2)      c8m_consume<KS, NBH, POOL, 2>(a, c8m_lds, lane, tile0, blk0, mt, img, oy0, npx);
+        else if (nt == 1) c8m_consume<KS, NBH, POOL, 1>(a, c8m_lds, lane, tile0, blk0, mt, img, oy0, npx);
+        else for (int s = 0; s < S; ++s) asm volatile("s_barrier" ::: "memory");
         return;
     }
-    unsigned pixoff[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int p  = 32 * nb + l31;
-        const int pc = p < a.R * a.W ? p : 0;
-        const int pr = pc / a.W, px = pc - pr * a.W;
-        pixoff[nb] = (unsigned)lh * blk_bytes + (unsigned)((pr * stride + px) * 16);
-    }
-    floatx16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
-
-#ifdef PVHIP_DIAG
-    const int abl = a.abl;
-#else
-    constexpr int abl = 0;
-#endif
-    const unsigned wlane = (abl & 2) ? kOob : (unsigned)lane * 16u + ((abl & 1) ? 0u : (unsigned)wid * 1024u);
-    // fragment of MFMA step t of stage cs: window taps (KS > 1): 16-channel step cs, tap t; 1x1: 16-channel step cs * 4 + t (past the
-    // last one: an out-of-range offset, zeros -- the copy wrote zeros for those channel blocks too)
-#define PVM_LOAD_A(dst_, cs_, t_)                                                                                \
-    {                                                                                                            \
-        const int c16_ = KS == 1 ? (cs_) * kMSteps + (t_) : (cs_);                                               \
-        const int tap_ = KS == 1 ? 0 : (t_);                                                                     \
-        const unsigned vo_ = c16_ < ncs16 ? wlane : kOob;                                                        \
-        dst_ = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wr, vo_,                          \
-                   (unsigned)((((mt * ncs16 + min(c16_, ncs16 - 1)) * TAPSW + tap_) * a.tm) * 1024), 0));        \
-    }
-    half8 af[RING];
-#pragma unroll
-    for (int s = 0; s < RING; ++s) PVM_LOAD_A(af[s], 0, s);
-    unsigned sb = 0;
-    for (int cs = 0; cs < S; ++cs) {
-        asm volatile("s_barrier" ::: "memory");
-        const char* const buf = c8m_lds + sb * buf_bytes;
-        sb = sb + 1 == (unsigned)a.nbuf ? 0u : sb + 1;
-        const int cs_x = cs + 1 < S ? cs + 1 : cs;                       // the stage the ring's tail prefetches (the last stage: its own again, unused)
-        half8 b8[2][NB];
-        // pixel operand of MFMA step t: window taps: channel blocks (0, 1), shifted by the tap; 1x1: channel blocks (2 t, 2 t + 1);
-        // pooled: the maximum over the 3x3 window of those
-#define PVM_READ_B(dst_, t_)                                                                                     \
-    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                          \
-        if (POOL) {                                                                                              \
-            const char* const p0_ = buf + pixoff[nb] + (unsigned)(2 * (t_)) * blk_bytes;                         \
-            half8 m_[3];                                                                                         \
-            _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                        \
-                m_[g] = pk_max3_nan(*reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 0) * 16)),   \
-                                    *reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 1) * 16)),   \
-                                    *reinterpret_cast<const half8*>(p0_ + (unsigned)((g * stride + 2) * 16)));  \
-            dst_[nb] = pk_max3_nan(m_[0], m_[1], m_[2]);                                                         \
-        } else if (KS == 1) {                                                                                    \
-            dst_[nb] = *reinterpret_cast<const half8*>(buf + pixoff[nb] + (unsigned)(2 * (t_)) * blk_bytes);     \
-        } else {                                                                                                 \
-            dst_[nb] = *reinterpret_cast<const half8*>(buf + pixoff[nb] + (unsigned)((((t_) / KS) * stride + ((t_) % KS)) * 16)); \
-        }                                                                                                        \
-    }
-        if (!POOL) PVM_READ_B(b8[0], 0);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            // window taps / 1x1: the operands of step t + 1 are read in front of the MFMAs of step t; pooled: step by step (nine reads and
-            // four maxima per operand: two steps of them in flight are registers the four accumulators do not leave)
-            if (POOL) { PVM_READ_B(b8[t & 1], t); }
-            else if (t + 1 < TAPS) { PVM_READ_B(b8[(t + 1) & 1], t + 1); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t % RING], b8[t & 1][nb], acc[nb], 0, 0, 0);
-            if (t + RING < TAPS) PVM_LOAD_A(af[t % RING], cs, t + RING)
-            else                 PVM_LOAD_A(af[t % RING], cs_x, t + RING - TAPS)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef PVM_READ_B
-    }
-#undef PVM_LOAD_A
-
-    // ---- epilogue: register 4 g + j of accumulator nb is panel row row0t + 8 g + 4 lh + j of tile pixel 32 nb + l31
-    const ActBounds ab = act_bounds(a.act, a.lo, a.hi);
-    typedef const __attribute__((address_space(4))) float* const_float_p;
-    const const_float_p bias_c = (const_float_p)(unsigned long)a.bias;
-    // the member table is read through the kernarg pointer (indexed as an ordinary argument array it would be copied to scratch)
-    typedef const __attribute__((address_space(4))) C8mArgs* kernarg_p;
-    kernarg_p ka = (kernarg_p)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    int sg = 0;
-    for (int q = 1; q < a.nseg; ++q) sg = row0t >= ka->seg[q].m_begin ? q : sg;
-    const int m_rel = row0t - ka->seg[sg].m_begin;                       // multiple of 32
-    const int kreal = ka->seg[sg].k;
-    const int P0    = oy0 * a.W + l31;
-    if (ka->seg[sg].layout == 1) {
-        _Float16* const yh = static_cast<_Float16*>(ka->seg[sg].y);
-        const int cbt = ka->seg[sg].ctotal >> 3, cb0 = (ka->seg[sg].coff + m_rel) >> 3, nblk = ka->seg[sg].nblk - (m_rel >> 3);
-        // Two register groups at a time: group g0 = 2 gp holds channels 8 g0 + 4 lh .. + 3 of the lane's pixel, g1 = g0 + 1 the next block's.
-        // v_permlane32_swap exchanges the upper lane half of one register with the lower half of another: afterwards a lane of the lower
-        // half holds ALL EIGHT channels of block g0 and its partner in the upper half all eight of block g1 -- one 16-byte store per
-        // lane instead of two 8-byte ones (a wave's stores leave at ~170 cycles apiece whatever their width: lesson 53).
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            float bs0[2][4], bs1[2][4];
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bs0[h2][j] = bs1[h2][j] = -0.0f;
-                    if (a.bias != nullptr) {
-                        bs0[h2][j] = bias_c[min(row0t + 8 * (2 * gp + h2) + j, a.Kp - 1)];
-                        bs1[h2][j] = bias_c[min(row0t + 8 * (2 * gp + h2) + 4 + j, a.Kp - 1)];
-                    }
-                }
-            const int  g_mine = 2 * gp + lh;
-            const bool g_ok   = g_mine < nblk;
-            _Float16* const yb = yh + (((size_t)img * cbt + cb0 + g_mine) * HW + P0) * 8;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                unsigned w0[2], w1[2];                                    // the lane's four channels of block g0 (w0) and g1 (w1) as two dwords each
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    half4 hv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = acc[nb][4 * (2 * gp + h2) + j] + (lh ? bs1[h2][j] : bs0[h2][j]);
-                        if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
-                        if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
-                        hv[j] = (_Float16)v;
-                    }
-                    const uint2 u = __builtin_bit_cast(uint2, hv);
-                    if (h2 == 0) { w0[0] = u.x; w0[1] = u.y; } else { w1[0] = u.x; w1[1] = u.y; }
-                }
-                uint4v piece;
-                {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(w0[0], w1[0], false, false);       // s0[0]: lower half own g0, upper half partner's g1; s0[1]: lower half partner's g0, upper half own g1
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(w0[1], w1[1], false, false);
-                    piece[0] = s0[0]; piece[1] = s1[0]; piece[2] = s0[1]; piece[3] = s1[1];             // channels 0-3 (two dwords), then 4-7
-                }
-                if (g_ok && 32 * nb + l31 < npx && !(abl & 4)) *reinterpret_cast<uint4v*>(yb + (size_t)(32 * nb) * 8) = piece;
-            }
-        }
-    } else {
-        float* const yf = static_cast<float*>(ka->seg[sg].y) + ((size_t)img * ka->seg[sg].ctotal + ka->seg[sg].coff + m_rel) * HW + P0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            float bs0 = -0.0f, bs1 = -0.0f;
-            if (a.bias != nullptr) {
-                bs0 = bias_c[min(row0t + dr, a.Kp - 1)];
-                bs1 = bias_c[min(row0t + dr + 4, a.Kp - 1)];
-            }
-            const int kk = m_rel + dr + 4 * lh;
-            if (kk >= kreal) continue;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                float v = acc[nb][r] + (lh ? bs1 : bs0);
-                if (a.act != 0) v = (v < ab.lo) ? ab.lo : v;
-                if (a.act == 2) v = (v > ab.hi) ? ab.hi : v;
-                if (32 * nb + l31 < npx) conv_store1(yf + (size_t)(dr + 4 * lh) * HW + 32 * nb, v);
-            }
-        }
-    }
+    if (wid < a.tm && (mt * a.tm + wid) * 32 < a.Kp) c8m_consume<KS, NB, POOL, 1>(a, c8m_lds, lane, wid, 0, mt, img, oy0, npx);
+    else for (int s = 0; s < S; ++s) asm volatile("s_barrier" ::: "memory");
 }
 
 // MaxPool 3x3 (any stride / padding, MaxPool.py:41-72) on fp16 c8 tensors: one lane = one (image, channel block, output pixel), nine
@@ -695,6 +736,10 @@ int pvhip_conv2d_f16_c8_multi(const void* xb, const float* wf, int n, int c, int
     a.wf_bytes = (unsigned)(pvhip_conv2d_f16_c8_pack_elems(k_panel, c, kh, kw) * 4);
     a.act = act; a.lo = act_lo; a.hi = act_hi;
     a.nseg = n_dest;
+    {
+        const int knob = settings().f16_c8_tpw;                                 // PVHIP_CONV_F16_C8_TPW=2: two channel tiles per consumer wave for 1x1 windows (measured slower: off)
+        a.tpw2 = (kh == 1 && knob == 2 && a.tm >= 2) ? 1 : 0;
+    }
     a.abl = 0;
 #ifdef PVHIP_DIAG
     a.abl = settings().conv_ablate;

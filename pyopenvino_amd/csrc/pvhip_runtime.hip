@@ -50,6 +50,7 @@ void load_settings() {
     s.f16_c8_wgs = num("PVHIP_CONV_F16_C8_WGS", 0);
     s.f16_c8_prod = num("PVHIP_CONV_F16_C8_PROD", 0);
     s.f16_c8_reg = num("PVHIP_CONV_F16_C8_REG", 0);
+    s.f16_c8_tpw = num("PVHIP_CONV_F16_C8_TPW", 0);
     s.lrnpool_wave = num("PVHIP_LRNPOOL_WAVE", 0) != 0;
     { const int v = num("PVHIP_CONV_MULTI_BM", 32); s.multi_bm = (v == 64 || v == 128) ? v : 32; }
     s.pw_stagger_pct = num("PVHIP_PW_STAGGER", 0);
