@@ -276,7 +276,7 @@ def extra_configs(blob=None):
                     'convolution_ms': round(conv_ms, 3), 'convolution_TFLOPs_algorithmic': round(conv_fl / (conv_ms * 1e-3) / 1e12, 1),
                     'note': 'pvhip_conv2d_f16_c8_multi on the inception modules (blocked fp16 in and out: the 1x1 arms as one launch, 3x3 / 5x5, '
                             'MaxPool + pool_proj with the pooling in the operand read; producer waves + LDS-DMA of whole rows, weights from L2: '
-                            'bound by the copy-instruction rate of the producers and the L2 -> CU path), conv2 on the same kernel, conv1 from row spans of '
+                            'within 2x of their matrix-pipe floor; copies, stores and weights fill most of the rest), conv2 on the same kernel, conv1 from row spans of '
                             'the padded image (pvhip_conv2d_f16_stem, blocked fp16 output), MaxPool + LRN and LRN + MaxPool on blocked tensors.  Far '
                             'from the 2.5 PFLOP/s f16 MFMA peak'})
     return out
