@@ -202,18 +202,29 @@ conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'      # Convolution
 conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'    # Convolution plugin, FP16 IRs: the f16 form of the LDS-DMA kernel where it applies
 conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)  # ... and the span kernel before it: 1 = 3x3 / 5x5 layers, 2 = 1x1 too (slower there), 0 = never
 conv_f16_stem = os.environ.get('PVHIP_CONV_F16_STEM', '1') != '0'  # ... and the row-span kernel for a 7x7 / 2 first convolution over three channels with a blocked output
-conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '2') != '0'      # ... and fp16 tensors blocked by eight channels between a 1x1 convolution and the 3x3 / 5x5 behind it
+def _env_level(name, default):
+    try:
+        return int(os.environ.get(name, default) or 0)
+    except ValueError:
+        return int(default)
+
+
+# ... and fp16 tensors blocked by eight channels: 0 = never, 1 = between a 1x1 convolution and the 3x3 / 5x5 behind it, 2 = whole modules and
+# the stem (Executable_Network.plan_fusion / plan_c8_modules read THIS value, the plugins too: one source for both sides)
+conv_f16_c8 = _env_level('PVHIP_CONV_F16_C8', '2')
+fuse_poolconv = _env_level('PVHIP_FUSE_POOLCONV', '2')             # MaxPool + pool_proj as one launch: 0 = never (what the plan reads; the library parses its own copy)
 
 
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
-    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8, conv_f16_stem
+    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8, conv_f16_stem, fuse_poolconv
     call('pvhip_settings_reload')
     conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'
     conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)
-    conv_f16_c8 = os.environ.get('PVHIP_CONV_F16_C8', '2') != '0'
+    conv_f16_c8 = _env_level('PVHIP_CONV_F16_C8', '2')
+    fuse_poolconv = _env_level('PVHIP_FUSE_POOLCONV', '2')
     conv_f16_stem = os.environ.get('PVHIP_CONV_F16_STEM', '1') != '0'
     settings_serial += 1
 

@@ -516,6 +516,7 @@ class Executable_Network:
             self.task_list = list(self.list_schedule)
         if not self.fuse_epilogues:
             return
+        from . import device           # settings only (parsed from the environment at import / reload_settings(): the SAME values the plugins read)
         G = self.ienet.G
         # LRN whose only consumer is a MaxPool the fused kernel covers: one launch, the LRN tensor is never written
         lrn_plugin = self.ienet.ie.plugins.plugins.get('LRN')
@@ -609,7 +610,7 @@ class Executable_Network:
         f16 = bool(getattr(self.ienet, 'f16_mfma', False))     # the f16-MFMA kernel fuses the epilogue and the Concat store only
         # A 3x3 / stride 1 / pad 1 MaxPool whose only consumer is a fused 1x1 convolution (pool -> pool_proj): the MaxPool is not
         # dispatched, the convolution reads the MaxPool's input and pools while it builds its input tile.
-        if (not f16 or os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0') and getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and os.environ.get('PVHIP_FUSE_POOLCONV', '1') != '0':
+        if (not f16 or device.conv_f16_dma) and getattr(conv_plugin, 'SUPPORTS_POOLED_INPUT', False) and device.fuse_poolconv != 0:
             for cid in list(self._fusion):
                 if G.nodes[cid]['type'] != 'Convolution':
                     continue
@@ -642,7 +643,7 @@ class Executable_Network:
         # 1x1, 3x3_reduce and 5x5_reduce arms of an inception module) are one launch of the first of them in schedule
         # order: the input is read once and every output-channel tile stores into the tensor of its own convolution
         # (Convolution.launch_siblings; each output has the bits of its own launch).
-        if (not f16 or os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0') and self.fuse_siblings and getattr(conv_plugin, 'SUPPORTS_SIBLINGS', False):
+        if (not f16 or device.conv_f16_dma) and self.fuse_siblings and getattr(conv_plugin, 'SUPPORTS_SIBLINGS', False):
             position = {t: i for i, t in enumerate(self.task_list)}
             groups = {}
             for cid, f in self._fusion.items():
@@ -664,8 +665,7 @@ class Executable_Network:
         # eight (device.BlockedHalf): what the reference holds there is a float16 tensor too (common_def.py:13-17), and the blocked
         # form is the reader's MFMA operand as it stands.  PVHIP_CONV_F16_C8=0: fp32 NCHW everywhere, as before.
         self._c8_out = set()
-        if f16 and os.environ.get('PVHIP_CONV_F16_C8', '2') != '0' and os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0' \
-                and getattr(conv_plugin, 'SUPPORTS_C8', False):
+        if f16 and device.conv_f16_c8 != 0 and device.conv_f16_dma and getattr(conv_plugin, 'SUPPORTS_C8', False):
             for cid, f in self._fusion.items():
                 if G.nodes[cid]['type'] != 'Convolution' or f['into'] is not None or cid in self._pool_conv or cid in self._pre_add:
                     continue
@@ -682,7 +682,7 @@ class Executable_Network:
                     self._c8_out.add(cid)
             # ... and the stem: a convolution whose only reader is a 3x3 MaxPool (with its LRN folded in: GoogLeNet's conv1 -> pool1 -> norm1)
             # whose readers are convolutions that take a blocked input: the MaxPool plugin pools a blocked tensor as it is
-            if os.environ.get('PVHIP_CONV_F16_C8', '2') == '2' and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
+            if device.conv_f16_c8 == 2 and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
                 for cid, f in self._fusion.items():
                     if G.nodes[cid]['type'] != 'Convolution' or f['into'] is not None or cid in self._pool_conv or cid in self._siblings or cid in self._fused_away:
                         continue
@@ -696,10 +696,11 @@ class Executable_Network:
                     folded = self._lrn_pool.get(pid)
                     if G.nodes[pid]['type'] == 'LRN' and folded is None:
                         continue
-                    pool_id, lrn_id = (pid, folded) if G.nodes[pid]['type'] == 'MaxPool' else (folded, pid)
-                    if tuple(common_def.string_to_tuple(G.nodes[pool_id]['data']['kernel'])) != (3, 3):
-                        continue
-                    if lrn_id is not None and int(G.nodes[lrn_id]['data'].get('size', 0)) != 5:
+                    # the SAME predicates the MaxPool / LRN plugins decide with at run time (blocked_ok): what is planned blocked is blocked
+                    if G.nodes[pid]['type'] == 'MaxPool':
+                        if not pool_plugin.blocked_ok(G.nodes[pid], G.nodes[folded] if folded is not None else None):
+                            continue
+                    elif not lrn_plugin.blocked_ok(G.nodes[pid], G.nodes[folded]):
                         continue
                     out_node = folded if folded is not None else pid   # the node folded into the leading one carries the tensor
                     after = list(G.successors(out_node))
@@ -720,7 +721,7 @@ class Executable_Network:
                     if conv_plugin.c8_writer_ok(G.nodes[cid]) or conv_plugin.c8_dma_writer_ok(G.nodes[cid]) or \
                             (own_blocked and conv_plugin.c8_module_member_ok(G.nodes[cid])):
                         self._c8_out.add(cid)
-            if os.environ.get('PVHIP_CONV_F16_C8', '2') == '2' and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
+            if device.conv_f16_c8 == 2 and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
                 self.plan_c8_modules(conv_plugin)
         self.order_for_locality()
 
@@ -731,6 +732,9 @@ class Executable_Network:
         blocked buffer (`_c8_concat`).  The tensor the first module reads is converted once (`_c8_entry`).  A reader that does not take
         the blocked layout densifies by itself (device.as_device): only writers need this plan."""
         G = self.ienet.G
+        pool_plugin, lrn_plugin = (self.ienet.ie.plugins.plugins.get(t) for t in ('MaxPool', 'LRN'))
+        pool_plugin = pool_plugin if hasattr(pool_plugin, 'blocked_ok') else None
+        lrn_plugin = lrn_plugin if hasattr(lrn_plugin, 'blocked_ok') else None
         src_of = lambda nid: next((p_ for p_ in G.pred[nid] if G.edges[(p_, nid)]['connection'][3] == 0), None)   # noqa: E731
         blocked = set()
         for cid in self._c8_out:
@@ -759,11 +763,14 @@ class Executable_Network:
             node = G.nodes[nid]
             if node['type'] == 'MaxPool':
                 src = src_of(nid)
-                if src in blocked and tuple(common_def.string_to_tuple(node['data']['kernel'])) == (3, 3) and nid not in self._lrn_pool.values():
+                folded = G.nodes[self._lrn_pool[nid]] if nid in self._lrn_pool else None
+                # MaxPool.blocked_ok / LRN.blocked_ok: the predicates the plugins themselves decide with at run time
+                if src in blocked and nid not in self._lrn_pool.values() and pool_plugin is not None and pool_plugin.blocked_ok(node, folded):
                     blocked.add(nid)          # the plugin pools a blocked tensor as it is (a folded pool hands its input on)
                     if nid in self._lrn_pool:
                         blocked.add(self._lrn_pool[nid])      # MaxPool + LRN on the blocked tensor: the folded LRN carries it
-            elif node['type'] == 'LRN' and nid in self._lrn_pool and src_of(nid) in blocked:
+            elif node['type'] == 'LRN' and nid in self._lrn_pool and src_of(nid) in blocked and lrn_plugin is not None \
+                    and lrn_plugin.blocked_ok(node, G.nodes[self._lrn_pool[nid]]):
                 blocked.add(self._lrn_pool[nid])              # LRN + MaxPool on a blocked tensor: the folded MaxPool carries it
             elif node['type'] == 'Concat' and nid in self._concat_direct:
                 members = members_of.get(nid, [])

@@ -110,6 +110,8 @@ def c8_reader_ok(node: dict) -> bool:
         if len(xd) != 4 or len(wd) != 4 or wd[1] != xd[1] or tuple(pb) != tuple(pe):
             return False
         oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
+        if 2 * int(xd[0]) * (-(-int(xd[1]) // 16) * 16) * int(xd[2]) * int(xd[3]) >= 2 ** 31 or int(xd[0]) * int(wd[0]) * oh * ow >= 2 ** 31:
+            return False       # (32-bit offsets in the kernel; the query does not know n)
         return bool(dev.call('pvhip_conv2d_f16_c8_supported', int(xd[1]), int(xd[2]), int(xd[3]), int(wd[2]), int(wd[3]), strides[0], strides[1],
                              pb[0], pb[1], oh, ow))
     except (KeyError, ValueError, AssertionError, IndexError):
@@ -158,6 +160,8 @@ def launch_c8(node, xb, w, bias=None, act=None, into=None):
 def c8_multi_ok(x_shape, kh: int, kw: int, pool: bool, n_members: int) -> bool:
     """True when pvhip_conv2d_f16_c8_multi covers a launch of n_members convolutions with this window over a blocked input of this shape."""
     n, c, h, wd = x_shape
+    if 2 * int(n) * (-(-int(c) // 16) * 16) * int(h) * int(wd) >= 2 ** 31:
+        return False       # (the launch addresses its input with 32-bit byte offsets; the query does not know n)
     return bool(dev.call('pvhip_conv2d_f16_c8_multi_supported', int(c), int(h), int(wd), int(kh), int(kw), 1 if pool else 0, int(n_members)))
 
 
@@ -283,14 +287,38 @@ def pre_add_fusable(node: dict, add_node: dict, const_node: dict, f16: bool = Fa
         return False
 
 
+def f16_route(c, h, wd, kh, kw, strides, pads_begin, oh, ow):
+    """(span kernel, f16 form of the LDS-DMA kernel) -- which f16 kernel launch() runs a dense-input layer of an FP16 IR on; neither: the first
+    (gather) f16 kernel.  Settings and libpvhip's _supported queries only (no device needed)."""
+    span_ok = dev.conv_f16_span >= (2 if kh == 1 else 1) and bool(dev.call(
+        'pvhip_conv2d_f16_span_supported', c, h, wd, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
+    return span_ok, (not span_ok) and dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
+
+
+def f16_stem_row(c, h, wd, kn, kh, kw, strides, pads_begin, pads_end, oh, ow) -> int:
+    """Row length (floats) of the padded image pvhip_conv2d_f16_stem wants for this layer, 0 when the row-span kernel does not cover it."""
+    if not dev.conv_f16_stem or tuple(pads_begin) != tuple(pads_end):
+        return 0
+    return int(dev.call('pvhip_conv2d_f16_stem_supported', c, h, wd, kn, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
+
+
 def c8_dma_writer_ok(node: dict) -> bool:
-    """True when the f16 form of the LDS-DMA kernel runs this Convolution node and can therefore store its output as dev.BlockedHalf
-    (pvhip_conv2d_f16_dma_c8): any window of fewer than 64 taps or C % 16 == 0 (GoogLeNet's conv1)."""
+    """True when launch(..., out_c8=True) stores this Convolution node's output as dev.BlockedHalf: the row-span kernel (GoogLeNet's conv1:
+    pvhip_conv2d_f16_stem) or the f16 form of the LDS-DMA kernel (pvhip_conv2d_f16_dma_c8) runs it.  The SAME route as launch() takes --
+    f16_stem_row / f16_route -- so a layer the span kernel is preferred for (a dense fp32 output) is not planned blocked."""
     try:
-        xd, wd = node['input'][0]['dims'], node['input'][1]['dims']
-        return len(xd) == 4 and len(wd) == 4 and wd[1] == xd[1] and dev.conv_f16_dma and \
-            bool(dev.call('pvhip_conv2d_f16_dma_supported', int(xd[1]), int(wd[2]), int(wd[3])))
-    except (KeyError, ValueError, AssertionError, IndexError):
+        attrs, xd, wd = node['data'], node['input'][0]['dims'], node['input'][1]['dims']
+        if len(xd) != 4 or len(wd) != 4 or wd[1] != xd[1]:
+            return False
+        strides, pb, pe = (common_def.string_to_tuple(attrs[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+        oh, ow = calc_output_shape(xd[2:], wd[2:], strides, pb, pe, 'floor', attrs['auto_pad'])
+        if oh <= 0 or ow <= 0:
+            return False
+        c, h, w_, kn, kh, kw = int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3])
+        if f16_stem_row(c, h, w_, kn, kh, kw, strides, pb, pe, oh, ow) > 0:
+            return True
+        return f16_route(c, h, w_, kh, kw, strides, pb, oh, ow)[1]
+    except (KeyError, ValueError, AssertionError, IndexError, TypeError):
         return False
 
 
@@ -309,9 +337,11 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     if pre_add is not None:
         pre_add = dev.as_device(pre_add)
         assert pre_add.size == c
-    if f16 and out_c8 and into is None and (act is None or act[0] == 'relu') and dev.conv_f16_stem and tuple(pads_begin) == tuple(pads_end):
+    if f16 and out_c8 and into is None and (act is None or act[0] == 'relu'):
         # FP16 IRs: a 7x7 / 2 convolution over three channels with a blocked fp16 output (GoogLeNet's conv1) from row spans of the padded image
-        wps = int(dev.call('pvhip_conv2d_f16_stem_supported', c, h, wd, kn, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
+        wps = f16_stem_row(c, h, wd, kn, kh, kw, strides, pads_begin, pads_end, oh, ow)
+        if wps > 0 and (4 * n * c * hp * wps >= 2 ** 31 or n * 64 * oh * ow >= 2 ** 31):
+            wps = 0        # (the kernel addresses its input with 32-bit byte offsets and the query does not know n: the LDS-DMA form takes it)
         if wps > 0:
             xp = dev.DeviceTensor.empty((n, c, hp, wps))
             dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
@@ -330,10 +360,8 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     route_key = (dev.settings_serial, x.shape, w.shape, tuple(strides), tuple(pads_begin), tuple(pads_end), bool(f16))
     route = node.get('_hip_route')
     if route is None or route[0] != route_key:
-        span_ok = f16 and dev.conv_f16_span >= (2 if kh == 1 else 1) and bool(dev.call(
-            'pvhip_conv2d_f16_span_supported', c, h, wd, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
-        route = (route_key, prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16), span_ok,
-                 f16 and not span_ok and dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw)))
+        span_ok, dma_ok = f16_route(c, h, wd, kh, kw, strides, pads_begin, oh, ow) if f16 else (False, False)
+        route = (route_key, prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16), span_ok, dma_ok)
         node['_hip_route'] = route
     if route[1] or pre_add is not None:
         # The zero-padded image (Convolution.py:64-66) as a tensor of its own, convolved WITHOUT padding: the gather of a layer whose
@@ -561,14 +589,22 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     # FP16 IRs: an input that is fp16 blocked by eight channels (dev.BlockedHalf) goes to the module form (blocked outputs, several members,
     # a MaxPool in front) or to the reader kernel (fp32 output); any other geometry densifies it (the same fp16 values)
     module_path = reader_path = False
-    if isinstance(inputs[0], dev.BlockedHalf) and node.get('_f16_mfma'):
+    if node.get('_f16_mfma'):
         kh_, kw_ = w.shape[2], w.shape[3]
         pad_ = (kh_ - 1) // 2
         same = kh_ == kw_ and tuple(strides) == (1, 1) and tuple(pads_begin) == (pad_, pad_) and tuple(pads_end) == (pad_, pad_)
         into_ = node.get('_out_into')
         pool_ = node.get('_fuse_pool_in') is not None
         sibs_ = node.get('_siblings') or ()
-        wants_module = bool(sibs_) or pool_ or bool(node.get('_out_c8')) or (into_ is not None and isinstance(into_[0], dev.BlockedHalf))
+        blocked_into = (into_ is not None and isinstance(into_[0], dev.BlockedHalf)) or \
+            any(sib.get('into') is not None and isinstance(sib['into'][0], dev.BlockedHalf) for sib in sibs_)
+        if blocked_into and not isinstance(inputs[0], dev.BlockedHalf):
+            # plan_c8_modules gave this launch the module's blocked Concat buffer, but a producer in front of it handed over a dense tensor
+            # after all (a kernel refused its size at launch): convert it here -- the values the reference holds (float16) -- and go on
+            inputs = dict(inputs)
+            inputs[0] = dev.BlockedHalf.from_dense(dev.as_device(inputs[0]))
+    if isinstance(inputs[0], dev.BlockedHalf) and node.get('_f16_mfma'):
+        wants_module = bool(sibs_) or pool_ or bool(node.get('_out_c8')) or blocked_into
         module_path = same and wants_module and c8_multi_ok(inputs[0].shape, kh_, kw_, pool_, 1 + len(sibs_))
         reader_path = not module_path and not sibs_ and not pool_ and c8_reader_ok(node)
     x = inputs[0] if (module_path or reader_path) else dev.as_device(inputs[0])

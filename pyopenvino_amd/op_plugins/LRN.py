@@ -44,6 +44,24 @@ def pool_fusable(node: dict, pool_node: dict) -> bool:
         return False
 
 
+def blocked_ok(node: dict, pool_node: dict) -> bool:
+    """True when compute() runs LRN + MaxPool (node['_fuse_pool'] = pool_node) on a dev.BlockedHalf input as it is and returns a
+    dev.BlockedHalf (FP16 IRs; IR attributes and port dims, no device needed).  The ONE predicate of the plan
+    (Executable_Network.plan_c8_modules) and of compute()."""
+    try:
+        if pool_node is None or int(node['data']['size']) != 5:
+            return False
+        dims = node['input'][0]['dims']
+        if len(dims) != 4:
+            return False
+        h, w = int(dims[2]), int(dims[3])
+        kernel, strides, pads_begin, pads_end, oh, ow = _pool_geometry(pool_node, h, w)
+        return tuple(kernel) == (3, 3) and oh > 0 and ow > 0 and bool(dev.call(
+            'pvhip_lrn_maxpool3x3_c8_supported', h, w, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1], 5))
+    except (KeyError, ValueError, AssertionError, IndexError, TypeError):
+        return False
+
+
 def name():
     print('LRN')
 
@@ -58,18 +76,16 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     bias = float(attrs['bias'])
     size = int(attrs['size'])
     pool_node = node.get('_fuse_pool')
-    if pool_node is not None and isinstance(inputs[0], dev.BlockedHalf) and size == 5:
+    if isinstance(inputs[0], dev.BlockedHalf) and blocked_ok(node, pool_node):
         # FP16 IRs: the input is fp16 blocked by eight channels (what the reference holds here is a float16 tensor): LRN + MaxPool on it as it
         # is, the output is blocked too
         xb = inputs[0]
         n, c, h, w = xb.shape
         kernel, strides, pads_begin, pads_end, oh, ow = _pool_geometry(pool_node, h, w)
-        if tuple(kernel) == (3, 3) and oh > 0 and ow > 0 and dev.call('pvhip_lrn_maxpool3x3_c8_supported', h, w, oh, ow, strides[0], strides[1],
-                                                                     pads_begin[0], pads_begin[1], size):
-            yb = dev.BlockedHalf((n, c, oh, ow))
-            dev.call('pvhip_lrn_maxpool3x3_c8', ctypes.c_void_p(xb.ptr), ctypes.c_void_p(yb.ptr), n, c, h, w, size, alpha, beta, bias, oh, ow,
-                     strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1])
-            return {common_def.first_output_port(node): yb}
+        yb = dev.BlockedHalf((n, c, oh, ow))
+        dev.call('pvhip_lrn_maxpool3x3_c8', ctypes.c_void_p(xb.ptr), ctypes.c_void_p(yb.ptr), n, c, h, w, size, alpha, beta, bias, oh, ow,
+                 strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1])
+        return {common_def.first_output_port(node): yb}
     x = dev.as_device(inputs[0])
     n, c, h, w = x.shape
     if pool_node is not None:

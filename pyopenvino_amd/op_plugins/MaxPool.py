@@ -43,6 +43,25 @@ def lrn_fusable(node: dict, lrn_node: dict) -> bool:
         return False
 
 
+def blocked_ok(node: dict, lrn_node: dict = None) -> bool:
+    """True when compute() pools a dev.BlockedHalf input of this node as it is and returns a dev.BlockedHalf (FP16 IRs; IR attributes
+    and port dims, no device needed): a 3x3 window with a non-empty output, and an LRN folded behind it only over five channels.
+    The ONE predicate of the plan (Executable_Network.plan_c8_modules) and of compute(): what the plan calls blocked IS blocked."""
+    try:
+        attrs = node['data']
+        if tuple(common_def.string_to_tuple(attrs['kernel'])) != (3, 3):
+            return False
+        if lrn_node is not None and int(lrn_node['data']['size']) != 5:
+            return False
+        dims = node['input'][0]['dims']
+        if len(dims) != 4:
+            return False
+        _, _, _, _, oh, ow = _geometry(node, int(dims[2]), int(dims[3]))
+        return oh > 0 and ow > 0
+    except (KeyError, ValueError, AssertionError, IndexError, TypeError):
+        return False
+
+
 def name():
     print('MaxPool')
 
@@ -62,7 +81,7 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     pads_end = common_def.string_to_tuple(attrs['pads_end'])
     kernel = common_def.string_to_tuple(attrs['kernel'])
     lrn_in = node.get('_fuse_lrn')
-    blocked = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and tuple(kernel) == (3, 3) and (lrn_in is None or int(lrn_in['data']['size']) == 5) else None
+    blocked = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and blocked_ok(node, lrn_in) else None
     x = blocked if blocked is not None else dev.as_device(inputs[0])
     n, c, h, w = x.shape
     oh, ow = calc_output_shape((h, w), kernel, strides, pads_begin, pads_end, attrs['rounding_type'], attrs['auto_pad'])

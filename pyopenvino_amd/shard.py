@@ -10,9 +10,11 @@ launcher exports (``python -m torch.distributed.run``, or ``bench.py --gpus N`` 
 ``launch_ranks``).  Nothing here imports torch.
 """
 import ctypes
+import json
 import os
-import pickle
+import secrets
 import socket
+import stat
 import struct
 import tempfile
 import time
@@ -49,9 +51,86 @@ class SingleGroup:
         return float(value)
 
 
+# ---- wire format of the host group: NO pickle (a peer's bytes are never executed).  A frame is a fixed 13-byte header
+# (magic, kind, payload length) and a payload of one of six kinds; arrays travel as a JSON header (dtype string of a plain
+# numeric type, shape) followed by the raw bytes.  What the collectives below exchange is None, bytes (RCCL's unique id), str
+# (an error text), float (timings), numeric ndarrays (row counts, host-gathered Result tensors) and flat lists of those.
+_MAGIC = b'PVHG'
+_HEADER = struct.Struct('<4sBQ')
+_K_NONE, _K_BYTES, _K_STR, _K_FLOAT, _K_ARRAY, _K_LIST = range(6)
+_MAX_FRAME = 1 << 34
+_HELLO = struct.Struct('<4sII32s')          # magic, rank, world, token: fixed size, checked BEFORE anything else is parsed
+_HELLO_REPLY = struct.Struct('<4sBI')       # magic, ok, world
+
+
+def _encode(obj) -> bytes:
+    if obj is None:
+        return _HEADER.pack(_MAGIC, _K_NONE, 0)
+    if isinstance(obj, (bytes, bytearray, memoryview)):
+        raw = bytes(obj)
+        return _HEADER.pack(_MAGIC, _K_BYTES, len(raw)) + raw
+    if isinstance(obj, str):
+        raw = obj.encode('utf-8')
+        return _HEADER.pack(_MAGIC, _K_STR, len(raw)) + raw
+    if isinstance(obj, (bool, int, float, np.floating, np.integer)):
+        return _HEADER.pack(_MAGIC, _K_FLOAT, 8) + struct.pack('<d', float(obj))
+    if isinstance(obj, np.ndarray):
+        if obj.dtype.kind not in 'biuf' or obj.dtype.hasobject:
+            raise TypeError('host group: only plain numeric arrays travel, not dtype {}'.format(obj.dtype))
+        arr = np.ascontiguousarray(obj)
+        head = json.dumps({'dtype': arr.dtype.str, 'shape': list(arr.shape)}).encode('ascii')
+        raw = arr.tobytes()
+        return _HEADER.pack(_MAGIC, _K_ARRAY, 4 + len(head) + len(raw)) + struct.pack('<I', len(head)) + head + raw
+    if isinstance(obj, (list, tuple)):
+        body = struct.pack('<I', len(obj)) + b''.join(_encode(item) for item in obj)
+        return _HEADER.pack(_MAGIC, _K_LIST, len(body)) + body
+    raise TypeError('host group: cannot send a {}'.format(type(obj).__name__))
+
+
+def _decode(buf, at=0):
+    """-> (object, offset behind it); ValueError on anything that is not a well-formed frame."""
+    if len(buf) - at < _HEADER.size:
+        raise ValueError('host group: truncated frame')
+    magic, kind, n = _HEADER.unpack_from(buf, at)
+    at += _HEADER.size
+    if magic != _MAGIC or n > len(buf) - at:
+        raise ValueError('host group: malformed frame')
+    body, end = buf[at:at + n], at + n
+    if kind == _K_NONE and n == 0:
+        return None, end
+    if kind == _K_BYTES:
+        return bytes(body), end
+    if kind == _K_STR:
+        return bytes(body).decode('utf-8'), end
+    if kind == _K_FLOAT and n == 8:
+        return struct.unpack('<d', body)[0], end
+    if kind == _K_ARRAY and n >= 4:
+        (hn,) = struct.unpack_from('<I', body, 0)
+        if hn > n - 4:
+            raise ValueError('host group: malformed array header')
+        head = json.loads(bytes(body[4:4 + hn]).decode('ascii'))
+        dtype = np.dtype(str(head['dtype']))
+        shape = tuple(int(d) for d in head['shape'])
+        if dtype.kind not in 'biuf' or dtype.hasobject or any(d < 0 for d in shape):
+            raise ValueError('host group: refused array of dtype {}'.format(dtype))
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if count * dtype.itemsize != n - 4 - hn:
+            raise ValueError('host group: array payload does not match its header')
+        return np.frombuffer(bytes(body[4 + hn:]), dtype=dtype).reshape(shape).copy(), end
+    if kind == _K_LIST and n >= 4:
+        (count,) = struct.unpack_from('<I', body, 0)
+        items, pos = [], 4
+        for _ in range(count):
+            item, pos = _decode(body, pos)
+            items.append(item)
+        if pos != n:
+            raise ValueError('host group: malformed list')
+        return items, end
+    raise ValueError('host group: unknown frame kind {}'.format(kind))
+
+
 def _send_msg(sock, obj):
-    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
-    sock.sendall(struct.pack('<Q', len(blob)) + blob)
+    sock.sendall(_encode(obj))
 
 
 def _recv_exact(sock, n):
@@ -66,19 +145,60 @@ def _recv_exact(sock, n):
 
 
 def _recv_msg(sock):
-    (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    head = _recv_exact(sock, _HEADER.size)
+    magic, _, n = _HEADER.unpack(head)
+    if magic != _MAGIC or n > _MAX_FRAME:
+        raise ValueError('host group: malformed frame')
+    obj, _ = _decode(memoryview(head + _recv_exact(sock, n)))
+    return obj
+
+
+def _rendezvous_dir():
+    """A directory only this user can enter (0700, owned by us, not a symlink): the rendezvous file of a run lives in it, so no other
+    user can plant a file or a link under the name the ranks will read."""
+    path = os.path.join(tempfile.gettempdir(), 'pvhip_rdv_{}'.format(os.getuid()))
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError('host group: {} is not a private directory of uid {}'.format(path, os.getuid()))
+    return path
+
+
+def _write_private(path, text):
+    """Create `path` anew (never through a link, never over a file somebody else made), mode 0600."""
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+    with os.fdopen(fd, 'w') as f:
+        f.write(text)
+
+
+def _read_private(path):
+    fd = os.open(path, os.O_RDONLY | getattr(os, 'O_NOFOLLOW', 0))
+    with os.fdopen(fd) as f:
+        st = os.fstat(f.fileno())
+        if st.st_uid != os.getuid() or not stat.S_ISREG(st.st_mode):
+            raise PermissionError('host group: {} was not written by uid {}'.format(path, os.getuid()))
+        return f.read(4096)
 
 
 class TcpGroup:
     """HostGroup over plain TCP sockets on one node (a star: rank 0 serves, ranks 1.. connect): rendezvous, barrier, the RCCL unique
-    id, row counts and max-over-ranks timing -- a few hundred bytes per call, never tensors of the data path on a GPU run.  No torch.
+    id, row counts and max-over-ranks timing -- a few hundred bytes per call, never tensors of the data path on a GPU run.  No torch,
+    no pickle: frames of a fixed header and raw bytes (`_encode` / `_decode`), so nothing a peer sends is ever executed.
 
-    Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment, which is what `python -m torch.distributed.run` and
-    `bench.py --gpus N` (its own launcher) both export.  MASTER_PORT itself belongs to the launcher (torchrun keeps its store there),
-    so rank 0 listens on a port the system picks and publishes `host port` in a rendezvous file named after MASTER_PORT and the
-    launcher's pid (all ranks are children of one launcher; PVHIP_RDV_FILE overrides the name).  A stale file of an earlier run is
-    harmless: a rank that cannot connect, or whose hello is not answered with this run's world size, reads the file again."""
+    Reads RANK / WORLD_SIZE / MASTER_PORT from the environment, which is what `python -m torch.distributed.run` and `bench.py --gpus N`
+    (its own launcher) both export.  The design is single-node: rank 0 ALWAYS listens on 127.0.0.1 (whatever MASTER_ADDR says), on a
+    port the system picks -- MASTER_PORT itself belongs to the launcher (torchrun keeps its store there) -- and publishes `port token`
+    in a rendezvous file named after MASTER_PORT and the launcher's pid inside a directory only this user can enter (created 0700,
+    the file O_EXCL | O_NOFOLLOW, 0600; PVHIP_RDV_FILE overrides the name).  A connecting rank sends a fixed-size hello whose token
+    is compared before anything else is parsed.  A stale file of an earlier run is harmless: a rank that cannot connect, or whose hello
+    is not answered with this run's world size, reads the file again."""
 
     def __init__(self, rank=None, world=None, timeout=600.0, rdv_file=None):
         self.rank = int(os.environ['RANK'] if rank is None else rank)
@@ -86,42 +206,40 @@ class TcpGroup:
         if not 0 <= self.rank < self.world:
             raise ValueError('bad rank/world {}/{}'.format(self.rank, self.world))
         self.timeout = float(timeout)
-        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
         port = os.environ.get('MASTER_PORT', '29500')
-        self._rdv = rdv_file or os.environ.get('PVHIP_RDV_FILE') or os.path.join(
-            tempfile.gettempdir(), 'pvhip_rdv_{}_{}_{}'.format(os.getuid(), port, os.getppid()))
         self._peers, self._sock, self._server = {}, None, None
         if self.world == 1:
+            self._rdv = None
             return
+        self._rdv = rdv_file or os.environ.get('PVHIP_RDV_FILE') or os.path.join(
+            _rendezvous_dir(), 'rdv_{}_{}'.format(port, os.getppid()))
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                srv.bind((addr, 0))
-            except OSError:
-                srv.bind(('127.0.0.1', 0))
+            srv.bind(('127.0.0.1', 0))
             srv.listen(self.world)
             srv.settimeout(self.timeout)
             self._server = srv
-            self._token = '{}-{}'.format(os.getpid(), time.time_ns())
+            token = secrets.token_hex(16).encode('ascii')          # 32 bytes
             tmp = '{}.{}'.format(self._rdv, os.getpid())
-            with open(tmp, 'w') as f:
-                f.write('{} {} {}\n'.format(srv.getsockname()[0], srv.getsockname()[1], self._token))
+            _write_private(tmp, '{} {}\n'.format(srv.getsockname()[1], token.decode('ascii')))
             os.replace(tmp, self._rdv)
             while len(self._peers) < self.world - 1:
                 conn, _ = srv.accept()
                 conn.settimeout(self.timeout)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 try:
-                    hello = _recv_msg(conn)
-                except (ConnectionError, OSError, struct.error, pickle.UnpicklingError):
+                    magic, rank_, world_, token_ = _HELLO.unpack(_recv_exact(conn, _HELLO.size))
+                except (ConnectionError, OSError, struct.error):
                     conn.close()
                     continue
-                ok = (isinstance(hello, dict) and hello.get('world') == self.world and hello.get('token') == self._token
-                      and isinstance(hello.get('rank'), int) and 0 < hello['rank'] < self.world and hello['rank'] not in self._peers)
-                _send_msg(conn, {'ok': bool(ok), 'world': self.world})
+                if magic != _MAGIC or not secrets.compare_digest(token_, token):
+                    conn.close()                   # not one of ours: nothing else of what it sent is looked at
+                    continue
+                ok = world_ == self.world and 0 < rank_ < self.world and rank_ not in self._peers
+                conn.sendall(_HELLO_REPLY.pack(_MAGIC, 1 if ok else 0, self.world))
                 if ok:
-                    self._peers[hello['rank']] = conn
+                    self._peers[rank_] = conn
                 else:
                     conn.close()
         else:
@@ -129,17 +247,22 @@ class TcpGroup:
             while True:
                 sock = None
                 try:
-                    with open(self._rdv) as f:
-                        host, rport, token = f.read().split()
-                    sock = socket.create_connection((host, int(rport)), timeout=5.0)
+                    rport, token = _read_private(self._rdv).split()
+                    token = token.encode('ascii')
+                    if len(token) != 32:
+                        raise ValueError('host group: malformed rendezvous file')
+                    sock = socket.create_connection(('127.0.0.1', int(rport)), timeout=5.0)
                     sock.settimeout(self.timeout)
                     sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    _send_msg(sock, {'rank': self.rank, 'world': self.world, 'token': token})
-                    if _recv_msg(sock).get('ok'):
+                    sock.sendall(_HELLO.pack(_MAGIC, self.rank, self.world, token))
+                    magic, ok, world_ = _HELLO_REPLY.unpack(_recv_exact(sock, _HELLO_REPLY.size))
+                    if magic == _MAGIC and ok == 1 and world_ == self.world:
                         self._sock = sock
                         break
                     sock.close()
-                except (OSError, ValueError, ConnectionError, struct.error, pickle.UnpicklingError):
+                except PermissionError:
+                    raise                          # a rendezvous file or directory that is not ours: never retried, never read
+                except (OSError, ValueError, ConnectionError, struct.error):
                     if sock is not None:
                         sock.close()
                 if time.monotonic() > deadline:
@@ -185,7 +308,7 @@ class TcpGroup:
             self._server = None
             try:
                 os.remove(self._rdv)
-            except OSError:
+            except (OSError, TypeError):
                 pass
 
 
@@ -203,7 +326,10 @@ def launch_ranks(argv, world, master_port=None, env=None):
         e = dict(os.environ if env is None else env)
         e.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
                   'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(master_port)})
-        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # RCCL across processes needs dmabuf IPC on this driver
+        # RCCL across processes needs dmabuf IPC on this pool's driver (the image exports this already).  UNVERIFIED on hardware: RCCL has
+        # never run with more than one rank (no multi-GPU node has been available); BatchShardComm sets the same default for ranks that
+        # another launcher (torchrun) started, so both launchers behave alike.
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen(list(argv), env=e))
     rc = 0
     try:
@@ -236,6 +362,10 @@ class BatchShardComm:
         # PVHIP_NO_RCCL=1 forces the host (gloo) gather: for rehearsing the multi-rank path on one GPU
         self.use_rccl = bool(use_rccl) and self.world > 1 and os.environ.get('PVHIP_NO_RCCL') != '1'
         self._rccl_ready = False
+        if self.use_rccl and not dev.is_initialised():
+            # the same default launch_ranks() exports, for ranks torchrun started (read by the HSA runtime when the process first touches
+            # the GPU, so only useful before device.init(); see launch_ranks: unverified with more than one rank)
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     def shard(self, total: int):
         """This rank's slice of a batch of `total` rows.  Every rank calls it with the SAME total (it is how the batch gets

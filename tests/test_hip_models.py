@@ -598,7 +598,7 @@ def _googlenet_fp16_logits(plugin_package, fp16_as_fp32, images, tmp_path):
     return prob, np.asarray(next(iter(net.G.nodes[next(iter(net.G.pred[soft]))]['output'].values()))['data']), net
 
 
-def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp_path):
+def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp_path, monkeypatch):
     """The FP16 entry bench.py times (GoogLeNet as an FP16 IR, Convolution / MatMul on v_mfma_f32_32x32x16_f16 with fp32 accumulation)
     against the REFERENCE's numpy-float16 run of the same IR (googlenet_fp16_rows2.npz: float16 logits of images 500 / 501; its
     float16 SoftMax overflows): logits within 1e-2 of their maximum (the reference rounds every tensor and partial sum to float16; fp32
@@ -606,20 +606,20 @@ def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp
     from pyopenvino_amd import synth
     z = np.load(os.path.join(GOLDEN, 'googlenet_fp16_rows2.npz'))
     images = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
-    os.environ['PVHIP_CONV_F16_C8'] = '1'         # the first step only: the tensors between a 1x1 convolution and the 3x3 / 5x5 behind it
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', '1')         # the first step only: the tensors between a 1x1 convolution and the 3x3 / 5x5 behind it
     try:
         prob16, logits16, net16 = _googlenet_fp16_logits(HIP, False, images, tmp_path)
     finally:
-        del os.environ['PVHIP_CONV_F16_C8']
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', None)
     assert net16.f16_mfma and all('_hip_f16' in net16.G.nodes[n] for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution')
     # the 3x3_reduce / 5x5_reduce tensors are fp16 in HBM (blocked by eight channels) and every 3x3 / 5x5 convolution reads them so
     spatial = [n for n in net16.G.nodes if net16.G.nodes[n]['type'] == 'Convolution' and net16.G.nodes[n]['input'][1]['dims'][2] in (3, 5)]
     assert len(spatial) == 19 and all(net16.G.nodes[n]['_hip_f16'] == 'c8' for n in spatial)
-    os.environ['PVHIP_CONV_F16_C8'] = '0'
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', '0')
     try:
         _, logits_dense, net_dense = _googlenet_fp16_logits(HIP, False, images, tmp_path)
     finally:
-        del os.environ['PVHIP_CONV_F16_C8']
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', None)
     assert not any(net_dense.G.nodes[n]['_hip_f16'] == 'c8' for n in spatial)
     assert_close(logits16, logits_dense, 1e-3, 'fp16 tensors between the convolutions vs fp32 tensors rounded at the reader', elementwise=False)      # the same values, other summation orders, and fp16 roundings that flip behind them
     prob32, logits32, net32 = _googlenet_fp16_logits(HIP, True, images, tmp_path)
@@ -642,9 +642,9 @@ def test_googlenet_fp16_ir_whole_modules_on_blocked_fp16_tensors(hip, tmp_path, 
     from pyopenvino_amd import device, synth
     z = np.load(os.path.join(GOLDEN, 'googlenet_fp16_rows2.npz'))
     images = np.concatenate([synth.uniform_pixels(int(s), (1, 3, 224, 224)) for s in z['image_seeds']], 0)
-    monkeypatch.setenv('PVHIP_CONV_F16_C8', '1')
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', '1')
     _, logits1, _ = _googlenet_fp16_logits(HIP, False, images, tmp_path)
-    monkeypatch.delenv('PVHIP_CONV_F16_C8')         # the default
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', None)         # the default
     from pyopenvino_amd import IECore
     xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
     xml16, blob16 = synth.fp16_ir(xml, synth.synth_weights(xml, 1234), str(tmp_path))
@@ -673,6 +673,38 @@ def test_googlenet_fp16_ir_whole_modules_on_blocked_fp16_tensors(hip, tmp_path, 
     assert err_1 <= 2e-3, err_1
     # a second pass (fresh Concat buffers) gives the same bits
     helpers.assert_bit_exact(helpers.infer_one(ex, net, images), prob, 'second pass')
+
+
+def test_fp16_ir_the_blocked_kernels_do_not_cover_runs_anyway(hip, tmp_path, monkeypatch):
+    """An FP16 IR the blocked-fp16 stem does not cover (GoogLeNet with LRN windows of three channels: neither MaxPool + LRN nor LRN + MaxPool
+    has a blocked form): plan and plugins decide with the same predicates, so the stem stays on fp32 tensors, module 3a's input is
+    converted once and the pass runs -- against the fp32 arithmetic of the same IR (5e-3: one fp16 rounding per tensor).  And the
+    recovery branch of Convolution.compute: a member of a blocked Concat that is handed a DENSE input converts it and goes on."""
+    from pyopenvino_amd import IECore, device, synth
+    import test_host_logic
+    images = np.concatenate([synth.uniform_pixels(500 + i, (1, 3, 224, 224)) for i in range(2)], 0)
+    xml16, blob16 = test_host_logic._googlenet_fp16_ir_with_lrn_size(str(tmp_path), 3)
+    logits = {}
+    for as32 in (False, True):
+        ie = IECore(plugin_package=HIP)
+        net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=as32)
+        net.set_batch(len(images))
+        ex = ie.load_network(net)
+        prob = helpers.infer_one(ex, net, images)
+        assert np.isfinite(prob).all()
+        soft = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'SoftMax')
+        logits[as32] = np.asarray(next(iter(net.G.nodes[next(iter(net.G.pred[soft]))]['output'].values()))['data'])
+        if not as32:
+            assert len(ex._c8_concat) == 9 and len(ex._c8_entry) == 1
+            cat = next(iter(ex._c8_concat))
+            assert isinstance(next(iter(net.G.nodes[cat]['output'].values()))['data'], device.BlockedHalf)
+            # the recovery branch: the tensor module 3a reads, handed over dense although the plan says blocked
+            entry = next(iter(ex._c8_entry))
+            ex._c8_entry.clear()
+            prob2 = helpers.infer_one(ex, net, images)
+            helpers.assert_bit_exact(prob2, prob, 'dense input of a blocked module converted by the convolution itself')
+            ex._c8_entry.add(entry)
+    assert_close(logits[False], logits[True], 5e-3, 'f16 MFMA vs fp32 arithmetic, GoogLeNet FP16 IR with LRN windows of three', elementwise=False)
 
 
 def test_infer_replays_a_hipgraph_by_itself_for_device_resident_inputs(hip, monkeypatch):

@@ -212,10 +212,7 @@ def test_plan_of_an_fp16_ir_keeps_googlenet_on_blocked_fp16_tensors(monkeypatch)
     blob = synth.synth_weights(xml, 1234)
 
     def plan(mode, fp16=True):
-        if mode is None:
-            monkeypatch.delenv('PVHIP_CONV_F16_C8', raising=False)
-        else:
-            monkeypatch.setenv('PVHIP_CONV_F16_C8', mode)
+        helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', mode)      # (reloads the settings: plan and plugins read device.conv_f16_c8)
         ie = IECore(plugin_package='pyopenvino_amd.op_plugins')
         if fp16:
             with tempfile.TemporaryDirectory() as tmp:
@@ -244,6 +241,51 @@ def test_plan_of_an_fp16_ir_keeps_googlenet_on_blocked_fp16_tensors(monkeypatch)
     assert ex0._c8_out == set() and ex0._c8_concat == set()
     _, ex32 = plan(None, fp16=False)
     assert ex32._c8_out == set() and ex32._c8_concat == set() and ex32._c8_entry == set()
+
+
+def _googlenet_fp16_ir_with_lrn_size(tmp, size):
+    """GoogLeNet as an FP16 IR whose two LRN layers take a window of `size` channels (the blocked-fp16 LRN kernels cover five only)."""
+    from pyopenvino_amd import synth
+    xml = os.path.join(MODELS, 'googlenet-v1.xml')
+    xml16, blob16 = synth.fp16_ir(xml, synth.synth_weights(xml, 1234), tmp)
+    text = open(xml16).read()
+    assert text.count('size="5"') == 2
+    with open(xml16, 'w') as f:
+        f.write(text.replace('size="5"', 'size="{}"'.format(size)))
+    return xml16, blob16
+
+
+def test_plan_of_an_fp16_ir_calls_blocked_only_what_the_plugins_will_keep_blocked(monkeypatch, tmp_path):
+    """The plan and the plugins decide with the SAME predicates (MaxPool.blocked_ok, LRN.blocked_ok, Convolution.c8_dma_writer_ok =
+    launch()'s own route).  GoogLeNet as an FP16 IR with LRN windows of THREE channels: neither MaxPool + LRN nor LRN + MaxPool runs on a
+    blocked tensor, so the stem's convolutions must not be planned with blocked outputs (conv1, conv2/3x3 stay fp32 NCHW) and the tensor
+    module 3a reads is converted once (`_c8_entry`), where the default IR (windows of five) keeps everything from conv1 on blocked."""
+    from pyopenvino_amd import IECore
+    from pyopenvino_amd.op_plugins import LRN, MaxPool
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_F16_C8', None)
+    xml16, blob16 = _googlenet_fp16_ir_with_lrn_size(str(tmp_path), 3)
+    ie = IECore(plugin_package='pyopenvino_amd.op_plugins')
+    net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+    net.set_batch(4)
+    ex = ie.load_network(net)
+    G = net.G
+    names = sorted(G.nodes[c]['name'].replace('/WithoutBiases', '') for c in ex._c8_out)
+    assert 'conv1/7x7_s2' not in names and 'conv2/3x3' not in names, names
+    assert len(ex._c8_concat) == 9 and len(ex._c8_entry) == 1           # the modules still run blocked, behind ONE conversion
+    lrns = [n for n in G.nodes if G.nodes[n]['type'] == 'LRN']
+    pools = {n: G.nodes[n] for n in G.nodes if G.nodes[n]['type'] == 'MaxPool'}
+    for lid in lrns:
+        folded = ex._lrn_pool.get(lid)
+        if folded is not None:                                          # LRN + MaxPool launch
+            assert not LRN.blocked_ok(G.nodes[lid], G.nodes[folded])
+    for pid, pnode in pools.items():
+        if pid in ex._lrn_pool:                                         # MaxPool + LRN launch
+            assert not MaxPool.blocked_ok(pnode, G.nodes[ex._lrn_pool[pid]])
+    # the predicates themselves, on IR attributes
+    pool1 = next(p for p in pools.values() if p['name'].startswith('pool1/3x3_s2'))
+    assert MaxPool.blocked_ok(pool1) and not MaxPool.blocked_ok(pool1, {'data': {'size': '3'}}) and MaxPool.blocked_ok(pool1, {'data': {'size': '5'}})
+    odd = dict(pool1, data=dict(pool1['data'], kernel='2, 2'))
+    assert not MaxPool.blocked_ok(odd)
 
 
 def test_stream_plan_orders_every_cross_stream_edge(monkeypatch):

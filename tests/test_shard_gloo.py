@@ -236,7 +236,7 @@ def test_tcp_group_survives_a_stale_rendezvous_file(tmp_path):
     from pyopenvino_amd import shard
     rdv = str(tmp_path / 'rdv')
     with open(rdv, 'w') as f:
-        f.write('127.0.0.1 {} stale-token\n'.format(_free_port()))
+        f.write('{} {}\n'.format(_free_port(), 'a' * 32))
     out, errs = {}, []
 
     def run(rank, delay):
@@ -259,6 +259,94 @@ def test_tcp_group_survives_a_stale_rendezvous_file(tmp_path):
     assert not errs, errs
     assert all(out[r] == (2.0, [10, 11, 12], b'x') for r in range(3)), out
     assert not os.path.exists(rdv)
+
+
+def test_host_group_frames_carry_no_pickle_and_refuse_what_they_do_not_know():
+    """The wire format of TcpGroup (a peer's bytes must never be unpickled): every kind the collectives exchange survives
+    a round trip; object arrays are refused on both sides; malformed, truncated or foreign frames raise ValueError and nothing else."""
+    import pickle
+    from pyopenvino_amd import shard
+    src = open(shard.__file__.replace('.pyc', '.py')).read()
+    assert 'import pickle' not in src and 'pickle.loads' not in src
+    cases = [None, b'\x00\x01raw' * 40, 'error: text \u00e9', 3.5, np.arange(12, dtype=np.int64).reshape(3, 4),
+             np.zeros((0, 1000), dtype=np.float32), [np.float32(1.5) * np.ones((2, 3), dtype=np.float32), None, b'id', 2.0]]
+    for obj in cases:
+        got, end = shard._decode(memoryview(shard._encode(obj)))
+        assert end == len(shard._encode(obj))
+        if isinstance(obj, np.ndarray):
+            assert got.dtype == obj.dtype and got.shape == obj.shape and np.array_equal(got, obj)
+        elif isinstance(obj, list):
+            assert len(got) == len(obj) and np.array_equal(got[0], obj[0]) and got[1] is None and got[2] == b'id' and got[3] == 2.0
+        else:
+            assert got == obj and type(got) is type(obj)
+    with pytest.raises(TypeError):
+        shard._encode(np.array([object()], dtype=object))
+    with pytest.raises(TypeError):
+        shard._encode({'rank': 1})
+    hostile = [pickle.dumps({'rank': 1}), b'PVHG' + bytes([9]) + (0).to_bytes(8, 'little'), shard._encode(b'abc')[:-1],
+               shard._HEADER.pack(b'PVHG', shard._K_ARRAY, 40) + (30).to_bytes(4, 'little') + b'{"dtype": "|O", "shape": [1]}    ' + b'\x00' * 6,
+               shard._HEADER.pack(b'PVHG', shard._K_LIST, 4) + (5).to_bytes(4, 'little')]
+    for blob in hostile:
+        with pytest.raises(ValueError):
+            shard._decode(memoryview(blob))
+
+
+def test_rendezvous_file_is_private_and_never_followed_through_a_link(tmp_path):
+    """rank 0 creates its rendezvous file O_EXCL | O_NOFOLLOW with mode 0600 inside a 0700 directory of its own; a rank refuses a file
+    that is a symbolic link (what another user could plant under a predictable name)."""
+    import stat
+    from pyopenvino_amd import shard
+    d = shard._rendezvous_dir()
+    st = os.lstat(d)
+    assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o077)
+    victim = tmp_path / 'victim'
+    victim.write_text('untouched')
+    link = tmp_path / 'rdv'
+    os.symlink(str(victim), str(link))
+    shard._write_private(str(link), '1234 ' + 'b' * 32)            # the link is replaced, not followed
+    assert victim.read_text() == 'untouched' and not os.path.islink(str(link))
+    assert stat.S_IMODE(os.lstat(str(link)).st_mode) == 0o600 and shard._read_private(str(link)).split()[0] == '1234'
+    os.unlink(str(link))
+    os.symlink(str(victim), str(link))
+    with pytest.raises(OSError):
+        shard._read_private(str(link))
+
+
+def test_tcp_group_ignores_a_stranger_on_its_port(tmp_path):
+    """A client that connects to rank 0's port without this run's token (or with garbage) is dropped; the ranks of the run still meet."""
+    import socket
+    import threading
+    import time
+    from pyopenvino_amd import shard
+    rdv = str(tmp_path / 'rdv')
+    out, errs = {}, []
+
+    def run(rank, delay):
+        try:
+            time.sleep(delay)
+            g = shard.TcpGroup(rank=rank, world=2, timeout=60, rdv_file=rdv)
+            out[rank] = g.allreduce_max(float(rank))
+            g.barrier()
+            g.close()
+        except Exception as exc:      # noqa: BLE001
+            errs.append((rank, exc))
+
+    t0 = threading.Thread(target=run, args=(0, 0.0))
+    t0.start()
+    deadline = time.time() + 30
+    while not os.path.exists(rdv) and time.time() < deadline:
+        time.sleep(0.02)
+    port = int(open(rdv).read().split()[0])
+    for junk in (b'', b'\x80\x04\x95' + b'x' * 60, shard._HELLO.pack(b'PVHG', 1, 2, b'z' * 32)):
+        s = socket.create_connection(('127.0.0.1', port), timeout=5)
+        s.sendall(junk)
+        s.close()
+    t1 = threading.Thread(target=run, args=(1, 0.0))
+    t1.start()
+    for t in (t0, t1):
+        t.join(90)
+    assert not errs, errs
+    assert out == {0: 1.0, 1: 1.0}
 
 
 def test_launch_ranks_exports_the_launcher_contract_and_reports_failures(tmp_path):
