@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   14
+#define PVHIP_ABI_VERSION   15
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -197,6 +197,7 @@ int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
 #define PVHIP_CONV_KIND_WINO_F2_3X3  2
 #define PVHIP_CONV_KIND_WINO_F4_3X3  3
 #define PVHIP_CONV_KIND_WINO_F2_5X5  4
+#define PVHIP_CONV_KIND_STEM         5   /* ABI v15: 7x7 / 2 over three channels from row spans (pvhip_stem.hip)  */
 int    pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
                                 int sh, int sw, int pad_top, int pad_left);
 /* MaxPool.py:41-72 (3x3 window, stride 1, pad 1 all round: output extent = input extent) followed by a 1x1 / stride 1 / unpadded
@@ -333,6 +334,18 @@ size_t pvhip_conv2d_f16_stem_pack_elems(int k_out);
 int    pvhip_conv2d_f16_stem_pack(const float* w_oihw, float* wf, int k_out);
 int    pvhip_conv2d_f16_stem(const float* xp, const float* wf, void* yb, int n, int hp, int wp, int k_out, int oh, int ow,
                              const float* bias, int act);
+/* The same first convolution in fp32 (ABI v15; Convolution.py:57-87: 7x7 / stride 2 / pad 3 over three channels, at most 64 output channels, output
+ * rows of at most 112 pixels and a multiple of four -- GoogLeNet's conv1): from row spans of the padded image, the whole weight tensor resident in
+ * registers, no vector instruction in the reduction loop; the reduction runs over the taps in the reference's own (c, r, s) order.  _supported: 0,
+ * or the floats per row the padded input must have (as pvhip_conv2d_f16_stem_supported); xp: that padded input (n, 3, hp, wp) with
+ * hp >= 2 (oh - 1) + 7, from pvhip_pad2d_f32; wf: _pack of the (k_out, 3, 7, 7) weights (_pack_elems floats); y: (n, k_out, oh, ow) fp32;
+ * bias / act / act_lo / act_hi as pvhip_conv2d_f32.  pvhip_conv2d_kernel_kind answers PVHIP_CONV_KIND_STEM for such a layer
+ * (PVHIP_CONV_STEM=0: never).                                                                                                       */
+int    pvhip_conv2d_stem_f32_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
+size_t pvhip_conv2d_stem_f32_pack_elems(int k_out);
+int    pvhip_conv2d_stem_f32_pack(const float* w_oihw, float* wf, int k_out);
+int    pvhip_conv2d_stem_f32(const float* xp, const float* wf, float* y, int n, int hp, int wp, int k_out, int oh, int ow,
+                             const float* bias, int act, float act_lo, float act_hi);
 /* AvgPool.py:41-59 on a c8 tensor (the window rule of pvhip_avgpool2d_f32); the output is fp32 NCHW. */
 int    pvhip_avgpool_c8(const void* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw);
 /* ... and the other order: LRN over five channels followed by MaxPool 3x3 on a c8 tensor as one launch (LRN.py:10-22 then MaxPool.py:41-72;

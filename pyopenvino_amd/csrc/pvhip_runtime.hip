@@ -36,6 +36,7 @@ void load_settings() {
     s.conv_winograd4 = tri("PVHIP_CONV_WINOGRAD4");
     s.conv_winograd5 = tri("PVHIP_CONV_WINOGRAD5");
     s.conv_pointwise = !is0("PVHIP_CONV_POINTWISE");
+    s.conv_stem      = !is0("PVHIP_CONV_STEM");
     if (const char* e = env("PVHIP_FUSE_POOLCONV")) s.fuse_poolconv = e[0] == '0' ? 0 : (e[0] == '4' ? 4 : (e[0] == '1' ? 1 : 2));
     s.pool3 = !(env("PVHIP_POOL3") != nullptr && num("PVHIP_POOL3", 1) == 0);
     s.stream_nt = num("PVHIP_STREAM_NT", 1);

@@ -265,7 +265,8 @@ def prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end
         return False
     if f16:         # FP16 IRs: the c-major f16 form of the LDS-DMA kernel (every such layer: there is no Winograd or pointwise form in front of it)
         return dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
-    return int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) == 0
+    # (kind 5, the row-span kernel, pads its input in a pass of its own too: the Add in front of the layer rides in that pass just the same)
+    return int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) in (0, 5)
 
 
 def pre_add_fusable(node: dict, add_node: dict, const_node: dict, f16: bool = False) -> bool:
@@ -361,8 +362,33 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     route = node.get('_hip_route')
     if route is None or route[0] != route_key:
         span_ok, dma_ok = f16_route(c, h, wd, kh, kw, strides, pads_begin, oh, ow) if f16 else (False, False)
-        route = (route_key, prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16), span_ok, dma_ok)
+        stem_wps = 0           # fp32: a 7x7 / 2 first convolution over three channels from row spans (pvhip_conv2d_stem_f32): floats per padded row
+        if not f16 and tuple(pads_begin) == tuple(pads_end) and oh > 0 and ow > 0 and \
+                int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) == 5:
+            stem_wps = int(dev.call('pvhip_conv2d_stem_f32_supported', c, h, wd, kn, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
+        route = (route_key, prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16), span_ok, dma_ok, stem_wps)
         node['_hip_route'] = route
+    if route[4] > 0 and into is None:
+        # the zero-padded image in rows of route[4] floats (the per-channel Add in front of the layer rides in the padding pass), then the
+        # row-span kernel: weights resident in registers, no vector instruction in its reduction loop
+        wps = route[4]
+        xp = dev.DeviceTensor.empty((n, c, hp, wps))
+        dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
+                 pads_end[0], wps - wd - pads_begin[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
+        cached = node.get('_hip_wpack_stem32')
+        if cached is None or cached[0] is not w._block:
+            wf = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_stem_f32_pack_elems', kn)),))
+            dev.call('pvhip_conv2d_stem_f32_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wf.ptr), kn)
+            cached = node['_hip_wpack_stem32'] = (w._block, wf)
+        y = dev.DeviceTensor.empty((n, kn, oh, ow))
+        act_code, act_lo, act_hi = 0, 0.0, 0.0
+        if act is not None:
+            act_code = 1 if act[0] == 'relu' else 2
+            if act_code == 2:
+                act_lo, act_hi = float(act[1]), float(act[2])
+        dev.call('pvhip_conv2d_stem_f32', ctypes.c_void_p(xp.ptr), ctypes.c_void_p(cached[1].ptr), ctypes.c_void_p(y.ptr), n, hp, wps, kn, oh, ow,
+                 ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, act_lo, act_hi)
+        return y
     if route[1] or pre_add is not None:
         # The zero-padded image (Convolution.py:64-66) as a tensor of its own, convolved WITHOUT padding: the gather of a layer whose
         # channel count is not a multiple of 16 (conv1: C = 3) then needs no window test -- zero vector instructions per gathered row
@@ -413,7 +439,8 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
 
 
 # pvhip_conv2d_kernel_kind codes -> (family name, fraction of the algorithmic multiply-adds the matrix cores execute)
-KERNEL_KINDS = {0: ('implicit GEMM (LDS-DMA)', 1.0), 1: ('pointwise', 1.0), 2: ('Winograd F(2x2,3x3)', 16.0 / 36.0),
+KERNEL_KINDS = {5: ('row spans (stem)', 148.0 / 147.0),          # four taps per MFMA step: 147 taps in 37 steps, one slot of zero weight
+                0: ('implicit GEMM (LDS-DMA)', 1.0), 1: ('pointwise', 1.0), 2: ('Winograd F(2x2,3x3)', 16.0 / 36.0),
                 3: ('Winograd F(4x4,3x3)', 36.0 / 144.0), 4: ('Winograd F(2x2,5x5)', 36.0 / 100.0)}
 
 

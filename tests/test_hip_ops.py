@@ -427,6 +427,48 @@ def test_conv_prepadded_input_is_bit_identical(hip, monkeypatch):
     hip.reload_settings()
 
 
+def test_conv_stem_row_span_kernel_has_the_bits_of_the_general_kernel(hip, monkeypatch):
+    """A 7x7 / 2 / pad 3 first convolution over three channels (GoogLeNet's conv1) runs from row spans of the padded image with its weights
+    resident in registers (pvhip_conv2d_stem_f32, round 5); PVHIP_CONV_STEM=0 keeps it on the general LDS-DMA kernel.  Both reduce over
+    the taps in the reference's (c, r, s) order on the fp32 matrix cores: the same bits -- whole and ragged tiles (output rows not a
+    multiple of four per image), fewer than 64 / 32 / 16 output channels, short rows, every epilogue, the Add in front folded into the
+    padding pass -- and the oracle's result within the path's 1e-4."""
+    from pyopenvino_amd.op_plugins import Convolution
+    cases = [((2, 3, 224, 224), 64, ('relu',)), ((3, 3, 56, 56), 64, None), ((1, 3, 36, 24), 40, ('relu',)), ((5, 3, 30, 32), 7, ('clamp', -0.5, 0.75)),
+             ((9, 3, 14, 8), 17, ('relu',)), ((2, 3, 100, 224), 33, None)]
+    st, pb, pe = (2, 2), (3, 3), (3, 3)
+    for i, (xs, k, act) in enumerate(cases):
+        ws = (k, 3, 7, 7)
+        x, w = rnd(40 + i, xs, 60.0), rnd(50 + i, ws, (2.0 / 147.0) ** 0.5)
+        c_add = rnd(11, (1, 3, 1, 1), 50.0)
+        bias = hip.DeviceTensor.from_numpy(rnd(5, (1, k, 1, 1))) if i != 1 else None
+        outs = {}
+        for mode in ('0', '1'):
+            helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', mode)
+            node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+            node['_fuse_bias'], node['_fuse_act'] = bias, act
+            assert (Convolution.kernel_kind(node)[0] == 'row spans (stem)') == (mode == '1'), (xs, k, Convolution.kernel_kind(node))
+            outs[mode] = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w})))
+            folded = dict(node)
+            folded['_pre_add'] = hip.DeviceTensor.from_numpy(c_add)
+            outs[mode + 'add'] = np.asarray(first_out(hip_plugin('Convolution').compute(folded, {0: x, 1: w})))
+        assert_bit_exact(outs['1'], outs['0'], 'row-span kernel vs general kernel {} k={} {}'.format(xs, k, act))
+        assert_bit_exact(outs['1add'], outs['0add'], 'row-span kernel vs general kernel, Add folded into the padding pass {} k={}'.format(xs, k))
+        plain = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+        want = np.asarray(first_out(oracle_plugin('Convolution').compute(plain, {0: x, 1: w})))
+        if bias is not None:
+            want = want + np.asarray(bias).reshape(1, k, 1, 1)
+        if act is not None:
+            want = np.where(want < 0, 0, want) if act[0] == 'relu' else np.clip(want, act[1], act[2])
+        assert_close(outs['1'], want.astype(np.float32), helpers.REL_TOL, 'row-span kernel vs oracle {} k={}'.format(xs, k))
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', None)
+    # geometries the kernel does not take stay where they were
+    for xs, ws, st_, pb_ in (((2, 3, 33, 29), (20, 3, 7, 7), (2, 2), (3, 3)), ((2, 4, 32, 32), (8, 4, 7, 7), (2, 2), (3, 3)), ((2, 3, 32, 32), (96, 3, 7, 7), (2, 2), (3, 3)),
+                             ((2, 3, 32, 32), (8, 3, 7, 7), (1, 1), (3, 3)), ((1, 3, 32, 480), (8, 3, 7, 7), (2, 2), (3, 3))):
+        node = make_node('Convolution', [np.zeros(xs, np.float32), np.zeros(ws, np.float32)], conv_data(st_, pb_, pb_))
+        assert Convolution.kernel_kind(node)[0] != 'row spans (stem)', (xs, ws)
+
+
 @pytest.mark.parametrize('kernel', ['default'])
 def test_conv_fused_bias_and_activation_bit_exact(hip, monkeypatch, kernel):
     """Fused epilogues (bias, then ReLU or Clamp) of both convolution kernels and of the depthwise kernel equal
