@@ -70,7 +70,8 @@ struct Settings {
     int  wino_shared_lag = 0;              // PVHIP_WINO_SHARED_LAG=1: the second consumer group of the shared-V form starts three stages behind the first (A/B runs: no gain, the ring bounds the stagger anyway)
     int  wino_shared_min_tiles = 2048;      // PVHIP_WINO_SHARED_MIN_TILES: tiles (patch blocks x channel-block pairs) from which the rule picks it for launches of 12-16 stages
     // ---- wrong-on-purpose ablations: honoured only by the diagnostic build (make diag -> libpvhip_diag.so, -DPVHIP_DIAG)
-    int  conv_ablate = 0, wino4_ablate = 0, pw_ablate = 0;
+    int  conv_ablate = 0, wino4_ablate = 0, pw_ablate = 0, stem_ablate = 0;
+    int  tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // PVHIP_TUNE0 .. PVHIP_TUNE7: free knobs of whatever experiment is running (A/B scripts; 0 = the product's choice)
     bool pool3_tuning() const { return pool3_kb != 16 || pool3_stage != 1 || pool3_wg != 0 || pool3_g != 0; }
 };
 const Settings& settings();
@@ -151,7 +152,14 @@ __device__ __forceinline__ void bias_act_n(float (&v)[N], const float (&b)[N], b
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = v[i] + b[i];
     }
-    if (act != 0) {
+    if (act == 1) {
+        // ReLU as ONE instruction per value (round 5): the IEEE 754-2019 maximum with +0.0 (v_maximum3_f32; a NaN stays a NaN).  It differs
+        // from ReLU.py:9-12's np.where(x < 0, 0, x) for one value only, an exact -0.0 (kept there, +0.0 here) -- which a sum that starts from
+        // a +0.0 accumulator can never be (+0.0 + -0.0 = +0.0 under round-to-nearest), nor that sum plus a bias (x + y = -0.0 only for
+        // x = y = -0.0).  The compare-and-select form is three instructions with its wait state, and vector instructions are matrix time.
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = __builtin_elementwise_maximum(v[i], 0.0f);
+    } else if (act != 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = (v[i] < ab.lo) ? ab.lo : v[i];
     }

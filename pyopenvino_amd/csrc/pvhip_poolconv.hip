@@ -37,7 +37,7 @@ struct PoolConvArgs {
     float act_lo, act_hi;
     int y_ctotal, y_coff;
     int prio;             // producers at wave priority 3 (PVHIP_POOLCONV_PRIO=0: everything at 0)
-    int abl;              // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no activation loads, 2 no pooling arithmetic, 4 no MFMAs, 8 no weight copies, 16 no stores
+    int abl;              // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no activation loads, 2 no pooling arithmetic, 4 no MFMAs, 8 no weight copies, 16 no stores, 32 no loads of the outer columns
 };
 
 __device__ __forceinline__ void pc_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
         _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
             if (abl & 1) continue;                                                                               \
             pc_load(ring[it_][r], xr, offv[r], soff);                                                            \
+            if (abl & 32) { edge[it_][r] = 0.0f; continue; }                                                     \
             edge[it_][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offe[r], soff, 0));  \
         }                                                                                                        \
     }
@@ -326,7 +327,8 @@ static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int 
 #ifdef PVHIP_DIAG
     a.abl = settings().conv_ablate;
 #endif
-    const int bm = k_out <= 32 ? 32 : (k_out <= 64 ? 64 : 128);
+    int bm = k_out <= 32 ? 32 : (k_out <= 64 ? 64 : 128);
+    if (settings().tune[0] == 32 || settings().tune[0] == 64) bm = settings().tune[0] < bm ? settings().tune[0] : bm;      // experiment: narrower channel tiles = more workgroups
     a.n_mtiles = (k_out + bm - 1) / bm;
     const int n_ptiles = (a.P + 127) / 128;
     const dim3 grid((unsigned)(a.n_mtiles * n_ptiles)), block(512);

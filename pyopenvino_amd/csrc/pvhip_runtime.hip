@@ -37,6 +37,11 @@ void load_settings() {
     s.conv_winograd5 = tri("PVHIP_CONV_WINOGRAD5");
     s.conv_pointwise = !is0("PVHIP_CONV_POINTWISE");
     s.conv_stem      = !is0("PVHIP_CONV_STEM");
+    for (int i = 0; i < 8; ++i) {
+        char name[16];
+        snprintf(name, sizeof(name), "PVHIP_TUNE%d", i);
+        s.tune[i] = num(name, 0);
+    }
     if (const char* e = env("PVHIP_FUSE_POOLCONV")) s.fuse_poolconv = e[0] == '0' ? 0 : (e[0] == '4' ? 4 : (e[0] == '1' ? 1 : 2));
     s.pool3 = !(env("PVHIP_POOL3") != nullptr && num("PVHIP_POOL3", 1) == 0);
     s.stream_nt = num("PVHIP_STREAM_NT", 1);
@@ -89,6 +94,7 @@ void load_settings() {
     s.conv_ablate  = num("PVHIP_CONV_ABLATE", 0);
     s.wino4_ablate = num("PVHIP_WINO4_ABLATE", 0);
     s.pw_ablate    = num("PVHIP_PW_ABLATE", 0);
+    s.stem_ablate  = num("PVHIP_STEM_ABLATE", 0);
 #endif
     g_settings = s;
 }

@@ -8,7 +8,9 @@
 // its 0.44 ms of MFMAs (0.64 ms, 0.60 of the peak).  Here:
 //   * a workgroup (8 waves, ONE per CU, persistent) owns tiles of four output rows of one image: 13 rows x 3 channels of the padded input
 //     (the plugin's padding pass has written them, data/mean added, rows of WP <= 256 floats) = 39 one-KiB LDS-DMA instructions per tile --
-//     issued for tile t + 1 while tile t is computed (two 39 KB buffers), waited for in front of the epilogue: ONE barrier per tile;
+//     issued for tile t + 1 while tile t is computed (two 39 KB buffers), waited for in front of the epilogue: ONE barrier per tile.
+//     (Two workgroups of four waves and two-row tiles per CU, half a tile apart so that one's stores run beside the other's MFMAs, were
+//     built and measured: 0.70 ms against 0.52 -- the copies of a starting tile queue behind the other workgroup's stores.)
 //   * wave (row wr, channel half hf) computes output row oy0 + wr x 32 channels as D[pixel][channel] on v_mfma_f32_16x16x4_f32: seven
 //     16-pixel groups x two 16-channel tiles = 56 accumulator registers;
 //   * reduction axis = the 147 taps (c, r, s) in the reference's own order (c-major: the bits of the general kernel's ascending chain),
@@ -35,8 +37,8 @@ constexpr int kBufBytes = kCopies * kLdsRow * 4;     // 39936
 constexpr int kTaps  = kC * kKH * kKW;               // 147
 constexpr int kSteps = (kTaps + 3) / 4;              // 37
 constexpr int kNG    = 7;                            // 16-pixel groups per output row: rows of at most 112 pixels
-constexpr int kWaves = 2 * kTR;                      // 8
-constexpr int kThreads = kWaves * kWave;             // 512
+constexpr int kWaves = 2 * kTR;                      // 8: two per SIMD
+constexpr int kThreads = kWaves * kWave;             // 512; ONE workgroup per CU
 constexpr unsigned kOob = 0x80000000u;
 
 struct StemArgs {
@@ -55,6 +57,9 @@ __device__ __forceinline__ float lds_read_f32(unsigned addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) float*>(addr);
 }
 
+// ABL (diagnostic build only; 1-3 wrong on purpose): 1 = no bias / activation / stores (one store per wave keeps the sums alive), 2 = no MFMAs, 3 = no copies after the first tile,
+// 4 = the stores of an instruction go to consecutive 16-byte pieces (lane l: piece l of a KiB; the WRONG places): what coalesced stores would cost
+template <int ABL>
 __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float stem_lds[];          // [2][39][256]
     const int tid  = threadIdx.x;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
     __syncthreads();
     int buf = 0;
     for (;;) {
-        if (tile + 1 < tile_end) issue(tile + 1, buf ^ 1);
+        if (ABL != 3 && tile + 1 < tile_end) issue(tile + 1, buf ^ 1);
         floatx4 acc[kNG][2];
 #pragma unroll
         for (int g = 0; g < kNG; ++g) {
@@ -150,6 +155,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < kNG; ++g) {
+                if (ABL == 2) {
+                    acc[g][0][0] += p[m & 1][g];
+                    continue;
+                }
                 acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[m & 1][g], w[m][0], acc[g][0], 0, 0, 0);
                 acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[m & 1][g], w[m][1], acc[g][1], 0, 0, 0);
             }
@@ -158,7 +167,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
         // this wave's copies for the NEXT tile were issued a whole tile ago: no wait to speak of, and the barrier below then publishes all of them
         lds_dma_wait_all();
         // ---- epilogue: register r of acc[g][t] = pixel 16 g + 4 kq + r of channel 32 hf + 16 t + l15 of output row oy0 + wr
-        {
+        if (ABL == 1) {
+            floatx4 sum = acc[0][0];
+#pragma unroll
+            for (int g = 0; g < kNG; ++g) sum += acc[g][1] + (g ? acc[g][0] : acc[g][1]);
+            if (sum[0] == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, sum), yr, (unsigned)(tid * 16), 0, 0);
+        } else {
             const int img = tile / a.tiles_per_image;
             const int oy  = (tile - img * a.tiles_per_image) * kTR + wr;
             const unsigned plane = (unsigned)(a.OH * a.OW * 4);
@@ -173,31 +187,42 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[g][t][r] = acc[g][t][r] + bias_l[t];
             }
-            if (a.act != 0) {
+            // (each activation stores by itself: merging three register assignments of the 56 sums behind the branches cost ~200 copies and spills)
+            auto store_all = [&]() {
 #pragma unroll
-                for (int g = 0; g < kNG; ++g)
+                for (int t = 0; t < 2; ++t) {
+                    const bool chok = rowok && ch0 + 16 * t < a.K;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[g][t][r] = (acc[g][t][r] < ab.lo) ? ab.lo : acc[g][t][r];
-            }
-            if (a.act == 2) {
-#pragma unroll
-                for (int g = 0; g < kNG; ++g)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[g][t][r] = (acc[g][t][r] > ab.hi) ? ab.hi : acc[g][t][r];
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const bool chok = rowok && ch0 + 16 * t < a.K;
-#pragma unroll
-                for (int g = 0; g < kNG; ++g) {
-                    const bool ok = chok && 16 * g + 4 * kq < a.OW;
-                    const unsigned vo = ok ? rowb + (unsigned)t * 16u * plane + (unsigned)(g * 64) : kOob;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, acc[g][t]), yr, vo, 0, 0);
+                    for (int g = 0; g < kNG; ++g) {
+                        const bool ok = chok && 16 * g + 4 * kq < a.OW;
+                        unsigned vo = ok ? rowb + (unsigned)t * 16u * plane + (unsigned)(g * 64) : kOob;
+                        if (ABL == 4) vo = (unsigned)((((tile * kWaves + wid) * 2 + t) * kNG + g) * 1024 + lane * 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, acc[g][t]), yr, vo, 0, 0);
+                    }
                 }
+            };
+            if (a.act == 1) {
+                // ReLU as ONE instruction per value (v_maximum3_f32: see bias_act_n in pvhip_common.h -- a sum that starts from +0.0 is never -0.0)
+                const floatx4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int g = 0; g < kNG; ++g)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[g][t] = __builtin_elementwise_maximum(acc[g][t], zero4);
+                store_all();
+            } else if (a.act == 2) {
+#pragma unroll
+                for (int g = 0; g < kNG; ++g)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[g][t][r];
+                            v = (v < ab.lo) ? ab.lo : v;
+                            acc[g][t][r] = (v > ab.hi) ? ab.hi : v;
+                        }
+                store_all();
+            } else {
+                store_all();
             }
         }
         if (++tile >= tile_end) break;
@@ -270,10 +295,23 @@ int pvhip_conv2d_stem_f32(const float* xp, const float* wf, float* y, int n, int
     const int grid = (int)(tiles < kNumCU ? tiles : kNumCU);
     static bool attr_set = false;
     if (!attr_set) {
-        PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
+        PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_stem_f32_kernel, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a);
+#ifdef PVHIP_DIAG
+    switch (settings().stem_ablate) {     // diagnostic build only: wrong on purpose (scripts/time_stem.py)
+    case 1: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
+            hipLaunchKernelGGL(conv_stem_f32_kernel<1>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
+    case 2: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
+            hipLaunchKernelGGL(conv_stem_f32_kernel<2>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
+    case 3: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
+            hipLaunchKernelGGL(conv_stem_f32_kernel<3>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
+    case 4: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
+            hipLaunchKernelGGL(conv_stem_f32_kernel<4>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
+    default: break;
+    }
+#endif
+    hipLaunchKernelGGL(conv_stem_f32_kernel<0>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

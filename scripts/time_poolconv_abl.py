@@ -15,7 +15,7 @@ for name, xs, k in (('3a', (256, 192, 28, 28), 32), ('3b', (256, 256, 28, 28), 6
     wt = dev.DeviceTensor.from_numpy((synth.normal(3, 4, k * c) * (2.0 / c) ** 0.5).astype(np.float32).reshape((k, c, 1, 1)))
     b = dev.DeviceTensor.from_numpy(np.zeros((1, k, 1, 1), dtype=np.float32))
     line = '{:3s} {:4.0f} MB |'.format(name, (x.nbytes + n * k * h * w * 4) / 1e6)
-    for tag, bits in (('whole', 0), ('no loads', 1), ('no pooling', 2), ('no MFMAs', 4), ('no weight copies', 8), ('no stores', 16), ('loop only', 31)):
+    for tag, bits in (('whole', 0), ('no loads', 1), ('no pooling', 2), ('no MFMAs', 4), ('no weight copies', 8), ('no stores', 16), ('no outer-column loads', 32), ('loop only', 31)):
         os.environ['PVHIP_CONV_ABLATE'] = str(bits); dev.reload_settings()
         node = {}
         run = lambda: Convolution.launch_pooled(node, x, wt, bias=b, act=('relu',))
