@@ -346,6 +346,12 @@ size_t pvhip_conv2d_stem_f32_pack_elems(int k_out);
 int    pvhip_conv2d_stem_f32_pack(const float* w_oihw, float* wf, int k_out);
 int    pvhip_conv2d_stem_f32(const float* xp, const float* wf, float* y, int n, int hp, int wp, int k_out, int oh, int ow,
                              const float* bias, int act, float act_lo, float act_hi);
+/* ... and straight from the UNPADDED image x (n, 3, h, w) where w % 4 == 0 and w <= 248 (_direct_supported: 1 / 0): no padding pass at all -- the
+ * zero padding is where the copies land in LDS plus out-of-range lanes and rows; pre_add: one fp32 constant per input channel added to the image
+ * (not to its padding) on the way, or NULL: the Add of a per-channel Const in front of the layer (Add.py:9-14; GoogLeNet's data/mean).           */
+int    pvhip_conv2d_stem_direct_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
+int    pvhip_conv2d_stem_direct_f32(const float* x, const float* wf, float* y, int n, int h, int w, int k_out, int oh, int ow,
+                                    const float* pre_add, const float* bias, int act, float act_lo, float act_hi);
 /* AvgPool.py:41-59 on a c8 tensor (the window rule of pvhip_avgpool2d_f32); the output is fp32 NCHW. */
 int    pvhip_avgpool_c8(const void* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw);
 /* ... and the other order: LRN over five channels followed by MaxPool 3x3 on a c8 tensor as one launch (LRN.py:10-22 then MaxPool.py:41-72;

@@ -46,7 +46,8 @@ struct StemArgs {
     const float* wf;       // [2 halves][37 steps][2 tiles][64 lanes]
     float*       y;        // [N][K][OH][OW]
     const float* bias;
-    int N, HP, WP, OH, OW, K;
+    const float* pre_add;  // DIRECT: one constant per input channel, added to the image (not to its padding) in LDS; or null
+    int N, HP, WP, OH, OW, K;      // DIRECT: HP, WP = the extents of the UNPADDED image (H, W; W % 4 == 0)
     int tiles_per_image, tiles;
     unsigned x_bytes, y_bytes;
     int act;
@@ -59,9 +60,14 @@ __device__ __forceinline__ float lds_read_f32(unsigned addr) {
 
 // ABL (diagnostic build only; 1-3 wrong on purpose): 1 = no bias / activation / stores (one store per wave keeps the sums alive), 2 = no MFMAs, 3 = no copies after the first tile,
 // 4 = the stores of an instruction go to consecutive 16-byte pieces (lane l: piece l of a KiB; the WRONG places): what coalesced stores would cost
-template <int ABL>
+// DIRECT: the image is read as it is -- no padding pass.  A row's copy lands FOUR floats into its LDS row (position p = image column p - 4): the
+// three positions in front of it are the left padding and stay zero (the kernel zeroes LDS once; the only other writer is lane 63 of the row
+// above, whose piece lies past the image: out of range, zeros), lanes past the image write the right padding's zeros, rows above / below
+// the image are out-of-range copies: zeros.  The per-channel constant of an Add in front of the layer (data/mean) is added IN LDS, by the wave
+// that copied the row, to the image's own positions only -- ten packed adds per wave and tile, outside the reduction loop.
+template <int ABL, bool DIRECT>
 __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) float stem_lds[];          // [2][39][256]
+    extern __shared__ __attribute__((aligned(1024))) float stem_lds[];          // [2][39][256] (+ 4 floats: the last row's lane 63 in the DIRECT form)
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
         const int t = min(4 * m + kq, kTaps - 1);
         const int j = t / kKW, s = t - j * kKW;
         const int c = j / kKH, r = j - c * kKH;
-        toff[m] = lds0 + (unsigned)(((c * kRows + kST * wr + r) * kLdsRow + kST * l15 + s) * 4);
+        toff[m] = lds0 + (unsigned)(((c * kRows + kST * wr + r) * kLdsRow + kST * l15 + s + (DIRECT ? 1 : 0)) * 4);
     }
     float bias_l[2] = {0.0f, 0.0f};
     const int ch0 = 32 * hf + l15;
@@ -108,19 +114,48 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
     const ActBounds ab = act_bounds(a.act, a.act_lo, a.act_hi);
     const bool colok = lane * 4 < a.WP;
 
-    // ---- the copies of one tile: instruction i = (channel, row), wave w takes i = w, w + 8, ...; lane l: floats 4 l .. 4 l + 3 of the padded row
+    // ---- the copies of one tile: instruction i = (channel, row), wave w takes i = w, w + 8, ...; lane l: floats 4 l .. 4 l + 3 of the (padded) row
     auto issue = [&](int tl, int buf) {
         const int img = tl / a.tiles_per_image;
-        const int iy0 = (tl - img * a.tiles_per_image) * (kTR * kST);
+        const int iy0 = (tl - img * a.tiles_per_image) * (kTR * kST) - (DIRECT ? kPad : 0);
 #pragma unroll
         for (int i0 = 0; i0 < kCopies; i0 += kWaves) {
             const int i = i0 + wid;
             if (i < kCopies) {
                 const int  c = i / kRows, rr = i - c * kRows;
                 const int  iy = iy0 + rr;
-                const bool ok = colok && iy < a.HP;
+                const bool ok = colok && (unsigned)iy < (unsigned)a.HP;
                 const unsigned vo = ok ? (unsigned)((((img * kC + c) * a.HP + iy) * a.WP + lane * 4) * 4) : kOob;
-                lds_dma_b128(xr, stem_lds + (buf * kCopies + i) * kLdsRow, vo, 0u);
+                lds_dma_b128(xr, stem_lds + (buf * kCopies + i) * kLdsRow + (DIRECT ? 4 : 0), vo, 0u);
+            }
+        }
+    };
+    // DIRECT: the Add in front of the layer, on the rows this wave copied (they have landed: the caller has waited), image positions only;
+    // all reads first, then the adds, then the writes: one LDS round trip per tile, not one per row
+    float* const lds_mean = stem_lds + 2 * kCopies * kLdsRow + 8;       // the three constants live in LDS (registers: none to spare; scalar ones spilled to scratch)
+    auto add_mean = [&](int tl, int buf) {
+        if (!DIRECT || a.pre_add == nullptr) return;
+        const int img = tl / a.tiles_per_image;
+        const int iy0 = (tl - img * a.tiles_per_image) * (kTR * kST) - kPad;
+        constexpr int NR = (kCopies + kWaves - 1) / kWaves;
+        floatx4 v[NR];
+        bool    live[NR];
+        float mcs[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int i = q * kWaves + wid;
+            const int c = i / kRows, rr = i - c * kRows;
+            live[q] = i < kCopies && (unsigned)(iy0 + rr) < (unsigned)a.HP && colok;
+            mcs[q] = lds_mean[i < kCopies ? c : 0];
+            if (live[q]) v[q] = *reinterpret_cast<const floatx4*>(stem_lds + (buf * kCopies + i) * kLdsRow + 4 + lane * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int i = q * kWaves + wid;
+            const float mc = mcs[q];
+            if (live[q]) {
+                v[q][0] = v[q][0] + mc; v[q][1] = v[q][1] + mc; v[q][2] = v[q][2] + mc; v[q][3] = v[q][3] + mc;
+                *reinterpret_cast<floatx4*>(stem_lds + (buf * kCopies + i) * kLdsRow + 4 + lane * 4) = v[q];
             }
         }
     };
@@ -129,8 +164,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
 #pragma unroll
     for (int m = 0; m < kSteps; ++m) asm volatile("" : "+v"(toff[m]));
 
+    if (DIRECT) {          // the left padding of every row (and whatever no copy ever writes) is zero for the whole launch
+        for (int e = tid; e < (2 * kCopies * kLdsRow + 4) / 4; e += kThreads) reinterpret_cast<floatx4*>(stem_lds)[e] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (tid < kC) lds_mean[tid] = a.pre_add != nullptr ? a.pre_add[tid] : 0.0f;
+        __syncthreads();
+    }
     issue(tile, 0);
     lds_dma_wait_all();
+    add_mean(tile, 0);
     __syncthreads();
     int buf = 0;
     for (;;) {
@@ -153,6 +194,13 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
                 for (int g = 0; g < kNG; ++g) p[(m + 1) & 1][g] = lds_read_f32(toff[m + 1] + (unsigned)(g * 16 * kST * 4));
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (DIRECT && m == kSteps / 2 && ABL != 3 && tile + 1 < tile_end) {
+                // half a tile after they were issued this wave's copies of the NEXT tile have landed: the Add in front of the layer on those rows
+                // here, between two steps -- ten packed adds and an LDS round trip that the other waves' MFMAs cover -- not in the epilogue
+                lds_dma_wait_all();
+                add_mean(tile + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < kNG; ++g) {
                 if (ABL == 2) {
@@ -245,6 +293,30 @@ __global__ __launch_bounds__(kBlock) void conv_stem_f32_pack_kernel(const float*
     }
 }
 
+template <bool DIRECT>
+static int stem_launch(StemArgs& a, long tiles) {
+    const int grid = (int)(tiles < kNumCU ? tiles : kNumCU);
+    const size_t lds = (size_t)2 * kBufBytes + (DIRECT ? 64 : 0);          // DIRECT: + the last row's lane 63, + the three constants of the folded Add
+    static bool attr_set = false;
+    if (!attr_set) {
+        PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<0, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+#ifdef PVHIP_DIAG
+#define PVS_ABL(N_)                                                                                                                             \
+    case N_: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<N_, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+             hipLaunchKernelGGL((conv_stem_f32_kernel<N_, DIRECT>), dim3((unsigned)grid), dim3(kThreads), lds, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
+    switch (settings().stem_ablate) {     // diagnostic build only: wrong on purpose (scripts/time_stem_abl.py)
+    PVS_ABL(1) PVS_ABL(2) PVS_ABL(3) PVS_ABL(4)
+    default: break;
+    }
+#undef PVS_ABL
+#endif
+    hipLaunchKernelGGL((conv_stem_f32_kernel<0, DIRECT>), dim3((unsigned)grid), dim3(kThreads), lds, state().stream, a);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -284,7 +356,7 @@ int pvhip_conv2d_stem_f32(const float* xp, const float* wf, float* y, int n, int
     if (n == 0) return PVHIP_OK;
     PVHIP_CHECK_ARG(xp != nullptr && wf != nullptr && y != nullptr);
     StemArgs a;
-    a.xp = xp; a.wf = wf; a.y = y; a.bias = bias;
+    a.xp = xp; a.wf = wf; a.y = y; a.bias = bias; a.pre_add = nullptr;
     a.N = n; a.HP = hp; a.WP = wp; a.OH = oh; a.OW = ow; a.K = k_out;
     a.tiles_per_image = (oh + kTR - 1) / kTR;
     const long tiles = (long)n * a.tiles_per_image;
@@ -292,28 +364,39 @@ int pvhip_conv2d_stem_f32(const float* xp, const float* wf, float* y, int n, int
     a.tiles = (int)tiles;
     a.x_bytes = (unsigned)in_b; a.y_bytes = (unsigned)out_b;
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
-    const int grid = (int)(tiles < kNumCU ? tiles : kNumCU);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
-        attr_set = true;
-    }
-#ifdef PVHIP_DIAG
-    switch (settings().stem_ablate) {     // diagnostic build only: wrong on purpose (scripts/time_stem.py)
-    case 1: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
-            hipLaunchKernelGGL(conv_stem_f32_kernel<1>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
-    case 2: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
-            hipLaunchKernelGGL(conv_stem_f32_kernel<2>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
-    case 3: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
-            hipLaunchKernelGGL(conv_stem_f32_kernel<3>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
-    case 4: PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes));
-            hipLaunchKernelGGL(conv_stem_f32_kernel<4>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a); PVHIP_LAUNCH_CHECK(); return PVHIP_OK;
-    default: break;
-    }
-#endif
-    hipLaunchKernelGGL(conv_stem_f32_kernel<0>, dim3((unsigned)grid), dim3(kThreads), (size_t)2 * kBufBytes, state().stream, a);
-    PVHIP_LAUNCH_CHECK();
-    return PVHIP_OK;
+    return stem_launch<false>(a, tiles);
+}
+
+/* The same layer straight from the UNPADDED image x (n, 3, h, w), w % 4 == 0 and w <= 248: no padding pass -- the zero padding is made by where
+ * the copies land in LDS and by out-of-range lanes and rows.  pre_add: one fp32 constant per input channel added to the image (not to its
+ * padding) on the way, or null -- the Add of a per-channel Const in front of the layer (GoogLeNet's data/mean; Add.py:9-14), the same fp32 add.  */
+int pvhip_conv2d_stem_direct_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow) {
+    if (pvhip_conv2d_stem_f32_supported(c, h, w, k_out, kh, kw, sh, sw, pad_top, pad_left, oh, ow) <= 0) return 0;
+    if (w % 4 != 0 || w + 8 > kLdsRow) return 0;
+    if (kST * (oh - 1) + kKH > h + 2 * kPad || kST * (ow - 1) + kKW > w + 2 * kPad) return 0;     // (pads_end = 3 as well: every tap inside the padded image)
+    return 1;
+}
+
+int pvhip_conv2d_stem_direct_f32(const float* x, const float* wf, float* y, int n, int h, int w, int k_out, int oh, int ow, const float* pre_add,
+                                 const float* bias, int act, float act_lo, float act_hi) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && k_out > 0 && k_out <= 64 && h > 0 && w > 0 && oh > 0 && ow > 0 && act >= 0 && act <= 2);
+    if (!pvhip_conv2d_stem_direct_supported(kC, h, w, k_out, kKH, kKW, kST, kST, kPad, kPad, oh, ow))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_stem_direct_f32: 7x7 / 2 / pad 3 over three channels, rows of a multiple of four and at most 248 pixels");
+    const unsigned long long in_b = (unsigned long long)n * kC * h * w * 4ull, out_b = (unsigned long long)n * k_out * oh * ow * 4ull;
+    if (in_b >= (1ull << 31) || out_b >= (1ull << 31)) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_stem_direct_f32: tensor too large");
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && wf != nullptr && y != nullptr);
+    StemArgs a;
+    a.xp = x; a.wf = wf; a.y = y; a.bias = bias; a.pre_add = pre_add;
+    a.N = n; a.HP = h; a.WP = w; a.OH = oh; a.OW = ow; a.K = k_out;
+    a.tiles_per_image = (oh + kTR - 1) / kTR;
+    const long tiles = (long)n * a.tiles_per_image;
+    if (tiles > 0x3fffffffL) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_stem_direct_f32: too many tiles");
+    a.tiles = (int)tiles;
+    a.x_bytes = (unsigned)in_b; a.y_bytes = (unsigned)out_b;
+    a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
+    return stem_launch<true>(a, tiles);
 }
 
 }  // extern "C"

@@ -113,6 +113,8 @@ SIGNATURES = {
     'pvhip_conv2d_stem_f32_pack_elems': (_c.c_size_t, [_c.c_int]),
     'pvhip_conv2d_stem_f32_pack': (_c.c_int, [_fp, _fp, _c.c_int]),
     'pvhip_conv2d_stem_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 6 + [_fp, _c.c_int, _c.c_float, _c.c_float]),
+    'pvhip_conv2d_stem_direct_supported': (_c.c_int, [_c.c_int] * 12),
+    'pvhip_conv2d_stem_direct_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 6 + [_fp, _fp, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),
     'pvhip_conv2d_pooled_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 5 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_pooled_f16': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 5 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
@@ -130,7 +132,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_conv2d_stem_direct_supported', 'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -205,6 +207,7 @@ settings_serial = 0      # bumped by every reload: host-side plans that bake ker
 conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'      # Convolution plugin: pad the input of a c-major layer in a pass of its own
 conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'    # Convolution plugin, FP16 IRs: the f16 form of the LDS-DMA kernel where it applies
 conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)  # ... and the span kernel before it: 1 = 3x3 / 5x5 layers, 2 = 1x1 too (slower there), 0 = never
+conv_stem_direct = os.environ.get('PVHIP_CONV_STEM_DIRECT', '1') != '0'   # Convolution plugin: the row-span kernel of a 7x7 / 2 first convolution reads the image itself (no padding pass)
 conv_f16_stem = os.environ.get('PVHIP_CONV_F16_STEM', '1') != '0'  # ... and the row-span kernel for a 7x7 / 2 first convolution over three channels with a blocked output
 def _env_level(name, default):
     try:
@@ -222,7 +225,7 @@ fuse_poolconv = _env_level('PVHIP_FUSE_POOLCONV', '2')             # MaxPool + p
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
-    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8, conv_f16_stem, fuse_poolconv
+    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8, conv_f16_stem, fuse_poolconv, conv_stem_direct
     call('pvhip_settings_reload')
     conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'
@@ -230,6 +233,7 @@ def reload_settings():
     conv_f16_c8 = _env_level('PVHIP_CONV_F16_C8', '2')
     fuse_poolconv = _env_level('PVHIP_FUSE_POOLCONV', '2')
     conv_f16_stem = os.environ.get('PVHIP_CONV_F16_STEM', '1') != '0'
+    conv_stem_direct = os.environ.get('PVHIP_CONV_STEM_DIRECT', '1') != '0'
     settings_serial += 1
 
 

@@ -372,9 +372,6 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         # the zero-padded image in rows of route[4] floats (the per-channel Add in front of the layer rides in the padding pass), then the
         # row-span kernel: weights resident in registers, no vector instruction in its reduction loop
         wps = route[4]
-        xp = dev.DeviceTensor.empty((n, c, hp, wps))
-        dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
-                 pads_end[0], wps - wd - pads_begin[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
         cached = node.get('_hip_wpack_stem32')
         if cached is None or cached[0] is not w._block:
             wf = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_stem_f32_pack_elems', kn)),))
@@ -386,6 +383,14 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
             act_code = 1 if act[0] == 'relu' else 2
             if act_code == 2:
                 act_lo, act_hi = float(act[1]), float(act[2])
+        if dev.conv_stem_direct and dev.call('pvhip_conv2d_stem_direct_supported', c, h, wd, kn, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow):
+            # rows of a multiple of four pixels: straight from the image -- no padding pass, the Add in front of the layer happens in LDS
+            dev.call('pvhip_conv2d_stem_direct_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(cached[1].ptr), ctypes.c_void_p(y.ptr), n, h, wd, kn, oh, ow,
+                     ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0), ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, act_lo, act_hi)
+            return y
+        xp = dev.DeviceTensor.empty((n, c, hp, wps))
+        dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
+                 pads_end[0], wps - wd - pads_begin[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
         dev.call('pvhip_conv2d_stem_f32', ctypes.c_void_p(xp.ptr), ctypes.c_void_p(cached[1].ptr), ctypes.c_void_p(y.ptr), n, hp, wps, kn, oh, ow,
                  ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, act_lo, act_hi)
         return y

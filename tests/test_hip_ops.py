@@ -429,7 +429,8 @@ def test_conv_prepadded_input_is_bit_identical(hip, monkeypatch):
 
 def test_conv_stem_row_span_kernel_has_the_bits_of_the_general_kernel(hip, monkeypatch):
     """A 7x7 / 2 / pad 3 first convolution over three channels (GoogLeNet's conv1) runs from row spans of the padded image with its weights
-    resident in registers (pvhip_conv2d_stem_f32, round 5); PVHIP_CONV_STEM=0 keeps it on the general LDS-DMA kernel.  Both reduce over
+    resident in registers (pvhip_conv2d_stem_f32 on a padded copy; pvhip_conv2d_stem_direct_f32 straight from the image: no padding pass, the
+    Add in front of the layer applied in LDS; round 5); PVHIP_CONV_STEM=0 keeps it on the general LDS-DMA kernel.  All reduce over
     the taps in the reference's (c, r, s) order on the fp32 matrix cores: the same bits -- whole and ragged tiles (output rows not a
     multiple of four per image), fewer than 64 / 32 / 16 output channels, short rows, every epilogue, the Add in front folded into the
     padding pass -- and the oracle's result within the path's 1e-4."""
@@ -443,17 +444,21 @@ def test_conv_stem_row_span_kernel_has_the_bits_of_the_general_kernel(hip, monke
         c_add = rnd(11, (1, 3, 1, 1), 50.0)
         bias = hip.DeviceTensor.from_numpy(rnd(5, (1, k, 1, 1))) if i != 1 else None
         outs = {}
-        for mode in ('0', '1'):
+        for mode, direct in (('0', '1'), ('1', '0'), ('1', '1')):       # general kernel; row spans of a padded copy; row spans of the image itself
             helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', mode)
+            helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM_DIRECT', direct)
+            tag = mode + direct
             node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
             node['_fuse_bias'], node['_fuse_act'] = bias, act
             assert (Convolution.kernel_kind(node)[0] == 'row spans (stem)') == (mode == '1'), (xs, k, Convolution.kernel_kind(node))
-            outs[mode] = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w})))
+            outs[tag] = np.asarray(first_out(hip_plugin('Convolution').compute(node, {0: x, 1: w})))
             folded = dict(node)
             folded['_pre_add'] = hip.DeviceTensor.from_numpy(c_add)
-            outs[mode + 'add'] = np.asarray(first_out(hip_plugin('Convolution').compute(folded, {0: x, 1: w})))
-        assert_bit_exact(outs['1'], outs['0'], 'row-span kernel vs general kernel {} k={} {}'.format(xs, k, act))
-        assert_bit_exact(outs['1add'], outs['0add'], 'row-span kernel vs general kernel, Add folded into the padding pass {} k={}'.format(xs, k))
+            outs[tag + 'add'] = np.asarray(first_out(hip_plugin('Convolution').compute(folded, {0: x, 1: w})))
+        for tag, what in (('10', 'row-span kernel (padded copy)'), ('11', 'row-span kernel (the image itself)')):
+            assert_bit_exact(outs[tag], outs['01'], '{} vs general kernel {} k={} {}'.format(what, xs, k, act))
+            assert_bit_exact(outs[tag + 'add'], outs['01add'], '{} vs general kernel, the Add in front folded in {} k={}'.format(what, xs, k))
+        outs['1'] = outs['11']
         plain = make_node('Convolution', [x, w], conv_data(st, pb, pe))
         want = np.asarray(first_out(oracle_plugin('Convolution').compute(plain, {0: x, 1: w})))
         if bias is not None:
@@ -462,6 +467,7 @@ def test_conv_stem_row_span_kernel_has_the_bits_of_the_general_kernel(hip, monke
             want = np.where(want < 0, 0, want) if act[0] == 'relu' else np.clip(want, act[1], act[2])
         assert_close(outs['1'], want.astype(np.float32), helpers.REL_TOL, 'row-span kernel vs oracle {} k={}'.format(xs, k))
     helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM', None)
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM_DIRECT', None)
     # geometries the kernel does not take stay where they were
     for xs, ws, st_, pb_ in (((2, 3, 33, 29), (20, 3, 7, 7), (2, 2), (3, 3)), ((2, 4, 32, 32), (8, 4, 7, 7), (2, 2), (3, 3)), ((2, 3, 32, 32), (96, 3, 7, 7), (2, 2), (3, 3)),
                              ((2, 3, 32, 32), (8, 3, 7, 7), (1, 1), (3, 3)), ((1, 3, 32, 480), (8, 3, 7, 7), (2, 2), (3, 3))):
