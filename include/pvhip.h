@@ -147,6 +147,16 @@ int pvhip_maxpool_lrn_supported(int n, int c, int h, int w, int oh, int ow, int 
                                 int pad_left, int pad_bottom, int pad_right, int size, float beta, float bias);
 int pvhip_maxpool_lrn_f32(const float* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw,
                           int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha, float beta, float bias);
+/* ... and with the 1x1 / stride 1 / unpadded convolution behind the LRN folded in as well (ABI v15; MaxPool.py:41-72, LRN.py:10-22,
+ * Convolution.py:57-87 + the fused bias / activation of pvhip_conv2d_f32; GoogLeNet's pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce): the
+ * normalised value a lane would have stored is its column of a k = 1 outer-product MFMA with that channel's weights -- neither the pooled nor
+ * the normalised tensor exists.  Rows of a multiple of four pixels, bands of at most 256 pooled outputs, c <= 64, k_out <= 64; w_oihw: the
+ * (k_out, c, 1, 1) weights as they are; y: (n, k_out, oh, ow).  The reduction runs over the input channels in ascending order.                */
+int pvhip_maxpool_lrn_conv1x1_supported(int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw, int pad_top,
+                                        int pad_left, int pad_bottom, int pad_right, int size, float beta, float bias, int k_out);
+int pvhip_maxpool_lrn_conv1x1_f32(const float* x, const float* w_oihw, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw,
+                                  int sh, int sw, int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha,
+                                  float beta, float bias, int k_out, const float* conv_bias, int act, float act_lo, float act_hi);
 
 /* ---------------------------------------------------------------- data movement ------------- */
 /* Concat.py:9-13 kernel_Concat_numpy: srcs[i] is viewed as [outer][inner[i]] and copied to

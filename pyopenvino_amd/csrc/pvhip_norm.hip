@@ -444,6 +444,182 @@ __global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_kernel(LrnPoolArgs a, F
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// MaxPool 3x3 -> LRN -> 1x1 convolution (GoogLeNet's pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce, 64 -> 64 channels, + bias + ReLU) in ONE
+// pass (round 5): the LRN tensor (205 MB at batch 256: written once, read once by a convolution that runs at its byte bound, 0.098 ms) never
+// exists either.  maxpool3x3_lrn_kernel already holds, lane by lane, the normalised value of ITS pixel for one channel after the other -- which is
+// exactly the B operand of the k = 1 matrix instruction: v_mfma_f32_32x32x1_2b_f32 adds the outer product A (32 x 1) x B (1 x 32) of each of its two
+// blocks, and block b's B is one value per lane of lanes 32 b .. 32 b + 31.  So a wave does, per input channel c and per 32 output channels,
+// ONE MFMA with A = W[k][c] (a broadcast LDS read of the transposed weights, 16 KB) and B = what it would have stored: D[k][pixel] += W[k][c] *
+// lrn[c][pixel], channel after channel in ascending order -- the reduction order of the pointwise kernel (the bits of the two launches).  No
+// transposition, no staging of an operand tile, no barrier beyond the two the pooling has.  Epilogue: register v of block b at lane (j, h) is
+// output channel 8 (v / 4) + 4 h + v % 4 of the pixel lane 32 b + j owns: that lane's output offset comes over once by a wave shuffle.
+typedef float floatx32 __attribute__((ext_vector_type(32)));
+
+struct PoolLrnConvArgs {
+    LrnPoolArgs  p;           // the pooling / LRN geometry (p.y unused)
+    const float* cw;          // (k_out, c, 1, 1)
+    const float* cbias;       // k_out, or null
+    float*       y;           // (n, k_out, oh, ow)
+    int   k_out, act;
+    float act_lo, act_hi;
+};
+
+template <int BETA_MODE, int ST, int KT>        // KT: 32-channel tiles of the convolution's output (k_out <= 32 KT)
+__global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_conv1x1_kernel(PoolLrnConvArgs ca, FastDiv d_bands, FastDiv d_ow) {
+    constexpr int beta_mode = BETA_MODE;
+    constexpr int SIZE = 5, HALF = SIZE / 2, T = 8, VEC = 4;
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) float planes[];   // [T][plane_l], then the weights [c][32 KT]
+    const LrnPoolArgs& a = ca.p;
+    float* const wl = planes + T * a.plane_l;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int img = (int)fdiv(blockIdx.x, d_bands), band = (int)blockIdx.x - img * a.n_bands;
+    const int oy0 = band * a.band_rows, oy1 = min(a.oh, oy0 + a.band_rows);
+    const int rows_t = oy1 - oy0;
+    const int iy_lo = max(0, oy0 * ST - a.pt), iy_hi = min(a.h, (oy1 - 1) * ST + 3 - a.pt);
+    const int band_px = (iy_hi - iy_lo) * a.w;
+    const int hw = a.h * a.w, ohw = a.oh * a.ow;
+    const bool   active  = tid * VEC < band_px;
+    const size_t cstride = (size_t)hw / VEC;
+    const vec_t* __restrict__ xv =
+        reinterpret_cast<const vec_t*>(a.x + (size_t)img * a.c * hw + (size_t)iy_lo * a.w + (active ? tid * VEC : 0));
+    float* const mine = planes + tid * VEC;
+    const int    n_chunks = a.c / T;
+    const int    out_pp   = a.band_rows * a.ow;
+
+    // the transposed weights: wl[c][k] = W[k][c], zeros past k_out
+    for (int e = tid; e < a.c * 32 * KT; e += kBlock) {
+        const int c = e / (32 * KT), k = e - c * (32 * KT);
+        wl[e] = k < ca.k_out ? ca.cw[(size_t)k * a.c + c] : 0.0f;
+    }
+
+    unsigned tap[9];
+    unsigned outo;
+    bool     live, zpad;
+    {
+        const unsigned rem = (unsigned)tid;
+        const unsigned oyl = fdiv(rem, d_ow), ox = rem - oyl * (unsigned)a.ow;
+        live = (int)rem < out_pp && (int)oyl < rows_t;
+        const int oy = oy0 + (int)oyl;
+        const int py0 = oy * ST - a.pt, px0 = (int)ox * ST - a.pl;
+        const int c0 = min(max(px0, 0), a.w - 1), c1 = min(max(px0 + 1, 0), a.w - 1), c2 = min(max(px0 + 2, 0), a.w - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int r = (min(max(py0 + k, 0), a.h - 1) - iy_lo) * a.w;
+            tap[3 * k + 0] = live ? (unsigned)(r + c0) * 4u : 0u;
+            tap[3 * k + 1] = live ? (unsigned)(r + c1) * 4u : 0u;
+            tap[3 * k + 2] = live ? (unsigned)(r + c2) * 4u : 0u;
+        }
+        const bool zc = (px0 < 0) || (min((int)ox * ST + 2, a.wp - 1) - a.pl >= a.w);
+        const bool zr = (py0 < 0) || (min(oy * ST + 2, a.hp - 1) - a.pt >= a.h);
+        zpad = zc || zr;
+        outo = live ? (unsigned)(oy * a.ow) + ox : 0xffffffffu;
+    }
+    const char* const planes_b = reinterpret_cast<const char*>(planes);
+    const unsigned plane_bytes = (unsigned)a.plane_l * 4u;
+    const float* const wl_lane = wl + (lane & 31);
+
+    float win[SIZE];
+#pragma unroll
+    for (int q = 0; q < SIZE; ++q) win[q] = 0.0f;
+    floatx32 acc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc[kt][r] = 0.0f;
+
+    // a new pooled value v_ of channel ch_ enters the window; the window is then centred on channel ch_ - HALF, whose normalised value -- what
+    // maxpool3x3_lrn_kernel stores -- is this lane's column of the outer product with that channel's weights (every lane takes part: no branch)
+#define PV_PUSH_MFMA(v_, ch_)                                                                  \
+    {                                                                                          \
+        _Pragma("unroll") for (int q = 0; q + 1 < SIZE; ++q) win[q] = win[q + 1];              \
+        win[SIZE - 1] = (v_);                                                                  \
+        if ((ch_) >= HALF) {                                                                   \
+            float s_ = win[0] * win[0];                                                        \
+            _Pragma("unroll") for (int q = 1; q < SIZE; ++q) s_ = s_ + win[q] * win[q];        \
+            const float d_ = a.bias + a.alpha * s_;                                            \
+            const float o_ = live ? lrn_div(win[HALF], d_, a.beta, beta_mode) : 0.0f;          \
+            const float* const wc_ = wl_lane + ((ch_) - HALF) * (32 * KT);                     \
+            _Pragma("unroll") for (int kt = 0; kt < KT; ++kt)                                  \
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x1f32(wc_[32 * kt], o_, acc[kt], 0, 0, 0); \
+        }                                                                                      \
+    }
+
+    vec_t cur[T], nxt[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) cur[j] = ldnt(xv + (size_t)j * cstride);
+    for (int k = 0; k < n_chunks; ++k) {
+        if (k + 1 < n_chunks) {
+            const vec_t* __restrict__ xn = xv + (size_t)(k + 1) * T * cstride;
+#pragma unroll
+            for (int j = 0; j < T; ++j) nxt[j] = ldnt(xn + (size_t)j * cstride);
+        }
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) *reinterpret_cast<vec_t*>(mine + j * a.plane_l) = cur[j];
+        }
+        __syncthreads();
+        {
+            unsigned pb = 0u;
+#pragma unroll
+            for (int p = 0; p < T; ++p, pb += plane_bytes) {
+                float h[3];                      // row maxima: a NaN IS the maximum (max3_nan), as for np.max
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float v0 = *reinterpret_cast<const float*>(planes_b + pb + tap[3 * q + 0]);
+                    const float v1 = *reinterpret_cast<const float*>(planes_b + pb + tap[3 * q + 1]);
+                    const float v2 = *reinterpret_cast<const float*>(planes_b + pb + tap[3 * q + 2]);
+                    h[q] = max3_nan(v0, v1, v2);
+                }
+                float m = max3_nan(h[0], h[1], h[2]);
+                if (zpad) m = max3_nan(m, 0.0f, 0.0f);
+                PV_PUSH_MFMA(m, k * T + p)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < T; ++j) cur[j] = nxt[j];
+    }
+    // the trailing HALF channels: their windows run past the tensor (zeros)
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) PV_PUSH_MFMA(0.0f, a.c + j)
+#undef PV_PUSH_MFMA
+
+    // ---- epilogue: acc[kt][16 b + v] at lane (j = lane & 31, h = lane >> 5) = output channel 32 kt + 8 (v / 4) + 4 h + v % 4 of the pixel of lane 32 b + j
+    const int h2 = lane >> 5;
+    unsigned outo_b[2];
+    outo_b[0] = (unsigned)__shfl((int)outo, lane & 31, kWave);
+    outo_b[1] = (unsigned)__shfl((int)outo, 32 + (lane & 31), kWave);
+    float* const yimg = ca.y + (size_t)img * ca.k_out * ohw;
+    const ActBounds ab = act_bounds(ca.act, ca.act_lo, ca.act_hi);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        float bv[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int kk = 32 * kt + 8 * (v >> 2) + 4 * h2 + (v & 3);
+            bv[v] = (ca.cbias != nullptr && kk < ca.k_out) ? ca.cbias[kk] : 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float vv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) vv[v] = acc[kt][16 * b + v];
+            bias_act_n<16>(vv, bv, ca.cbias != nullptr, ca.act, ab);
+            if (outo_b[b] != 0xffffffffu) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int kk = 32 * kt + 8 * (v >> 2) + 4 * h2 + (v & 3);
+                    if (kk < ca.k_out) yimg[(size_t)kk * ohw + outo_b[b]] = vv[v];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LRN + MaxPool 3x3 / stride 2 / no padding, WITHOUT A BARRIER (round 4; GoogLeNet's conv2/norm2 -> pool2/3x3_s2).  The workgroup form
 // above spends a third of its time in its pooling phase and 0.076 of its 0.184 ms in the loop and its two barriers per eight channels
 // (scripts/time_lrnpool_abl.py); its loads alone take 0.112 ms.  Here a WAVE is the unit: it owns four pooled rows of one image and a
@@ -826,5 +1002,55 @@ int pvhip_maxpool_lrn_f32(const float* x, float* y, int n, int c, int h, int w, 
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }
+
+// MaxPool (3x3) then LRN then a 1x1 / stride 1 / unpadded convolution (+ bias, activation) as ONE launch (round 5): the MaxPool + LRN geometry of
+// pvhip_maxpool_lrn_f32 with one pooled output per lane (bands of at most 256 outputs), a window of five channels, rows of a multiple of four
+// pixels; at most 64 input and 64 output channels (the transposed weights stay in LDS).
+static bool plan_pool_lrn_conv(int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw, int pt, int pl, int pb, int pr, int size,
+                               float beta, float bias, int k_out, LrnPoolArgs& a, int& bm, size_t& lds) {
+    int vec = 0;
+    if (!plan_lrn_pool(n, c, h, w, size, beta, bias, oh, ow, kh, kw, sh, sw, pt, pl, pb, pr, a, vec, bm, lds)) return false;
+    if (vec != 4 || a.band_rows * ow > kBlock || k_out <= 0 || k_out > 64 || c > 64) return false;
+    if ((unsigned long long)n * k_out * oh * ow >= (1ull << 31)) return false;
+    lds += (size_t)c * 32 * ((k_out + 31) / 32) * sizeof(float);
+    return lds <= 64 * 1024;
+}
+
+int pvhip_maxpool_lrn_conv1x1_supported(int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw, int pad_top, int pad_left,
+                                        int pad_bottom, int pad_right, int size, float beta, float bias, int k_out) {
+    LrnPoolArgs a{};
+    int bm = 0;
+    size_t lds = 0;
+    return plan_pool_lrn_conv(n, c, h, w, oh, ow, kh, kw, sh, sw, pad_top, pad_left, pad_bottom, pad_right, size, beta, bias, k_out, a, bm, lds) ? 1 : 0;
+}
+
+int pvhip_maxpool_lrn_conv1x1_f32(const float* x, const float* w_oihw, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw,
+                                  int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha, float beta, float bias,
+                                  int k_out, const float* conv_bias, int act, float act_lo, float act_hi) {
+    PVHIP_REQUIRE_INIT();
+    PoolLrnConvArgs ca{};
+    int bm = 0;
+    size_t lds = 0;
+    if (!plan_pool_lrn_conv(n, c, h, w, oh, ow, kh, kw, sh, sw, pad_top, pad_left, pad_bottom, pad_right, size, beta, bias, k_out, ca.p, bm, lds))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_maxpool_lrn_conv1x1_f32: shape outside the fused kernel (ask pvhip_maxpool_lrn_conv1x1_supported first)");
+    PVHIP_CHECK_ARG(x != nullptr && w_oihw != nullptr && y != nullptr && act >= 0 && act <= 2);
+    ca.p.x = x; ca.p.y = nullptr; ca.p.alpha = alpha; ca.p.beta = beta; ca.p.bias = bias;
+    ca.cw = w_oihw; ca.cbias = conv_bias; ca.y = y; ca.k_out = k_out; ca.act = act; ca.act_lo = act_lo; ca.act_hi = act_hi;
+    const dim3 grid((unsigned)(n * ca.p.n_bands));
+    const FastDiv d_bands = make_fastdiv((unsigned)ca.p.n_bands), d_ow = make_fastdiv((unsigned)ow);
+    const int kt = (k_out + 31) / 32;
+#define PV_PLC(BM_, ST_, KT_) hipLaunchKernelGGL((maxpool3x3_lrn_conv1x1_kernel<BM_, ST_, KT_>), grid, dim3(kBlock), lds, state().stream, ca, d_bands, d_ow)
+    if (bm == 4) {
+        if (sh == 1) { if (kt == 1) PV_PLC(4, 1, 1); else PV_PLC(4, 1, 2); }
+        else         { if (kt == 1) PV_PLC(4, 2, 1); else PV_PLC(4, 2, 2); }
+    } else {
+        if (sh == 1) { if (kt == 1) PV_PLC(1, 1, 1); else PV_PLC(1, 1, 2); }
+        else         { if (kt == 1) PV_PLC(1, 2, 1); else PV_PLC(1, 2, 2); }
+    }
+#undef PV_PLC
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
 
 }  // extern "C"

@@ -72,6 +72,8 @@ SIGNATURES = {
     'pvhip_lrn_maxpool_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 5 + [_c.c_float] * 3 + [_c.c_int] * 10),
     'pvhip_maxpool_lrn_supported': (_c.c_int, [_c.c_int] * 15 + [_c.c_float, _c.c_float]),
     'pvhip_maxpool_lrn_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 15 + [_c.c_float] * 3),
+    'pvhip_maxpool_lrn_conv1x1_supported': (_c.c_int, [_c.c_int] * 15 + [_c.c_float, _c.c_float, _c.c_int]),
+    'pvhip_maxpool_lrn_conv1x1_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 15 + [_c.c_float] * 3 + [_c.c_int, _fp, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_concat_f32': (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _i64p, _fp, _c.c_int64]),
     'pvhip_pad2d_f32': (_c.c_int, [_fp, _fp] + [_c.c_int] * 8 + [_fp]),
     'pvhip_transpose_f32': (_c.c_int, [_fp, _fp, _c.c_int, _i64p, _i64p]),
@@ -132,7 +134,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_conv2d_stem_direct_supported', 'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_maxpool_lrn_conv1x1_supported', 'pvhip_conv2d_stem_direct_supported', 'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -219,19 +221,21 @@ def _env_level(name, default):
 # ... and fp16 tensors blocked by eight channels: 0 = never, 1 = between a 1x1 convolution and the 3x3 / 5x5 behind it, 2 = whole modules and
 # the stem (Executable_Network.plan_fusion / plan_c8_modules read THIS value, the plugins too: one source for both sides)
 conv_f16_c8 = _env_level('PVHIP_CONV_F16_C8', '2')
-fuse_poolconv = _env_level('PVHIP_FUSE_POOLCONV', '2')             # MaxPool + pool_proj as one launch: 0 = never (what the plan reads; the library parses its own copy)
+fuse_poolconv = _env_level('PVHIP_FUSE_POOLCONV', '2')
+fuse_stem_conv = _env_level('PVHIP_FUSE_STEM_CONV', '1')          # the 1x1 convolution behind MaxPool + LRN in the same launch (0 = two launches)             # MaxPool + pool_proj as one launch: 0 = never (what the plan reads; the library parses its own copy)
 
 
 def reload_settings():
     """Make libpvhip read the PVHIP_* environment variables again (it parses them once, at pvhip_init or at the first
     query that needs them; no device needed)."""
-    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8, conv_f16_stem, fuse_poolconv, conv_stem_direct
+    global settings_serial, conv_prepad, conv_f16_dma, conv_f16_span, conv_f16_c8, conv_f16_stem, fuse_poolconv, conv_stem_direct, fuse_stem_conv
     call('pvhip_settings_reload')
     conv_prepad = os.environ.get('PVHIP_CONV_PREPAD', '1') != '0'
     conv_f16_dma = os.environ.get('PVHIP_CONV_F16_DMA', '1') != '0'
     conv_f16_span = int(os.environ.get('PVHIP_CONV_F16_SPAN', '1') or 0)
     conv_f16_c8 = _env_level('PVHIP_CONV_F16_C8', '2')
     fuse_poolconv = _env_level('PVHIP_FUSE_POOLCONV', '2')
+    fuse_stem_conv = _env_level('PVHIP_FUSE_STEM_CONV', '1')
     conv_f16_stem = os.environ.get('PVHIP_CONV_F16_STEM', '1') != '0'
     conv_stem_direct = os.environ.get('PVHIP_CONV_STEM_DIRECT', '1') != '0'
     settings_serial += 1

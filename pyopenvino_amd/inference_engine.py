@@ -512,6 +512,7 @@ class Executable_Network:
         plugin) never see them because fusion is only planned for this package's plugin."""
         self._fusion, self._fused_away, self._lrn_pool, self._siblings, self._pool_conv = {}, set(), {}, {}, {}
         self._pre_add, self._c8_out, self._c8_concat, self._c8_entry = {}, set(), set(), set()
+        self._stem_conv = {}                 # MaxPool (leading MaxPool + LRN) -> the 1x1 convolution behind the LRN that rides in the same launch
         if 'list_schedule' in self.__dict__:
             self.task_list = list(self.list_schedule)
         if not self.fuse_epilogues:
@@ -660,6 +661,24 @@ class Executable_Network:
                 if len(members) >= 2 and conv_plugin.siblings_fusable([G.nodes[m] for m in members]):
                     self._siblings[members[0]] = members[1:]
                     self._fused_away.update(members[1:])
+        # MaxPool -> LRN (one launch already) whose only reader is a fused 1x1 convolution chain that stands alone (no siblings, no Concat slot):
+        # the convolution rides in that launch too (GoogLeNet: pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce) -- the normalised tensor never
+        # exists; the MaxPool task returns the convolution's output and the chain's ports alias it.  fp32 IRs only.
+        if not f16 and device.fuse_stem_conv != 0 and pool_plugin is not None and getattr(pool_plugin, 'SUPPORTS_FUSED_LRN_CONV', False):
+            for pid, lid in self._lrn_pool.items():
+                if G.nodes[pid]['type'] != 'MaxPool':
+                    continue
+                readers = list(G.successors(lid))
+                if len(readers) != 1 or G.edges[(lid, readers[0])]['connection'][3] != 0:
+                    continue
+                cid = readers[0]
+                f = self._fusion.get(cid)
+                if f is None or G.nodes[cid]['type'] != 'Convolution' or f['into'] is not None or cid in self._siblings or cid in self._fused_away \
+                        or cid in self._pool_conv or cid in self._pre_add:
+                    continue
+                if pool_plugin.lrn_conv_fusable(G.nodes[pid], G.nodes[lid], G.nodes[cid]):
+                    self._stem_conv[pid] = cid
+                    self._fused_away.update(n_ for n_ in (cid, f['add'], f['relu']) if n_ is not None)
         # FP16 IRs on the f16 matrix cores: a fused 1x1 convolution chain whose ONLY reader is a 3x3 / 5x5 convolution that
         # pvhip_conv2d_f16_c8 covers (3x3_reduce -> 3x3, 5x5_reduce -> 5x5) hands its output over as fp16 with the channels blocked by
         # eight (device.BlockedHalf): what the reference holds there is a float16 tensor too (common_def.py:13-17), and the blocked
@@ -880,6 +899,10 @@ class Executable_Network:
                 for nid in (sid, self._fusion[sid]['add'], self._fusion[sid]['relu']):
                     if nid is not None:
                         owner[nid] = lead
+        for pid, cid in self._stem_conv.items():       # the 1x1 convolution chain behind MaxPool + LRN: written by the MaxPool's launch
+            for nid in (cid, self._fusion[cid]['add'], self._fusion[cid]['relu']):
+                if nid is not None:
+                    owner[nid] = pid
 
         folded_adds = {pool_id: src_id for pool_id, src_id in self._pool_conv.values()}      # MaxPools folded into their consumer's fetch
         folded_adds.update({add_id: src_id for add_id, _, src_id in self._pre_add.values()})  # Adds folded into a padding pass
@@ -919,6 +942,9 @@ class Executable_Network:
         position = {t: i for i, t in enumerate(dispatched)}
 
         def tail(task):                  # graph node whose output port carries the tensor the task writes
+            if task in self._stem_conv:
+                f = self._fusion[self._stem_conv[task]]
+                return f['relu'] if f['relu'] is not None else (f['add'] if f['add'] is not None else self._stem_conv[task])
             if task in self._lrn_pool:
                 return self._lrn_pool[task]
             f = self._fusion.get(task)
@@ -1136,6 +1162,14 @@ class Executable_Network:
                 node[fuse_key] = G.nodes[pooled]
             else:
                 node.pop(fuse_key, None)
+            stem_conv = self._stem_conv.get(task)        # the 1x1 convolution behind MaxPool + LRN, in the same launch
+            if stem_conv is not None:
+                sf = self._fusion[stem_conv]
+                wsrc = next(G.edges[(p_, stem_conv)]['connection'] for p_ in G.pred[stem_conv] if G.edges[(p_, stem_conv)]['connection'][3] == 1)
+                node['_fuse_conv'] = {'node': G.nodes[stem_conv], 'w': G.nodes[wsrc[0]]['output'][wsrc[1]]['data'],
+                                      'bias': G.nodes[sf['bias']]['output'][0]['data'], 'act': sf['act']}
+            else:
+                node.pop('_fuse_conv', None)
             plugin = registry.get(node_type)
             if plugin is None:
                 print("ERROR: Operation '{}' (node={}) is not supported.".format(node_type, node['name']))
@@ -1188,6 +1222,12 @@ class Executable_Network:
                 if pooled is not None:           # the folded node's port carries the tensor
                     out = G.nodes[pooled]['output']
                     out[next(iter(out))]['data'] = next(iter(res.values()))
+                if stem_conv is not None:        # ... and so do the ports of the folded convolution chain (what the launch returned IS its output;
+                    sf = self._fusion[stem_conv]  # the pooled and the normalised tensor do not exist: their ports hold it only as a placeholder)
+                    for nid in (stem_conv, sf['add'], sf['relu']):
+                        if nid is not None:
+                            out = G.nodes[nid]['output']
+                            out[next(iter(out))]['data'] = next(iter(res.values()))
         if open_run is not None:
             self._close_run(open_run)
         if plan is not None:

@@ -43,6 +43,33 @@ def lrn_fusable(node: dict, lrn_node: dict) -> bool:
         return False
 
 
+# ... and, behind that LRN, a 1x1 / stride 1 / unpadded convolution with its fused bias / activation as part of the SAME launch: node['_fuse_conv']
+# = {'node': the Convolution's node dict, 'w': its weights, 'bias': its fused bias or None, 'act': its fused activation or None}; what is
+# returned is then the convolution's output.  The engine asks lrn_conv_fusable() first.
+SUPPORTS_FUSED_LRN_CONV = True
+
+
+def lrn_conv_fusable(node: dict, lrn_node: dict, conv_node: dict) -> bool:
+    """True when libpvhip's MaxPool -> LRN -> 1x1 convolution kernel covers this triple (IR attributes and port dims; no device needed)."""
+    try:
+        if not lrn_fusable(node, lrn_node):
+            return False
+        dims = node['input'][0]['dims']
+        n, c, h, w = (int(d) for d in dims)
+        kernel, strides, pads_begin, pads_end, oh, ow = _geometry(node, h, w)
+        ca, xd, wd = conv_node['data'], conv_node['input'][0]['dims'], conv_node['input'][1]['dims']
+        cs, cpb, cpe = (common_def.string_to_tuple(ca[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+        if tuple(wd[2:]) != (1, 1) or tuple(cs) != (1, 1) or tuple(cpb) != (0, 0) or tuple(cpe) != (0, 0) or ca['auto_pad'] not in ('explicit', 'valid'):
+            return False
+        if tuple(xd) != (n, c, oh, ow) or int(wd[1]) != c or conv_node['input'][0]['precision'] != 'FP32':
+            return False
+        la = lrn_node['data']
+        return bool(dev.call('pvhip_maxpool_lrn_conv1x1_supported', n, c, h, w, oh, ow, kernel[0], kernel[1], strides[0], strides[1],
+                             pads_begin[0], pads_begin[1], pads_end[0], pads_end[1], int(la['size']), float(la['beta']), float(la['bias']), int(wd[0])))
+    except (KeyError, ValueError, AssertionError, IndexError, TypeError):
+        return False
+
+
 def blocked_ok(node: dict, lrn_node: dict = None) -> bool:
     """True when compute() pools a dev.BlockedHalf input of this node as it is and returns a dev.BlockedHalf (FP16 IRs; IR attributes
     and port dims, no device needed): a 3x3 window with a non-empty output, and an LRN folded behind it only over five channels.
@@ -103,8 +130,27 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
         return {common_def.first_output_port(node): yb}
     if blocked is not None:
         x = dev.as_device(blocked)
-    y = dev.DeviceTensor.empty((n, c, oh, ow))
     lrn_node = node.get('_fuse_lrn')
+    conv = node.get('_fuse_conv')
+    if lrn_node is not None and conv is not None:
+        # MaxPool -> LRN -> 1x1 convolution (+ bias, activation) as one launch: neither the pooled nor the normalised tensor exists
+        la = lrn_node['data']
+        cw = dev.as_device(conv['w'])
+        cb = dev.as_device(conv['bias']) if conv.get('bias') is not None else None
+        k_out = cw.shape[0]
+        assert tuple(cw.shape[1:]) == (c, 1, 1) and (cb is None or cb.size == k_out)
+        act, act_code, act_lo, act_hi = conv.get('act'), 0, 0.0, 0.0
+        if act is not None:
+            act_code = 1 if act[0] == 'relu' else 2
+            if act_code == 2:
+                act_lo, act_hi = float(act[1]), float(act[2])
+        yc = dev.DeviceTensor.empty((n, k_out, oh, ow))
+        dev.call('pvhip_maxpool_lrn_conv1x1_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(cw.ptr), ctypes.c_void_p(yc.ptr), n, c, h, w, oh, ow,
+                 kernel[0], kernel[1], strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1],
+                 int(la['size']), float(la['alpha']), float(la['beta']), float(la['bias']), k_out, ctypes.c_void_p(cb.ptr if cb is not None else 0),
+                 act_code, act_lo, act_hi)
+        return {common_def.first_output_port(node): yc}
+    y = dev.DeviceTensor.empty((n, c, oh, ow))
     if lrn_node is not None:
         la = lrn_node['data']
         dev.call('pvhip_maxpool_lrn_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(y.ptr), n, c, h, w, oh, ow,

@@ -151,7 +151,8 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
     x = np.concatenate([synth.uniform_pixels(70 + i, (1, 3, 224, 224)) for i in range(2)], 0)
     _, net_f, ex_f = build_network(HIP, 'googlenet-v1', weights=blob, batch=2)
     _, net_u, ex_u = build_network(HIP, 'googlenet-v1', weights=blob, batch=2, fuse=False)
-    assert len(ex_f._fusion) == 57 and len(ex_f._fused_away) == 114 + 9 + 2 + 18 + 7 + 1 and len(ex_f._concat_direct) == 9 and not ex_u._fusion
+    assert len(ex_f._fusion) == 57 and len(ex_f._fused_away) == 114 + 9 + 2 + 18 + 7 + 1 + 1 and len(ex_f._concat_direct) == 9 and not ex_u._fusion
+    assert len(ex_f._stem_conv) == 1 and not ex_u._stem_conv          # conv2/3x3_reduce inside the pool1/3x3_s2 + pool1/norm1 launch (its Add / ReLU were folded away already)
     assert len(ex_f._pre_add) == 1 and not ex_u._pre_add              # data/mean folded into conv1's padding pass
     assert len(ex_f._pool_conv) == 7 and not ex_u._pool_conv           # pool + pool_proj of the 28x28 and 14x14 modules (3a .. 4e) as one launch (the 7x7 ones only with PVHIP_FUSE_POOLCONV=1: slower)
     assert len(ex_f._siblings) == 9 and not ex_u._siblings            # 1x1 + 3x3_reduce + 5x5_reduce of a module as one launch
@@ -162,9 +163,11 @@ def test_fused_epilogue_is_bit_identical_and_aliases(hip):
         fused = next(iter(net_f.G.nodes[cid]['output'].values()))['data']
         relu_u = next(iter(net_u.G.nodes[f['relu']]['output'].values()))['data']
         assert next(iter(net_f.G.nodes[f['relu']]['output'].values()))['data'] is fused
-        if cid in (4, 293):   # first and one late layer (the latter written in place into its Concat): bit for bit
+        if cid in (4, 293) or cid in ex_f._stem_conv.values():   # first and one late layer (the latter written in place into its Concat), and the one inside the MaxPool + LRN launch: bit for bit
             helpers.assert_bit_exact(np.asarray(fused), np.asarray(relu_u), 'fused conv {}'.format(cid))
     for lid, pid in ex_f._lrn_pool.items():   # LRN + MaxPool in one launch == the two launches; the MaxPool's port carries the tensor
+        if lid in ex_f._stem_conv:            # (the 1x1 convolution behind this pair rides in the launch: neither tensor exists, the chain's output was checked above)
+            continue
         port = next(iter(net_f.G.nodes[pid]['output']))
         assert net_f.G.nodes[pid]['output'][port]['data'] is next(iter(net_f.G.nodes[lid]['output'].values()))['data']
         helpers.assert_bit_exact(np.asarray(net_f.G.nodes[pid]['output'][port]['data']),
@@ -705,6 +708,34 @@ def test_fp16_ir_the_blocked_kernels_do_not_cover_runs_anyway(hip, tmp_path, mon
             helpers.assert_bit_exact(prob2, prob, 'dense input of a blocked module converted by the convolution itself')
             ex._c8_entry.add(entry)
     assert_close(logits[False], logits[True], 5e-3, 'f16 MFMA vs fp32 arithmetic, GoogLeNet FP16 IR with LRN windows of three', elementwise=False)
+
+
+def test_googlenet_stem_convolution_rides_in_the_maxpool_lrn_launch(hip, monkeypatch):
+    """pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce (+ bias + ReLU) as ONE launch (plan_fusion: `_stem_conv`; PVHIP_FUSE_STEM_CONV=0: the
+    MaxPool + LRN launch followed by the pointwise convolution): the same bits end to end, one dispatched task fewer, and the folded
+    chain's ports carry the launch's output."""
+    from pyopenvino_amd import synth
+    blob = synth.synth_weights(os.path.join(helpers.MODELS, 'googlenet-v1.xml'), 1234)
+    x = np.concatenate([synth.uniform_pixels(500 + i, (1, 3, 224, 224)) for i in range(3)], 0)
+    out, tasks = {}, {}
+    for mode in ('0', '1'):
+        helpers.setenv(monkeypatch, 'PVHIP_FUSE_STEM_CONV', mode)
+        _, net, ex = build_network(HIP, 'googlenet-v1', weights=blob, batch=3)
+        out[mode] = infer_one(ex, net, x)
+        tasks[mode] = len([t for t in ex.task_list if t not in ex._fused_away])
+        if mode == '1':
+            assert len(ex._stem_conv) == 1
+            (pid, cid), = ex._stem_conv.items()
+            G = net.G
+            assert G.nodes[pid]['name'].startswith('pool1/3x3_s2') and G.nodes[cid]['name'].startswith('conv2/3x3_reduce')
+            f = ex._fusion[cid]
+            got = next(iter(G.nodes[f['relu']]['output'].values()))['data']
+            assert tuple(got.shape) == (3, 64, 56, 56) and got is next(iter(G.nodes[pid]['output'].values()))['data']
+        else:
+            assert not ex._stem_conv
+    assert tasks['1'] == tasks['0'] - 1
+    helpers.assert_bit_exact(out['1'], out['0'], 'GoogLeNet with conv2/3x3_reduce inside the MaxPool + LRN launch')
+    helpers.setenv(monkeypatch, 'PVHIP_FUSE_STEM_CONV', None)
 
 
 def test_infer_replays_a_hipgraph_by_itself_for_device_resident_inputs(hip, monkeypatch):

@@ -911,6 +911,57 @@ def test_fused_maxpool_lrn_has_the_bits_of_the_two_launches(hip, xs, st, pb, pe,
     assert_bit_exact(got, two, 'fused MaxPool+LRN vs two launches {}'.format(xs))
 
 
+@pytest.mark.parametrize('xs,st,pb,pe,rounding,k_out,act', [
+    ((2, 64, 112, 112), (2, 2), (0, 0), (0, 0), 'ceil', 64, ('relu',)),      # GoogLeNet pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce
+    ((3, 16, 24, 20), (2, 2), (0, 0), (0, 0), 'ceil', 40, None),             # ragged band, output channels that end inside a 32-channel tile
+    ((1, 24, 12, 16), (1, 1), (1, 1), (1, 1), 'floor', 8, ('clamp', -0.25, 0.5)),
+    ((2, 64, 30, 28), (2, 2), (0, 0), (0, 0), 'ceil', 33, ('relu',)),
+])
+def test_fused_maxpool_lrn_conv1x1_has_the_bits_of_the_two_launches(hip, xs, st, pb, pe, rounding, k_out, act):
+    """3x3 MaxPool -> LRN -> 1x1 convolution (+ bias, activation) as ONE launch (node['_fuse_lrn'] + node['_fuse_conv'], round 5): the
+    normalised value a lane holds is its column of a k = 1 outer-product MFMA with that channel's weights.  Bit for bit what MaxPool + LRN
+    followed by the pointwise convolution launch give (the same ascending-channel fma chain), and the oracle's three nodes within 1e-4."""
+    x = rnd(sum(xs), xs, 40.0)
+    axes = np.array([1], dtype=np.int64)
+    pool_node = make_node('MaxPool', [x], pool_data((3, 3), st, pb, pe, rounding))
+    pooled = first_out(oracle_plugin('MaxPool').compute(pool_node, {0: x}, kernel_type='special'))
+    lrn_node = make_node('LRN', [pooled, axes], {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'})
+    normed = first_out(oracle_plugin('LRN').compute(lrn_node, {0: pooled, 1: axes}, kernel_type='special'))
+    lrn_node['output'][2]['dims'] = tuple(normed.shape)
+    w = rnd(7, (k_out, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5)
+    bias = rnd(9, (1, k_out, 1, 1))
+    conv_node = make_node('Convolution', [normed, w], conv_data((1, 1), (0, 0), (0, 0)))
+    want = first_out(oracle_plugin('Convolution').compute(conv_node, {0: normed, 1: w}, kernel_type='special')) + bias
+    if act is not None:
+        want = np.where(want < 0, 0, want) if act[0] == 'relu' else np.clip(want, act[1], act[2])
+    pool_plugin = hip_plugin('MaxPool')
+    assert pool_plugin.lrn_conv_fusable(pool_node, lrn_node, conv_node)
+    two_node = dict(pool_node)
+    two_node['_fuse_lrn'] = lrn_node
+    two_a = first_out(pool_plugin.compute(two_node, {0: x}))
+    cn = dict(conv_node)
+    cn['_fuse_bias'], cn['_fuse_act'] = hip.DeviceTensor.from_numpy(bias), act
+    two = np.asarray(first_out(hip_plugin('Convolution').compute(cn, {0: two_a, 1: w})))
+    fused_node = dict(two_node)
+    fused_node['_fuse_conv'] = {'node': conv_node, 'w': w, 'bias': hip.DeviceTensor.from_numpy(bias), 'act': act}
+    got = np.asarray(first_out(pool_plugin.compute(fused_node, {0: x})))
+    assert got.shape == want.shape
+    assert_close(got, want.astype(np.float32), helpers.REL_TOL, 'fused MaxPool+LRN+1x1 {}'.format(xs))
+    assert_bit_exact(got, two, 'fused MaxPool+LRN+1x1 vs two launches {}'.format(xs))
+    # a NaN in the input poisons exactly what it poisons in the two launches
+    x2 = x.copy()
+    x2[0, 1, 2, 3] = np.nan
+    two_b = np.asarray(first_out(hip_plugin('Convolution').compute(dict(cn), {0: first_out(pool_plugin.compute(dict(two_node), {0: x2})), 1: w})))
+    got_b = np.asarray(first_out(pool_plugin.compute(dict(fused_node), {0: x2})))
+    assert np.isnan(got_b).any() and np.array_equal(np.isnan(got_b), np.isnan(two_b))
+    assert_bit_exact(np.nan_to_num(got_b), np.nan_to_num(two_b), 'fused MaxPool+LRN+1x1 vs two launches, a NaN in the input {}'.format(xs))
+    # what the kernel does not cover is declined: more than 64 channels either side, a 3x3 convolution, a stride
+    big = make_node('Convolution', [normed, np.zeros((96, xs[1], 1, 1), np.float32)], conv_data((1, 1), (0, 0), (0, 0)))
+    assert not pool_plugin.lrn_conv_fusable(pool_node, lrn_node, big)
+    k3 = make_node('Convolution', [normed, np.zeros((8, xs[1], 3, 3), np.float32)], conv_data((1, 1), (1, 1), (1, 1)))
+    assert not pool_plugin.lrn_conv_fusable(pool_node, lrn_node, k3)
+
+
 def test_fused_maxpool_lrn_declines_what_it_does_not_cover(hip):
     pool_plugin = hip_plugin('MaxPool')
     axes = np.array([1], dtype=np.int64)
