@@ -4,7 +4,7 @@
 # the judged summaries under profiles/ via scripts/summarize_profile.py.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

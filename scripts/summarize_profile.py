@@ -15,13 +15,13 @@ import sys
 
 def is_conv(name):
     """The kernels behind the Convolution nodes: implicit GEMM (also with the MaxPool in front folded in), the Winograd forms, the pointwise kernel."""
-    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name
+    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name or 'conv_stem_f32_kernel' in name
 
 
 def conv_family(name):
     """Which convolution kernel: the split of `convolution_kernels` (profiles/<tag>_traffic.json: convolution_kernels_by_family)."""
     for key, fam in (('conv_wino4s_kernel', 'conv_wino4s_kernel'), ('conv_wino4_kernel', 'conv_wino4_kernel'), ('conv_wino_kernel', 'conv_wino_kernel'), ('conv_pw_kernel', 'conv_pw_kernel'),
-                     ('conv_pool1x1_kernel', 'conv_pool1x1_kernel'), ('conv_igemm_dma_kernel', 'conv_igemm_dma_kernel'), ('conv_igemm', 'conv_igemm_other')):
+                     ('conv_pool1x1_kernel', 'conv_pool1x1_kernel'), ('conv_stem_f32_kernel', 'conv_stem_kernel'), ('conv_igemm_dma_kernel', 'conv_igemm_dma_kernel'), ('conv_igemm', 'conv_igemm_other')):
         if key in name:
             return fam
     return None
@@ -62,7 +62,7 @@ def main():
                 conv_total_ns += float(r['TotalDurationNs'])
                 conv_calls += int(r['Calls'])
         if conv_calls:
-            md += ['', '**conv_wino4s_kernel + conv_wino4_kernel + conv_wino_kernel + conv_pw_kernel + conv_igemm_dma_kernel + conv_pool1x1_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
+            md += ['', '**conv_wino4s_kernel + conv_wino4_kernel + conv_wino_kernel + conv_pw_kernel + conv_stem_f32_kernel + conv_igemm_dma_kernel + conv_pool1x1_kernel, all instantiations:** {} launches, {:.3f} ms total, **average {:.2f} us per launch** '
                    '({:.3f} ms per forward pass of {} launches).'.format(conv_calls, conv_total_ns / 1e6, conv_total_ns / conv_calls / 1e3,
                                                                          conv_total_ns / conv_calls * per_pass / 1e6, per_pass)]
     trace = find(os.path.join(raw, 'stats'), '*kernel_trace.csv')
