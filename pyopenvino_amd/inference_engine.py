@@ -76,9 +76,12 @@ class IECore:
         xml, as the reference does) or the blob itself (bytes / uint8 ndarray) when the weights were
         synthesised in memory.  ``fp16_as_fp32``: run an FP16 IR with fp32 tensors AND fp32 arithmetic (constants upcast once
         at load, every FP16 port declared FP32); default: what the plugin package asks for (``COMPUTE_FP32``).  False with a
-        package that declares ``F16_MFMA`` (this one): the tensors are still fp32 in HBM, but Convolution and MatMul round
-        their operands to fp16 and run on the f16 matrix cores with fp32 accumulation (``net.f16_mfma``); with any other
-        package the IR is left as it is (FP16 ports, float16 constants: the reference's own mode)."""
+        package that declares ``F16_MFMA`` (this one): Convolution and MatMul round their operands to fp16 and run on the f16
+        matrix cores with fp32 accumulation (``net.f16_mfma``), and the tensors between them are fp16 in HBM wherever the plan
+        can keep them so (``plan_fusion`` / ``plan_c8_modules``: channels blocked by eight, ``device.BlockedHalf`` -- GoogLeNet
+        from conv1's output to pool5; ``PVHIP_CONV_F16_C8=0``: fp32 NCHW tensors holding fp16 values); the ports stay declared
+        FP32, which is what a reader outside those kernels gets.  With any other package the IR is left as it is (FP16 ports,
+        float16 constants: the reference's own mode)."""
         net = IENetwork(self)
         net.read_IR_Model(model, weights)
         net.parse_IR_XML()

@@ -104,6 +104,63 @@ def test_two_rank_batch_shard_and_gather(tmp_path, kind, total):
         helpers.assert_close(got, want, 1e-6, 'rank {} gathered batch'.format(r))
 
 
+def _parity_worker(rank, world, port, out_dir, kind):
+    """One rank of bench.py's `parity_of_timed_path` branch on a stub device (the oracle plugins on the CPU, the product's Result plugin and
+    gather): GoogLeNet on the seeded weights, this rank's shard = the first two golden images, the gathered Result checked by bench.py's own
+    rows_vs_reference() -- the golden rows of BOTH ranks, at rank * batch in the gathered tensor."""
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
+                       'LOCAL_RANK': str(rank)})
+    sys.path.insert(0, helpers.REPO)
+    import importlib
+    import json
+    import bench
+    from pyopenvino_amd import IECore, shard, synth
+    group = _group(kind)
+    comm = shard.BatchShardComm(group, use_rccl=False)
+    batch = 2
+    lo, hi = comm.shard(batch * world)
+    assert hi - lo == batch
+    golden = np.load(os.path.join(helpers.GOLDEN, 'googlenet_rows8.npz'))
+    ie = IECore(plugin_package='oracle.op_plugins')
+    ie.plugins.plugins['Result'] = importlib.import_module('pyopenvino_amd.op_plugins.Result')   # the product's gather
+    xml = os.path.join(helpers.MODELS, 'googlenet-v1.xml')
+    net = ie.read_network(xml, weights=synth.synth_weights(xml, int(golden['weight_seed'])))
+    net.set_batch(batch)
+    ex = ie.load_network(net, 'CPU')
+    ex.comm = comm
+    x = np.concatenate([synth.uniform_pixels(int(s_), (1, 3, 224, 224)) for s_ in golden['image_seeds'][:batch]], 0)
+    if rank == 1:
+        x = x.copy()                     # (the same golden images on every rank, as bench.py feeds them)
+    gathered = ex.infer({net.inputs[0]['name']: x})[net.outputs[0]['name']]
+    parity = {'checked_requests': 1, 'rows_vs_reference': 0, 'max_norm_error_vs_reference': None, 'worst_element_of_1e-4_allowance': None}
+    bench.rows_vs_reference(gathered, golden['out'], batch, world, batch, parity)
+    # ... and a gathered tensor in which ONE rank's rows are wrong must show: rank 1's shard swapped
+    broken = np.asarray(gathered).copy()
+    broken[batch:] = broken[batch:][::-1]
+    bad = {'rows_vs_reference': 0, 'max_norm_error_vs_reference': None, 'worst_element_of_1e-4_allowance': None}
+    bench.rows_vs_reference(broken, golden['out'], batch, world, batch, bad)
+    group.barrier()
+    with open(os.path.join(out_dir, 'parity{}.json'.format(rank)), 'w') as f:
+        json.dump({'parity': parity, 'bad': bad, 'shape': list(np.asarray(gathered).shape)}, f)
+    group.close()
+
+
+@pytest.mark.parametrize('kind', ['tcp', 'gloo'])
+def test_two_rank_parity_of_the_timed_path_sees_both_ranks_golden_rows(tmp_path, kind):
+    """bench.py's check of the gathered Result against the reference's recorded answers, with two ranks (CPU stub device): the golden rows of
+    BOTH shards are compared (rows_vs_reference = ranks x rows), they pass at 1e-4 in both norms, and a wrong shard is noticed."""
+    import json
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_parity_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
+    for r in range(world):
+        rec = json.load(open(os.path.join(str(tmp_path), 'parity{}.json'.format(r))))
+        assert rec['shape'] == [4, 1000]
+        p = rec['parity']
+        assert p['rows_vs_reference'] == 4 and p['max_norm_error_vs_reference'] <= 1e-4 and p['worst_element_of_1e-4_allowance'] <= 1.0, p
+        assert rec['bad']['rows_vs_reference'] == 4 and rec['bad']['worst_element_of_1e-4_allowance'] > 1.0, rec['bad']
+
+
 def _fallback_worker(rank, world, port, out_dir, kind):
     os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
                        'LOCAL_RANK': str(rank)})
