@@ -632,6 +632,10 @@ def test_googlenet_fp16_ir_on_the_f16_matrix_cores_vs_reference_float16(hip, tmp
           'from the reference'.format(err_ref, err_32, helpers.rel_err(logits32, z['logits'])))
     assert np.isfinite(prob16).all() and np.array_equal(logits16.argmax(axis=1), z['logits'].argmax(axis=1))
     assert err_ref <= 1e-2, err_ref
+    # ... and element by element (1e-2 |want| + 1e-2 rms(want)): the max-norm alone would not notice a wrong channel block of small values
+    ex_ref = helpers.elementwise_excess(logits16, z['logits'].astype(np.float32), 1e-2)
+    print('  worst element at {:.2f} of its 1e-2 allowance'.format(ex_ref))
+    assert ex_ref <= 1.0, ex_ref
     assert helpers.rel_err(logits32, z['logits']) <= 3e-3
     assert_close(logits16, logits32, 5e-3, 'f16 MFMA vs fp32 arithmetic, GoogLeNet FP16 IR', elementwise=False)
     assert np.abs(prob16.sum(axis=1) - 1).max() <= 1e-4
@@ -673,6 +677,9 @@ def test_googlenet_fp16_ir_whole_modules_on_blocked_fp16_tensors(hip, tmp_path, 
     print('GoogLeNet FP16 IR, blocked modules: logits {:.2e} from the reference float16 run, {:.2e} from the default mode'.format(err_ref, err_1))
     assert np.isfinite(prob).all() and np.array_equal(logits2.argmax(axis=1), z['logits'].argmax(axis=1))
     assert err_ref <= 1e-2, err_ref
+    ex_ref = helpers.elementwise_excess(logits2, z['logits'].astype(np.float32), 1e-2)      # element by element: 1e-2 |want| + 1e-2 rms(want)
+    print('  worst element at {:.2f} of its 1e-2 allowance'.format(ex_ref))
+    assert ex_ref <= 1.0, ex_ref
     assert err_1 <= 2e-3, err_1
     # a second pass (fresh Concat buffers) gives the same bits
     helpers.assert_bit_exact(helpers.infer_one(ex, net, images), prob, 'second pass')
