@@ -225,6 +225,89 @@ def median_infer_rate(ex, feed, batch, reps, warm=3):
     return batch / statistics.median(times), statistics.median(times) * 1e3
 
 
+PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16 / FP16 MFMA dense peak (~2.5 PF; never the 2:1-sparsity figure)
+
+
+def fp16_roofline(ex, net, feed):
+    """The FP16 entry against ITS roofline: one per-layer pass (one hipEvent bracket per launch, one stream), the Convolution
+    launches grouped by the kernel that ran (node['_hip_f16']) and by window; per family: launches, ms, algorithmic f16 flops (2*N*K*C*kh*kw*oh*ow:
+    a direct contraction executes exactly those, plus the padding of its pixel and channel tiles, which is NOT counted: the fraction is useful work
+    over the peak) against min(2.5 PFLOP/s, AI x 8 TB/s) with the bytes of fp16 tensors (2 per element in and out, 2 per weight).  `traffic` /
+    `traffic_ratio`: HBM bytes per Convolution launch from the committed PMC passes of `python bench.py --fp16-passes N` (profiles/*_fp16_traffic.json)."""
+    G = net.G
+    work = collect_work(net)
+    ex.device_timing, ex.compute_streams = 'all', 1
+    ex.infer(feed)
+    times = list(ex.device_times_ms())
+    ex.device_timing = None
+    fams, conv_ms, conv_fl, conv_by, others = {}, 0.0, 0.0, 0.0, {}
+    for nid, typ, nm, t_ms in times:
+        if typ != 'Convolution':
+            if typ not in ('Const', 'Parameter', 'Reshape'):
+                others[typ] = others.get(typ, 0.0) + t_ms
+            continue
+        node = G.nodes[nid]
+        members = [nid] + list(getattr(ex, '_siblings', {}).get(nid, []))
+        fl = sum(work[m][0] for m in members)
+        # fp16 tensors: the shared input once, every member's weights and output (2 bytes each; conv1's input is the fp32 image)
+        xin = int(np.prod(node['input'][0]['dims']))
+        by = (4.0 if node['input'][1]['dims'][2] == 7 else 2.0) * xin
+        for m in members:
+            by += 2.0 * (int(np.prod(G.nodes[m]['input'][1]['dims'])) + int(np.prod(next(iter(G.nodes[m]['output'].values()))['dims'])))
+        kh = node['input'][1]['dims'][2]
+        fam = '{}x{} {}'.format(kh, kh, node.get('_hip_f16', '?'))
+        if nid in getattr(ex, '_pool_conv', {}):
+            fam = 'MaxPool + ' + fam
+        agg = fams.setdefault(fam, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+        agg['launches'] += 1; agg['ms'] += t_ms; agg['flops'] += fl; agg['bytes'] += by
+        conv_ms += t_ms; conv_fl += fl; conv_by += by
+    per_kernel = {}
+    for fam, agg in sorted(fams.items(), key=lambda kv: -kv[1]['ms']):
+        bound = min(PEAK_MFMA_F16_TFLOPS, agg['flops'] / agg['bytes'] * PEAK_HBM_GBS / 1e3)
+        tf = agg['flops'] / (agg['ms'] * 1e-3) / 1e12
+        per_kernel[fam] = {'launches': agg['launches'], 'ms': round(agg['ms'], 4), 'TFLOPs': round(tf, 1), 'frac_of_f16_mfma_peak': round(tf / PEAK_MFMA_F16_TFLOPS, 4),
+                           'bound_TFLOPs': round(bound, 1), 'frac_of_bound': round(tf / bound, 3), 'GBs_algorithmic': round(agg['bytes'] / (agg['ms'] * 1e-3) / 1e9, 1)}
+    n_launch = sum(a_['launches'] for a_ in fams.values())
+    tf = conv_fl / (conv_ms * 1e-3) / 1e12
+    roof = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_MFMA_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_MFMA_F16_TFLOPS,
+            'kernel': 'all {} Convolution launches of the FP16 pass (v_mfma_f32_32x32x16_f16; algorithmic flops: tile padding not counted)'.format(n_launch),
+            'launches_per_pass': n_launch, 'flops_per_launch': conv_fl / n_launch, 'avg_launch_us': conv_ms / n_launch * 1e3,
+            'algorithmic_bytes_per_launch': conv_by / n_launch, 'hbm_GBs_algorithmic': round(conv_by / (conv_ms * 1e-3) / 1e9, 1),
+            'hbm_frac_algorithmic': round(conv_by / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 3),
+            'per_kernel': per_kernel, 'other_launches_ms': {k: round(v, 4) for k, v in sorted(others.items(), key=lambda kv: -kv[1])},
+            'traffic': None, 'traffic_ratio': None, 'traffic_source': None,
+            'measured_on': 'one per-layer pass of the FP16 entry (one hipEvent bracket per launch, one stream; a bracket adds ~10 us to launches of 15-300 us)',
+            '_conv_ms': conv_ms, '_conv_fl': conv_fl}
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_fp16_traffic.json')), reverse=True):
+        try:
+            doc = json.load(open(path))
+            k = doc['kernels']['convolution_kernels']
+            roof['traffic'] = k['read_bytes_per_launch'] + k['write_bytes_per_launch']
+            roof['traffic_ratio'] = round(roof['traffic'] / (conv_by / n_launch), 3)
+            roof['traffic_source'] = 'static: {} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_fp16.sh, tree {}; not re-measured in this run)'.format(
+                os.path.relpath(path, REPO), doc.get('tree', 'unknown'))
+            break
+        except Exception:
+            continue
+    return roof
+
+
+def fp16_network(blob):
+    """GoogLeNet as an FP16 IR read with fp16_as_fp32=False (the FP16 entry of extra_configs), batch 256, and its device-resident feed."""
+    import tempfile
+    from pyopenvino_amd import IECore, device, synth
+    ie = IECore()
+    gxml = os.path.join(REPO, 'models', MODEL + '.xml')
+    with tempfile.TemporaryDirectory() as tmp:
+        xml16, blob16 = synth.fp16_ir(gxml, blob, tmp)
+        net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
+    assert net.f16_mfma
+    net.set_batch(BATCH_PER_GPU)
+    ex = ie.load_network(net)
+    x = device.DeviceTensor.from_numpy(synth.uniform_pixels(1000, (BATCH_PER_GPU, 3, 224, 224)))
+    return net, ex, {net.inputs[0]['name']: x}
+
+
 def extra_configs(blob=None):
     """BASELINE configs 2 and 5 next to the headline (one synchronous infer() at a time, input resident in HBM, result on the
     host; median of 10-20): mnist batch 64 on the shipped weights, ssd_mobilenet_v1_coco batch 128 (whole IR: prior boxes
@@ -271,28 +354,16 @@ def extra_configs(blob=None):
         # the FP16 IR of the headline model (every constant stored as f16, what Model Optimizer --data_type FP16
         # writes) read with fp16_as_fp32=False: Convolution and MatMul round their operands to fp16 and run on the f16 matrix
         # cores with fp32 accumulation, every tensor stays fp32 in HBM.  A separate entry: never the headline dtype.
-        import tempfile
-        gxml = os.path.join(REPO, 'models', MODEL + '.xml')
-        with tempfile.TemporaryDirectory() as tmp:
-            xml16, blob16 = synth.fp16_ir(gxml, blob, tmp)
-            net = ie.read_network(xml16, weights=blob16, fp16_as_fp32=False)
-        assert net.f16_mfma
-        net.set_batch(BATCH_PER_GPU)
-        ex = ie.load_network(net)
-        x = device.DeviceTensor.from_numpy(synth.uniform_pixels(1000, (BATCH_PER_GPU, 3, 224, 224)))
-        feed = {net.inputs[0]['name']: x}
+        net, ex, feed = fp16_network(blob)
         rate, ms = median_infer_rate(ex, feed, BATCH_PER_GPU, 10)
-        ex.device_timing, ex.compute_streams = {'Convolution'}, 1
-        ex.infer(feed)
-        conv_ms = sum(t[3] for t in ex.device_times_ms())
-        ex.device_timing = None
-        work = collect_work(net)
-        conv_fl = sum(fl for nid, (fl, _) in work.items() if net.G.nodes[nid]['type'] == 'Convolution')
+        fp16_roof = fp16_roofline(ex, net, feed)
+        conv_ms, conv_fl = fp16_roof.pop('_conv_ms'), fp16_roof.pop('_conv_fl')
         out.append({'workload': 'models/googlenet-v1.xml as an FP16 IR, batch 256: fp16 operands on the f16 matrix cores (v_mfma_f32_32x32x16_f16), fp32 '
                                 'accumulation; the inception modules on fp16 tensors in HBM (channels blocked by eight: module inputs, reduce tensors, '
                                 'Concat buffers, and the stem from the output of conv1 on), the classifier fp32; one synchronous infer() at a time',
                     'dtype': 'f16 operands / f32 accumulate', 'images_per_sec': round(rate, 1), 'ms_per_infer': round(ms, 3),
                     'convolution_ms': round(conv_ms, 3), 'convolution_TFLOPs_algorithmic': round(conv_fl / (conv_ms * 1e-3) / 1e12, 1),
+                    'roofline': fp16_roof,
                     'note': 'pvhip_conv2d_f16_c8_multi on the inception modules (blocked fp16 in and out: the 1x1 arms as one launch, 3x3 / 5x5, '
                             'MaxPool + pool_proj with the pooling in the operand read; producer waves + LDS-DMA of whole rows, weights from L2: '
                             'within 2x of their matrix-pipe floor; copies, stores and weights fill most of the rest), conv2 on the same kernel, conv1 from row spans of '
@@ -310,6 +381,7 @@ def main():
     ap.add_argument('--cpu-images', type=int, default=60, help='images timed on the CPU baseline (0 = skip)')
     ap.add_argument('--no-node-timing', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip extra_configs (mnist batch 64, SSD batch 128)')
+    ap.add_argument('--fp16-passes', type=int, default=0, help='profiling hook: run ONLY this many eager passes of the FP16 entry (GoogLeNet as an FP16 IR, batch 256, one stream) and exit')
     ap.add_argument('--min-seconds', type=float, default=1.0, help='repeat the block of --steps steps until this much has been timed')
     ap.add_argument('--streams', type=int, default=0, help='compute streams the scheduler forks branches onto (0 = engine default)')
     ap.add_argument('--requests', type=int, default=int(os.environ.get('PVHIP_BENCH_REQUESTS', '6')), help='(default also from PVHIP_BENCH_REQUESTS: a sweep hook for a driver that cannot pass flags) ''infer requests in flight per GPU (each a whole batch; 1 = synchronous infer(); at most 8).  Six: same box, alternating, '
@@ -323,6 +395,16 @@ def main():
         sys.exit(shard.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     from pyopenvino_amd import IECore, device, synth
     from pyopenvino_amd.op_plugins import Convolution as conv_plugin
+    if args.fp16_passes > 0:
+        # scripts/profile_fp16.sh: the FP16 pass under rocprofv3 (kernel trace / PMC passes), eager dispatch on one stream so that a launch's duration is its own
+        device.init(0)
+        os.environ['PVHIP_AUTO_GRAPH'] = '0'
+        net, ex, feed = fp16_network(synth.synth_weights(os.path.join(REPO, 'models', MODEL + '.xml'), WEIGHT_SEED))
+        ex.compute_streams = 1
+        for _ in range(args.fp16_passes):
+            ex.infer(feed)
+        print(json.dumps({'fp16_passes': args.fp16_passes, 'batch': BATCH_PER_GPU}))
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world:
