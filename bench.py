@@ -256,7 +256,7 @@ def fp16_roofline(ex, net, feed):
             by += 2.0 * (int(np.prod(G.nodes[m]['input'][1]['dims'])) + int(np.prod(next(iter(G.nodes[m]['output'].values()))['dims'])))
         kh = node['input'][1]['dims'][2]
         fam = '{}x{} {}'.format(kh, kh, node.get('_hip_f16', '?'))
-        if nid in getattr(ex, '_pool_conv', {}):
+        if nid in getattr(ex, '_pool_conv', {}) and 'MaxPool' not in fam:
             fam = 'MaxPool + ' + fam
         agg = fams.setdefault(fam, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
         agg['launches'] += 1; agg['ms'] += t_ms; agg['flops'] += fl; agg['bytes'] += by

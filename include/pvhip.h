@@ -344,6 +344,12 @@ size_t pvhip_conv2d_f16_stem_pack_elems(int k_out);
 int    pvhip_conv2d_f16_stem_pack(const float* w_oihw, float* wf, int k_out);
 int    pvhip_conv2d_f16_stem(const float* xp, const float* wf, void* yb, int n, int hp, int wp, int k_out, int oh, int ow,
                              const float* bias, int act);
+/* ... and straight from the UNPADDED image (ABI v15; as pvhip_conv2d_stem_direct_f32: w % 4 == 0, w <= 248; no padding pass; pre_add: the per-channel
+ * constant of an Add in front of the layer, or NULL); wf from _direct_pack (the k slots of a filter row start one column in front of the window). */
+int    pvhip_conv2d_f16_stem_direct_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
+int    pvhip_conv2d_f16_stem_direct_pack(const float* w_oihw, float* wf, int k_out);
+int    pvhip_conv2d_f16_stem_direct(const float* x, const float* wf, void* yb, int n, int h, int w, int k_out, int oh, int ow,
+                                    const float* pre_add, const float* bias, int act);
 /* The same first convolution in fp32 (ABI v15; Convolution.py:57-87: 7x7 / stride 2 / pad 3 over three channels, at most 64 output channels, output
  * rows of at most 112 pixels and a multiple of four -- GoogLeNet's conv1): from row spans of the padded image, the whole weight tensor resident in
  * registers, no vector instruction in the reduction loop; the reduction runs over the taps in the reference's own (c, r, s) order.  _supported: 0,
@@ -362,7 +368,8 @@ int    pvhip_conv2d_stem_f32(const float* xp, const float* wf, float* y, int n, 
 int    pvhip_conv2d_stem_direct_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
 int    pvhip_conv2d_stem_direct_f32(const float* x, const float* wf, float* y, int n, int h, int w, int k_out, int oh, int ow,
                                     const float* pre_add, const float* bias, int act, float act_lo, float act_hi);
-/* AvgPool.py:41-59 on a c8 tensor (the window rule of pvhip_avgpool2d_f32); the output is fp32 NCHW. */
+/* AvgPool.py:41-59 on a c8 tensor (the window rule of pvhip_avgpool2d_f32); the output is fp32 NCHW holding fp16 values (the mean in fp32,
+ * rounded once: the reference's AvgPool of a float16 tensor returns float16). */
 int    pvhip_avgpool_c8(const void* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw);
 /* ... and the other order: LRN over five channels followed by MaxPool 3x3 on a c8 tensor as one launch (LRN.py:10-22 then MaxPool.py:41-72;
  * the LRN tensor never exists).  _supported: pooled rows per workgroup (0: outside the kernel).                                        */

@@ -621,7 +621,8 @@ __global__ __launch_bounds__(kBlock) void avgpool_c8_kernel(const _Float16* __re
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int ch = 8 * b + q;
-            if (ch < c) y[(((size_t)im * c + ch) * oh + oy) * ow + ox] = cnt > 0 ? sum[q] / (float)cnt : NAN;
+            // (rounded to fp16: the reference's AvgPool of a float16 tensor returns float16 -- AvgPool.py:57-58, res dtype = input dtype; kept in an fp32 tensor)
+            if (ch < c) y[(((size_t)im * c + ch) * oh + oy) * ow + ox] = cnt > 0 ? (float)(_Float16)(sum[q] / (float)cnt) : NAN;
         }
     }
 }

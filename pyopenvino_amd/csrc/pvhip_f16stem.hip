@@ -33,14 +33,20 @@ struct StemArgs {
     const _Float16* wf;      // [steps][tm][64 lanes][8 halves]
     _Float16*       yb;      // fp16 c8 [N][ceil16(K) / 8][OH * OW][8]
     const float*    bias;
-    int N, HP, WP, OH, OW, K, tm;
+    const float*    pre_add; // DIRECT: one constant per input channel, added to the image (not its padding) in LDS; or null
+    int N, HP, WP, OH, OW, K, tm;      // DIRECT: HP, WP = the extents of the UNPADDED image
     int tiles_per_image;
     unsigned x_bytes, wf_bytes;
     int act;
 };
 
+// DIRECT (round 5, as conv_stem_f32_kernel of pvhip_stem.hip): the image is read as it is -- no padding pass.  A row's copy lands FOUR floats into its
+// LDS row (position p = image column p - 4): positions 1 .. 3 are the left padding, zeroed by the workgroup before the copies are issued (the only
+// other writer is lane 63 of the row above, whose piece lies past the image: zeros); lanes past the image write the right padding, rows outside
+// the image are out-of-range copies.  The Add in front of the layer (data/mean) happens in LDS, on the image's own positions, by the wave that copied.
+template <bool DIRECT>
 __global__ __launch_bounds__(kBlock, 4) void conv_f16_stem_kernel(StemArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) float stem_lds[];          // [3 * 9][256]
+    extern __shared__ __attribute__((aligned(1024))) float stem_lds[];          // [3 * 9][256] (+ 4 floats: the last row's lane 63 in the DIRECT form)
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wid  = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -63,17 +69,33 @@ __global__ __launch_bounds__(kBlock, 4) void conv_f16_stem_kernel(StemArgs a) {
 
     // ---- the copies: instruction i = (channel, row), wave w takes i = w, w + 4, ...; lane l: floats 4 l .. 4 l + 3 of the padded row
     {
-        const int  iy0   = oy0 * kST;
+        const int  iy0   = oy0 * kST - (DIRECT ? 3 : 0);
         const bool colok = lane * 4 < a.WP;
+        if (DIRECT) {                   // the left padding of every row (and row 0's position 0 .. 3, which no lane 63 writes)
+            if (tid < kC * kRows) *reinterpret_cast<float4*>(stem_lds + tid * kLdsRow) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            __syncthreads();
+        }
         for (int i = wid; i < kC * kRows; i += kBlock / kWave) {
             const int  c = i / kRows, rr = i - c * kRows;
             const int  iy = iy0 + rr;
-            const bool ok = colok && iy < a.HP;
+            const bool ok = colok && (unsigned)iy < (unsigned)a.HP;
             const unsigned vo = ok ? (unsigned)((((img * kC + c) * a.HP + iy) * a.WP + lane * 4) * 4) : kOob;
-            lds_dma_b128(xr, stem_lds + i * kLdsRow, vo, 0u);
+            lds_dma_b128(xr, stem_lds + i * kLdsRow + (DIRECT ? 4 : 0), vo, 0u);
+        }
+        lds_dma_wait_all();
+        if (DIRECT && a.pre_add != nullptr) {      // the rows this wave copied have landed: the Add, image positions only
+            for (int i = wid; i < kC * kRows; i += kBlock / kWave) {
+                const int c = i / kRows, rr = i - c * kRows;
+                if ((unsigned)(iy0 + rr) < (unsigned)a.HP && colok) {
+                    const float mc = a.pre_add[c];
+                    float4* const p4 = reinterpret_cast<float4*>(stem_lds + i * kLdsRow + 4 + lane * 4);
+                    float4 v = *p4;
+                    v.x += mc; v.y += mc; v.z += mc; v.w += mc;
+                    *p4 = v;
+                }
+            }
         }
     }
-    lds_dma_wait_all();
     __syncthreads();
 
     // ---- pixel geometry: tile pixel p = (row p / OW, column p % OW) reads LDS row 2 (p / OW) + r, columns 2 (p % OW) + s
@@ -85,7 +107,7 @@ __global__ __launch_bounds__(kBlock, 4) void conv_f16_stem_kernel(StemArgs a) {
         live[j] = p < npx;
         const int pc = live[j] ? p : 0;
         const int pr = pc / a.OW, px = pc - pr * a.OW;
-        pixoff[j] = (unsigned)((pr * kST * kLdsRow + px * kST) * 4);
+        pixoff[j] = (unsigned)((pr * kST * kLdsRow + px * kST) * 4);     // DIRECT: position 2 px = image column 2 px - 4, one IN FRONT of the first tap: slot 0 carries a zero weight there
     }
     floatx16 acc[4];
 #pragma unroll
@@ -105,10 +127,16 @@ __global__ __launch_bounds__(kBlock, 4) void conv_f16_stem_kernel(StemArgs a) {
         for (int j = 0; j < 4; ++j) {
             const char* const p0 = lds_b + pixoff[j] + roff;
             const float2v v01 = *reinterpret_cast<const float2v*>(p0), v23 = *reinterpret_cast<const float2v*>(p0 + 8), v45 = *reinterpret_cast<const float2v*>(p0 + 16);
-            const float   v6  = *reinterpret_cast<const float*>(p0 + 24);
             half8 b8;
             b8[0] = (_Float16)v01.x; b8[1] = (_Float16)v01.y; b8[2] = (_Float16)v23.x; b8[3] = (_Float16)v23.y;
-            b8[4] = (_Float16)v45.x; b8[5] = (_Float16)v45.y; b8[6] = (_Float16)v6;    b8[7] = (_Float16)v6;        // (the eighth slot: zero weight)
+            b8[4] = (_Float16)v45.x; b8[5] = (_Float16)v45.y;
+            if (DIRECT) {          // eight floats from an 8-byte boundary: [the column in front of the window (zero weight), taps 0 .. 6]
+                const float2v v67 = *reinterpret_cast<const float2v*>(p0 + 24);
+                b8[6] = (_Float16)v67.x; b8[7] = (_Float16)v67.y;
+            } else {               // [taps 0 .. 6, tap 6 again (zero weight)]
+                const float v6 = *reinterpret_cast<const float*>(p0 + 24);
+                b8[6] = (_Float16)v6; b8[7] = (_Float16)v6;
+            }
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_cur, b8, acc[j], 0, 0, 0);
         }
         af_cur = af_nxt;
@@ -167,14 +195,16 @@ __global__ __launch_bounds__(kBlock, 4) void conv_f16_stem_kernel(StemArgs a) {
 
 // w (K, 3, 7, 7) fp32 -> fp16 fragments [step t][tile i][lane][q]: channel 32 i + lane % 32; k slot (t, lane / 32, q) = filter row
 // j = 2 t + lane / 32 = (input channel j / 7, window row j % 7), tap q; q = 7 and j = 21: zero
-__global__ __launch_bounds__(kBlock) void conv_f16_stem_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wf, int K, int tm, size_t total) {
+// direct: k slot q = tap q - 1 (slot 0: zero) -- the operand of the DIRECT form starts one column in front of the window
+__global__ __launch_bounds__(kBlock) void conv_f16_stem_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wf, int K, int tm, size_t total, int direct) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(e & 7), lane = (int)((e >> 3) & 63);
         const size_t f = e >> 9;
         const int i = (int)(f % tm), t = (int)(f / tm);
         const int k = 32 * i + (lane & 31), j = 2 * t + (lane >> 5);
         float v = 0.0f;
-        if (k < K && j < kFRows && q < kKW) v = w[(((size_t)k * kC + j / kKH) * kKH + j % kKH) * kKW + q];
+        const int tap = direct ? q - 1 : q;
+        if (k < K && j < kFRows && tap >= 0 && tap < kKW) v = w[(((size_t)k * kC + j / kKH) * kKH + j % kKH) * kKW + tap];
         wf[e] = (_Float16)v;
     }
 }
@@ -197,15 +227,18 @@ size_t pvhip_conv2d_f16_stem_pack_elems(int k_out) {            // FLOATS of the
     return (size_t)kSteps * ((k_out + 31) / 32) * 512 / 2;
 }
 
-int pvhip_conv2d_f16_stem_pack(const float* w_oihw, float* wf, int k_out) {
+static int stem_pack(const float* w_oihw, float* wf, int k_out, int direct) {
     PVHIP_REQUIRE_INIT();
     PVHIP_CHECK_ARG(w_oihw != nullptr && wf != nullptr && k_out > 0 && k_out <= 64);
     const int tm = (k_out + 31) / 32;
     const size_t total = (size_t)kSteps * tm * 512;
-    hipLaunchKernelGGL(conv_f16_stem_pack_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, w_oihw, reinterpret_cast<_Float16*>(wf), k_out, tm, total);
+    hipLaunchKernelGGL(conv_f16_stem_pack_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, w_oihw, reinterpret_cast<_Float16*>(wf), k_out, tm, total, direct);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }
+
+int pvhip_conv2d_f16_stem_pack(const float* w_oihw, float* wf, int k_out) { return stem_pack(w_oihw, wf, k_out, 0); }
+int pvhip_conv2d_f16_stem_direct_pack(const float* w_oihw, float* wf, int k_out) { return stem_pack(w_oihw, wf, k_out, 1); }
 
 /* xp: the zero-padded input (n, 3, hp, wp) fp32 with hp >= 2 (oh - 1) + 7 rows and wp = _supported()'s answer floats per row (pvhip_pad2d_f32
  * with pad_top = pad_left = 3 and the bottom / right padding that makes those extents); yb: fp16 c8 output; act: none or ReLU.           */
@@ -218,7 +251,7 @@ int pvhip_conv2d_f16_stem(const float* xp, const float* wf, void* yb, int n, int
     if (n == 0) return PVHIP_OK;
     PVHIP_CHECK_ARG(xp != nullptr && wf != nullptr && yb != nullptr);
     StemArgs a;
-    a.xp = xp; a.wf = reinterpret_cast<const _Float16*>(wf); a.yb = static_cast<_Float16*>(yb); a.bias = bias;
+    a.xp = xp; a.wf = reinterpret_cast<const _Float16*>(wf); a.yb = static_cast<_Float16*>(yb); a.bias = bias; a.pre_add = nullptr;
     a.N = n; a.HP = hp; a.WP = wp; a.OH = oh; a.OW = ow; a.K = k_out; a.tm = (k_out + 31) / 32;
     a.tiles_per_image = (oh + kR - 1) / kR;
     a.x_bytes  = (unsigned)in_b;
@@ -226,7 +259,41 @@ int pvhip_conv2d_f16_stem(const float* xp, const float* wf, void* yb, int n, int
     a.act = act;
     const long grid = (long)n * a.tiles_per_image;
     if (grid > 0x7fffffffL) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_stem: grid too large");
-    hipLaunchKernelGGL(conv_f16_stem_kernel, dim3((unsigned)grid), dim3(kBlock), (size_t)kC * kRows * kLdsRow * sizeof(float), state().stream, a);
+    hipLaunchKernelGGL(conv_f16_stem_kernel<false>, dim3((unsigned)grid), dim3(kBlock), (size_t)kC * kRows * kLdsRow * sizeof(float), state().stream, a);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+/* The same layer straight from the UNPADDED image x (n, 3, h, w), w % 4 == 0 and w <= 248 (ABI v15, as pvhip_conv2d_stem_direct_f32): no padding
+ * pass; wf from pvhip_conv2d_f16_stem_direct_pack (the k slots of a filter row start one column in front of the window); pre_add: one constant per
+ * input channel added to the image on the way, or NULL.                                                                                       */
+int pvhip_conv2d_f16_stem_direct_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow) {
+    if (pvhip_conv2d_f16_stem_supported(c, h, w, k_out, kh, kw, sh, sw, pad_top, pad_left, oh, ow) <= 0) return 0;
+    if (w % 4 != 0 || w + 8 > kLdsRow) return 0;
+    if (kST * (oh - 1) + kKH > h + 6 || kST * (ow - 1) + kKW > w + 6) return 0;        // (pads_end = 3 as well)
+    return 1;
+}
+
+int pvhip_conv2d_f16_stem_direct(const float* x, const float* wf, void* yb, int n, int h, int w, int k_out, int oh, int ow, const float* pre_add,
+                                 const float* bias, int act) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && k_out > 0 && k_out <= 64 && h > 0 && w > 0 && oh > 0 && ow > 0 && (act == 0 || act == 1));
+    if (!pvhip_conv2d_f16_stem_direct_supported(kC, h, w, k_out, kKH, kKW, kST, kST, 3, 3, oh, ow))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_stem_direct: 7x7 / 2 / pad 3 over three channels, rows of a multiple of four and at most 248 pixels");
+    const unsigned long long in_b = (unsigned long long)n * kC * h * w * 4ull;
+    if (in_b >= (1ull << 31) || (unsigned long long)n * 64 * oh * ow >= (1ull << 31)) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_stem_direct: tensor too large");
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && wf != nullptr && yb != nullptr);
+    StemArgs a;
+    a.xp = x; a.wf = reinterpret_cast<const _Float16*>(wf); a.yb = static_cast<_Float16*>(yb); a.bias = bias; a.pre_add = pre_add;
+    a.N = n; a.HP = h; a.WP = w; a.OH = oh; a.OW = ow; a.K = k_out; a.tm = (k_out + 31) / 32;
+    a.tiles_per_image = (oh + kR - 1) / kR;
+    a.x_bytes  = (unsigned)in_b;
+    a.wf_bytes = (unsigned)(pvhip_conv2d_f16_stem_pack_elems(k_out) * 4);
+    a.act = act;
+    const long grid = (long)n * a.tiles_per_image;
+    if (grid > 0x7fffffffL) return fail(PVHIP_EUNSUPPORTED, "pvhip_conv2d_f16_stem_direct: grid too large");
+    hipLaunchKernelGGL(conv_f16_stem_kernel<true>, dim3((unsigned)grid), dim3(kBlock), (size_t)kC * kRows * kLdsRow * sizeof(float) + 16, state().stream, a);
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

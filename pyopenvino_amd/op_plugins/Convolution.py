@@ -344,16 +344,22 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
         if wps > 0 and (4 * n * c * hp * wps >= 2 ** 31 or n * 64 * oh * ow >= 2 ** 31):
             wps = 0        # (the kernel addresses its input with 32-bit byte offsets and the query does not know n: the LDS-DMA form takes it)
         if wps > 0:
+            direct = dev.conv_stem_direct and bool(dev.call('pvhip_conv2d_f16_stem_direct_supported', c, h, wd, kn, kh, kw, strides[0], strides[1],
+                                                            pads_begin[0], pads_begin[1], oh, ow))
+            cached = node.get('_hip_wpack_stem')
+            if cached is None or cached[0] is not w._block or cached[2] != direct:
+                wf = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_f16_stem_pack_elems', kn)),))
+                dev.call('pvhip_conv2d_f16_stem_direct_pack' if direct else 'pvhip_conv2d_f16_stem_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wf.ptr), kn)
+                cached = node['_hip_wpack_stem'] = (w._block, wf, direct)
+            yb = dev.BlockedHalf((n, kn, oh, ow))
+            node['_hip_f16'] = 'row spans, blocked output'
+            if direct:       # rows of a multiple of four pixels: straight from the image, the Add in front of the layer applied in LDS
+                dev.call('pvhip_conv2d_f16_stem_direct', ctypes.c_void_p(x.ptr), ctypes.c_void_p(cached[1].ptr), ctypes.c_void_p(yb.ptr), n, h, wd, kn, oh, ow,
+                         ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0), ctypes.c_void_p(bias.ptr if bias is not None else 0), 1 if act is not None else 0)
+                return yb
             xp = dev.DeviceTensor.empty((n, c, hp, wps))
             dev.call('pvhip_pad2d_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(xp.ptr), n, c, h, wd, pads_begin[0], pads_begin[1],
                      pads_end[0], wps - wd - pads_begin[1], ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0))
-            cached = node.get('_hip_wpack_stem')
-            if cached is None or cached[0] is not w._block:
-                wf = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_f16_stem_pack_elems', kn)),))
-                dev.call('pvhip_conv2d_f16_stem_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(wf.ptr), kn)
-                cached = node['_hip_wpack_stem'] = (w._block, wf)
-            yb = dev.BlockedHalf((n, kn, oh, ow))
-            node['_hip_f16'] = 'row spans, blocked output'
             dev.call('pvhip_conv2d_f16_stem', ctypes.c_void_p(xp.ptr), ctypes.c_void_p(cached[1].ptr), ctypes.c_void_p(yb.ptr), n, hp, wps, kn, oh, ow,
                      ctypes.c_void_p(bias.ptr if bias is not None else 0), 1 if act is not None else 0)
             return yb

@@ -1495,7 +1495,8 @@ def test_fp16_stem_on_blocked_tensors(hip):
     # 64 / 40 / 24 output channels, with and without the folded per-channel constant
     assert not dev.call('pvhip_conv2d_f16_stem_supported', 3, 9, 252, 64, 7, 7, 2, 2, 3, 3, 5, 126)          # (a padded row of more than 256 floats)
     assert not dev.call('pvhip_conv2d_f16_stem_supported', 4, 30, 30, 64, 7, 7, 2, 2, 3, 3, 15, 15) and not dev.call('pvhip_conv2d_f16_stem_supported', 3, 30, 30, 96, 7, 7, 2, 2, 3, 3, 15, 15)
-    for xs, k, add in [((2, 3, 224, 224), 64, True), ((1, 3, 37, 41), 40, False), ((3, 3, 30, 18), 24, True), ((1, 3, 9, 250), 64, False)]:
+    for xs, k, add in [((2, 3, 224, 224), 64, True), ((1, 3, 37, 41), 40, False), ((3, 3, 30, 18), 24, True), ((1, 3, 9, 250), 64, False),
+                       ((2, 3, 20, 24), 24, True), ((1, 3, 12, 248), 64, False)]:
         x, w, b = np.round(rnd(sum(xs), xs, 60.0)), rnd(k, (k, 3, 7, 7), (2.0 / 147) ** 0.5), rnd(3, (1, k, 1, 1), 0.2)
         mean = np.array([-104.0, -117.0, -123.0], dtype=np.float32).reshape(1, 3, 1, 1)
         node = make_node('Convolution', [x, w], conv_data((2, 2), (3, 3), (3, 3)))
@@ -1510,6 +1511,17 @@ def test_fp16_stem_on_blocked_tensors(hip):
         got = np.asarray(y)
         assert_bit_exact(got, f16r(got), 'a blocked output holds fp16 values')
         assert_close(got, want, 2e-3, 'row-span conv1 {} k{}'.format(xs, k), elementwise=False)
+        if xs[3] % 4 == 0 and xs[3] <= 248:
+            # rows of a multiple of four pixels were read straight from the image (pvhip_conv2d_f16_stem_direct, round 5: no padding pass, the Add
+            # applied in LDS): the bits of the padding pass + the kernel on the padded copy
+            os.environ['PVHIP_CONV_STEM_DIRECT'] = '0'
+            dev.reload_settings()
+            try:
+                y0 = next(iter(plugin.compute(dict(node), {0: x, 1: w}).values()))
+            finally:
+                del os.environ['PVHIP_CONV_STEM_DIRECT']
+                dev.reload_settings()
+            assert_bit_exact(got, np.asarray(y0), 'row-span conv1 straight from the image vs from the padded copy {} k{}'.format(xs, k))
     for xs, k, kk, st, pb, pe in [((2, 3, 37, 37), 64, 7, (2, 2), (3, 3), (3, 3)), ((1, 20, 13, 11), 24, 3, (1, 1), (1, 1), (1, 1)), ((2, 32, 9, 9), 40, 3, (2, 2), (0, 0), (1, 1))]:
         x, w, b = rnd(sum(xs), xs), rnd(k, (k, xs[1], kk, kk), (2.0 / (xs[1] * kk * kk)) ** 0.5), rnd(3, (1, k, 1, 1), 0.2)
         outs = {}
@@ -1566,8 +1578,9 @@ def test_fp16_stem_on_blocked_tensors(hip):
 
 
 def test_avgpool_on_a_blocked_tensor(hip):
-    """AvgPool (the reference's window rule: the 7x7 pool averages the top-left 6x6) on fp16 blocked by eight channels, fp32 output:
-    1e-6 from the fp32 launch on the same fp16 values (the same sequential sum)."""
+    """AvgPool (the reference's window rule: the 7x7 pool averages the top-left 6x6) on fp16 blocked by eight channels, fp32 output holding
+    fp16 VALUES (the reference's AvgPool of a float16 tensor returns float16: AvgPool.py:57-58): the fp16 rounding of what the fp32 launch
+    gives on the same fp16 values (the same sequential sum, 1e-6 before the rounding)."""
     from pyopenvino_amd import device as dev
     for xs, kern, st in [((3, 1024, 7, 7), (7, 7), (1, 1)), ((2, 20, 9, 12), (3, 3), (2, 2)), ((1, 8, 5, 5), (2, 2), (1, 1))]:
         x = f16r(rnd(sum(xs), xs))
@@ -1576,7 +1589,9 @@ def test_avgpool_on_a_blocked_tensor(hip):
         want = first_out(hip_plugin('AvgPool').compute(dict(node), {0: x}))
         node['output'] = {1: {'precision': 'FP32', 'dims': tuple(want.shape)}}
         got = first_out(hip_plugin('AvgPool').compute(dict(node), {0: dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))}))
-        assert_close(got, want, 1e-6, 'AvgPool on a blocked tensor {}'.format(xs))
+        got = np.asarray(got)
+        assert_bit_exact(got, f16r(got), 'AvgPool on a blocked tensor returns fp16 values')
+        assert_close(got, f16r(np.asarray(want)), 1e-3, 'AvgPool on a blocked tensor {}'.format(xs), elementwise=False)      # (one fp16 ulp where the two sums round apart)
 
 
 def test_conv_f16_mfma_reference_fp16_node_fixture(hip):
