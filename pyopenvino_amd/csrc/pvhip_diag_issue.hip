@@ -1,7 +1,7 @@
 // DIAGNOSTIC BUILD ONLY (make diag -> libpvhip_diag.so): what shares the SIMD's vector issue with what.  scripts/issue_mix.py runs
 // MFMA streams (fp32 32x32x2 or bf16 32x32x16) and packed-fp32 vector streams alone, interleaved in one wave, and on different waves of
 // one SIMD, and prints the times: "fp32 MFMA + vector = the sum" is what the convolution kernels (Convolution.py:57-87 replacements) are
-// built around (DESIGN lesson 1); whether the bf16 matrix instructions behave the same decides what a split-bf16 contraction
+// built around (LESSONS.md lesson 1); whether the bf16 matrix instructions behave the same decides what a split-bf16 contraction
 // (fp32 operands as three bf16 terms, six products, fp32 accumulation) could buy.  Not part of the product library.
 #include "pvhip_common.h"
 

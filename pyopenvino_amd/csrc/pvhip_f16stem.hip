@@ -1,7 +1,7 @@
 // FP16 IRs: the first convolution of an image network as an f16 layer -- 7x7 / stride 2 over THREE channels (GoogLeNet's
 // conv1; Convolution.py:57-87 computed in numpy float16 by the reference, common_def.py:13-17) -- from ROW SPANS instead of an im2col gather.
 // The implicit-GEMM forms gather 4-byte pieces: every input value 12 times over, 320 copy instructions per 128 output pixels, and in an f16
-// kernel the copy instructions are the time (DESIGN lesson 53).  Here a workgroup owns two output rows of one image, i.e. nine rows of the
+// kernel the copy instructions are the time (LESSONS.md lesson 53).  Here a workgroup owns two output rows of one image, i.e. nine rows of the
 // zero-padded input per channel (the padding pass of the plugin has written them, data/mean added, rows of WP = W + 8 floats: 16-byte
 // pieces): 27 one-KiB LDS-DMA instructions bring the tile in, once.  The reduction axis is laid out for the reads, not for the tensor:
 // a k-slot group of eight = one FILTER ROW (seven taps + one slot of zero weight), a 16-wide MFMA step = two filter rows -- the lane half

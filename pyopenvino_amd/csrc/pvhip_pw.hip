@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
     // The weight loads are ORDINARY loads (hipcc tracks them and places their s_waitcnt itself); only the LDS-DMA copies, which have no
     // register destination, are asm statements.  Rounds 1-2 issued the weight loads from asm too and waited for them in a second asm
     // statement with a hand-counted vmcnt: between the two statements hipcc considers the destination register defined and may copy it
-    // before the data has landed (DESIGN lesson 24: wrong images at batch 256 next to other streams, in pvhip_wino.hip).  With tracked
+    // before the data has landed (LESSONS.md lesson 24: wrong images at batch 256 next to other streams, in pvhip_wino.hip).  With tracked
     // loads (buffer-load builtins: scalar panel offset, one lane offset) there is no such window, by construction: the vector-memory
     // counter retires in order and hipcc counts only ITS loads, a
     // subsequence of the real queue (the asm copies are invisible to it), so the vmcnt it emits can only wait for MORE than it needs.

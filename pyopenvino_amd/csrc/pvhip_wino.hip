@@ -847,7 +847,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     }
         // A gather = 12 loads; its row / edge offsets are loop invariants held in registers: with address temporaries inside the loop
         // (the first version) hipcc reused a temporary's register as a load destination and put a wait for the WHOLE previous gather
-        // in front of the last loads of the next one -- one stage in flight instead of two (DESIGN.md lesson 23).
+        // in front of the last loads of the next one -- one stage in flight instead of two (LESSONS.md lesson 23).
         using VecT = typename std::conditional<M == 4, float4v, float2v>::type;      // own (inner) columns of a row
         using EdgT = typename std::conditional<M == 4, float, float2v>::type;        // edge lanes: their outer column(s)
         VecT vA[6], vB[6];
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
         // a register between the asm that issues a load into it and the asm that waits for it -- it did, in the F(2x2,5x5)
         // instantiation (different physical registers for the same patch in the steady loop and in the tile-boundary code) -- and the
         // copy reads whatever the register held: wrong results whenever the load is slow, i.e. only with other kernels running
-        // beside this one (DESIGN.md lesson 24).  With the edge offsets precomputed (no address temporaries in the loop) hipcc's own
+        // beside this one (LESSONS.md lesson 24).  With the edge offsets precomputed (no address temporaries in the loop) hipcc's own
         // waits come out where they belong: vmcnt(12) .. after the twelve loads of the next gather.
 #define PVW4_GATHER(v_, e_, s_)                                                                                  \
     {                                                                                                            \

@@ -354,7 +354,7 @@ class CaptureStreamModel:
     one that makes W join.  hipStreamEndCapture then walks those lists recursively from the origin and clears them on the way
     back.  The parent test stops a 2-cycle only while E's parent still IS W; after E has waited for a third stream in between,
     W <-> E (or a longer ring) closes, the walk never returns and the process dies of stack overflow inside hipStreamEndCapture
-    (what DESIGN lesson 30 filed as "crashes inside the runtime").  The origin never registers anywhere, so a dependency that
+    (what LESSONS.md lesson 30 filed as "crashes inside the runtime").  The origin never registers anywhere, so a dependency that
     would close a ring is RELAYED through it: the origin waits for E's event, records a fresh one, W waits for that."""
 
     def __init__(self):

@@ -1,4 +1,4 @@
-"""Where does a forked (multi-stream) hipGraph recording of a pass crash?  (DESIGN lesson 30.)
+"""Where does a forked (multi-stream) hipGraph recording of a pass crash?  (LESSONS.md lesson 30.)
 
     python scripts/capture_probe.py                 # the driver: every case in a process of its own, a bounded bisect per crashing plan
     python scripts/capture_probe.py <kind> <streams> <K>   # one case: record the first K dispatched tasks of the plan (0 = all)

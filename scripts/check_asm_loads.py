@@ -3,7 +3,7 @@
 vector-memory load with a REGISTER destination (an LDS read only with its `s_waitcnt lgkmcnt(0)` in the same statement).
 
 Why: a load issued from one asm statement and waited for (`s_waitcnt vmcnt`) in another leaves a window in which hipcc considers the
-destination register defined and may copy or spill it before the data has landed (DESIGN lesson 24: wrong images at batch 256 next to
+destination register defined and may copy or spill it before the data has landed (LESSONS.md lesson 24: wrong images at batch 256 next to
 other streams).  Loads into registers are therefore always the compiler's own (`__builtin_amdgcn_raw_buffer_load_*`, plain loads): it
 places their s_waitcnt itself.  What asm statements may issue are LDS-DMA copies (`buffer_load_* ... lds`, `global_load_lds_*`), which
 have no register destination, and waits / barriers, which name no data register.
@@ -65,7 +65,7 @@ def main():
     for b in bad:
         print(b)
     if bad:
-        print('check_asm_loads: register loads must be compiler-tracked (builtins / plain loads), see DESIGN lesson 24')
+        print('check_asm_loads: register loads must be compiler-tracked (builtins / plain loads), see LESSONS.md lesson 24')
         return 1
     print('check_asm_loads: ok (inline asm issues LDS-DMA copies, waits and barriers only)')
     return 0

@@ -519,7 +519,7 @@ def test_hipgraph_replay_of_a_forward_pass_is_bit_identical(hip, model, shape, s
 def test_forked_recordings_that_used_to_kill_the_process_replay_the_eager_bits(hip, kind, streams):
     """capture_graph(streams='plan') on the plans whose recording ended in a stack overflow inside hipStreamEndCapture (ROCm 7.2:
     its recursive walk over the per-stream lists of parallel capture streams meets a ring when non-origin streams wait for each
-    other in both directions over time; DESIGN lesson 30 rewritten, profiles/r04_capture.md): the dispatcher relays the
+    other in both directions over time; LESSONS.md lesson 30 rewritten, profiles/r04_capture.md): the dispatcher relays the
     ring-closing waits through the origin stream while it records, the recording is made, and its replay gives the bits of the
     eager pass.  The waits issued are the ones Executable_Network.recorded_waits() predicts from the plan."""
     import tempfile
