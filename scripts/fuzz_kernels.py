@@ -19,12 +19,12 @@ def node(type_, ins, data):
             'input': {i: {'precision': 'I64' if a.dtype == np.int64 else 'FP32', 'dims': tuple(a.shape)} for i, a in enumerate(ins)},
             'output': {len(ins): {'precision': 'FP32', 'dims': ()}}}
 def setenv(env):
-    for k_ in ('PVHIP_CONV_WINOGRAD4', 'PVHIP_CONV_WINOGRAD5', 'PVHIP_CONV_WINOGRAD', 'PVHIP_CONV_PREPAD', 'PVHIP_CONV_F16_SPAN', 'PVHIP_CONV_F16_DMA', 'PVHIP_DWCONV_COLS', 'PVHIP_POOL3'): os.environ.pop(k_, None)
+    for k_ in ('PVHIP_CONV_WINOGRAD4', 'PVHIP_CONV_WINOGRAD5', 'PVHIP_CONV_WINOGRAD', 'PVHIP_CONV_PREPAD', 'PVHIP_CONV_F16_SPAN', 'PVHIP_CONV_F16_DMA', 'PVHIP_DWCONV_COLS', 'PVHIP_POOL3', 'PVHIP_CONV_STEM', 'PVHIP_CONV_STEM_DIRECT'): os.environ.pop(k_, None)
     os.environ.update(env); dev.reload_settings()
 bad = 0
 compared = {}
 for i in range(cases):
-    kind = rng.choice(['w3', 'w5', 'poolconv', 'poollrn', 'lrnpool', 'prepad', 'f16', 'dw', 'pool'])
+    kind = rng.choice(['w3', 'w5', 'poolconv', 'poollrn', 'lrnpool', 'prepad', 'f16', 'dw', 'pool', 'stem', 'stemconv'])
     n, h, w = rng.randint(1, 9), rng.randint(1, 30), rng.randint(1, 30)
     if kind in ('w3', 'w5'):
         ks = 3 if kind == 'w3' else 5
@@ -40,6 +40,54 @@ for i in range(cases):
         err = float(np.abs(outs[0] - outs[1]).max() / max(1e-20, np.abs(outs[1]).max()))
         ok = err < 5e-5
         what = '{}x{} conv x{} k{}: {:.1e}'.format(ks, ks, (n, c, h, w), k, err)
+    elif kind == 'stem':              # 7x7 / 2 / pad 3 over three channels (round 5): the row-span kernel on a padded copy and straight from the image == the general kernel, bit for bit
+        k = rng.randint(1, 64)
+        h, w = rng.randint(7, 60), 4 * rng.randint(2, 56)          # (output rows of a multiple of four pixels; odd ones stay on the general kernel anyway)
+        if rng.random() < 0.3:
+            w = 2 * rng.randint(4, 110)
+        x = synth.normal(i, 2, n * 3 * h * w).astype(np.float32).reshape((n, 3, h, w)) * 60.0
+        wt = (synth.normal(i, 3, k * 147) * (2.0 / 147) ** 0.5).astype(np.float32).reshape((k, 3, 7, 7))
+        addc = synth.normal(i, 5, 3).astype(np.float32).reshape((1, 3, 1, 1)) * 50.0
+        b = dev.DeviceTensor.from_numpy(synth.normal(i, 4, k).astype(np.float32).reshape((1, k, 1, 1)))
+        act = rng.choice([None, ('relu',), ('clamp', -0.5, 0.7)])
+        pre = rng.random() < 0.5
+        outs = []
+        for env in ({'PVHIP_CONV_STEM': '0'}, {'PVHIP_CONV_STEM': '1', 'PVHIP_CONV_STEM_DIRECT': '0'}, {'PVHIP_CONV_STEM': '1', 'PVHIP_CONV_STEM_DIRECT': '1'}):
+            setenv(env)
+            nd = {'_pre_add': dev.DeviceTensor.from_numpy(addc)} if pre else {}
+            outs.append(np.asarray(Convolution.launch(nd, dev.DeviceTensor.from_numpy(x), dev.DeviceTensor.from_numpy(wt), (2, 2), (3, 3), (3, 3), 'explicit', bias=b, act=act)))
+        setenv({})
+        ok = all(bool((o.view(np.uint32) == outs[0].view(np.uint32)).all()) for o in outs[1:])
+        what = 'stem conv x{} k{} act {} pre_add {}'.format(x.shape, k, act, pre)
+    elif kind == 'stemconv':          # MaxPool -> LRN -> 1x1 convolution as one launch (round 5) == MaxPool + LRN then the pointwise launch, bit for bit
+        c, k = 8 * rng.randint(1, 8), rng.randint(1, 64)
+        st = rng.choice([1, 2])
+        h, w = rng.randint(3, 40), 4 * rng.randint(1, 28)
+        x = synth.normal(i, 2, n * c * h * w).astype(np.float32).reshape((n, c, h, w)) * 30.0
+        pads = rng.choice([((0, 0), (0, 0)), ((1, 1), (1, 1))])
+        pn = node('MaxPool', [x], {'kernel': '3, 3', 'strides': '{0}, {0}'.format(st), 'pads_begin': '{}, {}'.format(*pads[0]), 'pads_end': '{}, {}'.format(*pads[1]),
+                                   'rounding_type': rng.choice(['ceil', 'floor']), 'auto_pad': 'explicit'})
+        try:
+            oh, ow = MaxPool.calc_output_shape((h, w), (3, 3), (st, st), pads[0], pads[1], pn['data']['rounding_type'], 'explicit')
+            if oh <= 0 or ow <= 0:
+                continue
+            axes = np.array([1], dtype=np.int64)
+            ln = node('LRN', [np.zeros((n, c, oh, ow), np.float32), axes], {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'})
+            ln['output'][2]['dims'] = (n, c, oh, ow)
+            wt = (synth.normal(i, 3, k * c) * (2.0 / c) ** 0.5).astype(np.float32).reshape((k, c, 1, 1))
+            cn = node('Convolution', [np.zeros((n, c, oh, ow), np.float32), wt], {'strides': '1, 1', 'dilations': '1, 1', 'pads_begin': '0, 0', 'pads_end': '0, 0', 'auto_pad': 'explicit'})
+            if not MaxPool.lrn_conv_fusable(pn, ln, cn):
+                continue
+            b = dev.DeviceTensor.from_numpy(synth.normal(i, 4, k).astype(np.float32).reshape((1, k, 1, 1)))
+            act = rng.choice([None, ('relu',), ('clamp', -0.5, 0.7)])
+            two_p = dict(pn); two_p['_fuse_lrn'] = ln
+            two_c = dict(cn); two_c['_fuse_bias'], two_c['_fuse_act'] = b, act
+            two = np.asarray(Convolution.compute(two_c, {0: MaxPool.compute(two_p, {0: x})[1], 1: wt})[2])
+            one_p = dict(two_p); one_p['_fuse_conv'] = {'node': cn, 'w': wt, 'bias': b, 'act': act}
+            one = np.asarray(MaxPool.compute(one_p, {0: x})[1])
+        except (ValueError, dev.PvhipError):
+            continue
+        ok = bool((one.view(np.uint32) == two.view(np.uint32)).all()); what = 'MaxPool + LRN + 1x1 x{} k{} stride {} pads {} act {}'.format(x.shape, k, st, pads, act)
     elif kind == 'prepad':            # c-major layers (C % 16 != 0) with padding: padding pass + test-free gather == window test in the gather, bit for bit
         c, k, ks, st = rng.choice([1, 3, 5, 7, 24]), rng.randint(1, 80), rng.choice([3, 5, 7]), rng.choice([1, 2])
         pb, pe = (rng.randint(0, ks // 2), rng.randint(0, ks // 2)), (rng.randint(0, ks // 2), rng.randint(0, ks // 2))
