@@ -334,6 +334,13 @@ int    pvhip_conv2d_f16_dma_c8(const float* x, const float* wpack, void* yb,
 int    pvhip_maxpool3x3_lrn_c8(const void* x, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
                                int pad_top, int pad_left, int pad_bottom, int pad_right,
                                int size, float alpha, float beta, float bias);
+/* ... with the 1x1 / stride 1 / unpadded convolution behind the LRN in the same launch (ABI v15; the FP16-IR twin of pvhip_maxpool_lrn_conv1x1_f32:
+ * fp16 operands on v_mfma_f32_32x32x4_2b_f16, fp32 accumulation).  x: c8 (n, c, h, w), c <= 64; w_oihw: the (k_out, c, 1, 1) fp32 weights, rounded to
+ * fp16 as they are staged; k_out <= 64; y: c8 (n, k_out, oh, ow); conv_bias may be NULL; act: none or ReLU.                                   */
+int    pvhip_maxpool3x3_lrn_conv1x1_c8_supported(int c, int k_out, int size);
+int    pvhip_maxpool3x3_lrn_conv1x1_c8(const void* x, const float* w_oihw, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
+                                       int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha, float beta, float bias,
+                                       int k_out, const float* conv_bias, int act);
 /* The first convolution of an image network as an FP16 layer, from row spans (ABI v14): 7x7 / stride 2 / pad 3 over three channels, at most 64
  * output channels (GoogLeNet's conv1).  _supported: 0, or the floats per row the padded input must have (w + 3 rounded up so that every
  * tap of the last output column exists, whole 16-byte pieces); xp: that padded input (n, 3, hp, wp), e.g. from pvhip_pad2d_f32 with

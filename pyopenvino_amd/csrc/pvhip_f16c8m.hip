@@ -657,6 +657,144 @@ void launch_c8m(const C8mArgs& a, int grid, int nb, size_t lds) {
     else         hipLaunchKernelGGL((conv_f16_c8m_kernel<KS, 4, POOL>), dim3(grid), dim3(threads), lds, state().stream, a);
 }
 
+// MaxPool 3x3 -> LRN -> 1x1 convolution (+ bias, ReLU) on blocked fp16 tensors as ONE launch (round 5; the FP16-IR twin of
+// maxpool3x3_lrn_conv1x1_kernel of pvhip_norm.hip: GoogLeNet's pool1 -> norm1 -> conv2/3x3_reduce).  maxpool3x3_lrn_c8_kernel holds, block
+// after block, the eight normalised channels of ITS pixel as one 16-byte piece -- two B operands of v_mfma_f32_32x32x4_2b_f16, whose two blocks
+// take four k-values per LANE (lane l: column l & 31 of block l >> 5): D[k][pixel] += W[k][4 c'..4 c' + 3] . lrn[4 c'..][pixel], fp32
+// accumulation.  A = the weights rounded to fp16 once (the constants of an FP16 IR are fp16 values) and transposed into LDS as
+// wl[c / 4][k][4].  Epilogue as conv_f16_c8m_kernel's: bias, ReLU, fp16, v_permlane32_swap between the lane halves, one 16-byte blocked
+// piece per lane -- for the pixel of lane 32 b + (l & 31), whose output index comes over by a wave shuffle.
+template <int BETA_MODE, int KT>
+__global__ __launch_bounds__(kBlock) void maxpool3x3_lrn_conv1x1_c8_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, const float* __restrict__ cw,
+                                                                           const float* __restrict__ cbias, int n, int cb, int c, int h, int w, int oh, int ow,
+                                                                           int sh, int sw, int pt, int pl, int hp, int wp, float alpha, float beta, float bias,
+                                                                           int k_out, int act) {
+    typedef float floatx32 __attribute__((ext_vector_type(32)));
+    constexpr int KP = 32 * KT;
+    __shared__ __attribute__((aligned(16))) half4 wl[16][KP];                 // [input channel / 4][output channel]: cb <= 8 blocks = 16 quads
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    for (int e = tid; e < 2 * cb * KP; e += kBlock) {
+        const int q4 = e / KP, k = e - q4 * KP;
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (k < k_out && 4 * q4 + j < c) ? (_Float16)cw[(size_t)k * c + 4 * q4 + j] : (_Float16)0.0f;
+        wl[q4][k] = v;
+    }
+    __syncthreads();
+    const size_t total = (size_t)n * oh * ow;
+    const half8 zero = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    const int ohw = oh * ow;
+    const int kbt = (k_out + 15) / 16 * 2;                                    // blocks of the output tensor
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (size_t e0 = (size_t)blockIdx.x * blockDim.x; e0 < total; e0 += (size_t)gridDim.x * blockDim.x) {       // (workgroup-uniform: every lane takes part in the MFMAs)
+        const size_t e = e0 + tid;
+        const bool live = e < total;
+        const size_t ee = live ? e : 0;
+        const int ox = (int)(ee % ow);
+        const size_t f = ee / ow;
+        const int oy = (int)(f % oh), im = (int)(f / oh);
+        int off[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                const int py = oy * sh + r, px = ox * sw + s2;
+                const bool inwin = py < hp && px < wp;
+                const int cy = (inwin ? py : oy * sh) - pt, cx = (inwin ? px : ox * sw) - pl;
+                off[3 * r + s2] = (cy >= 0 && cy < h && cx >= 0 && cx < w) ? cy * w + cx : -1;
+            }
+        const half8* const xi = reinterpret_cast<const half8*>(x) + (size_t)im * cb * (h * w);
+        auto pooled = [&](int b, float (&dst)[8]) {
+            if (b < 0 || b >= cb) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dst[q] = 0.0f;
+                return;
+            }
+            const half8* const xp = xi + (size_t)b * (h * w);
+            half8 v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = off[t] >= 0 ? xp[off[t]] : zero;
+            const half8 m = pk_max3_nan(pk_max3_nan(v[0], v[1], v[2]), pk_max3_nan(v[3], v[4], v[5]), pk_max3_nan(v[6], v[7], v[8]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = (8 * b + q < c) ? (float)m[q] : 0.0f;
+        };
+        floatx32 acc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) acc[kt][r] = 0.0f;
+        float prev[8], cur[8], nxt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) prev[q] = 0.0f;
+        pooled(0, cur);
+        for (int b = 0; b < cb; ++b) {
+            pooled(b + 1, nxt);
+            float ext[12];                        // channels 8 b - 2 .. 8 b + 9
+            ext[0] = prev[6]; ext[1] = prev[7];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ext[2 + q] = cur[q];
+            ext[10] = nxt[0]; ext[11] = nxt[1];
+            half4 o[2];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s_ = ext[q] * ext[q];
+#pragma unroll
+                for (int t = 1; t < 5; ++t) s_ = s_ + ext[q + t] * ext[q + t];
+                const _Float16 v = (_Float16)lrn_div(ext[q + 2], bias + alpha * s_, beta, BETA_MODE);      // (the fp16 value maxpool3x3_lrn_c8_kernel stores)
+                o[q >> 2][q & 3] = live ? v : (_Float16)0.0f;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x4f16(wl[2 * b + s2][32 * kt + l31], o[s2], acc[kt], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { prev[q] = cur[q]; cur[q] = nxt[q]; }
+        }
+        // ---- epilogue: register 16 b2 + 4 g + j of acc[kt] at lane (l31, lh) = output channel 32 kt + 8 g + 4 lh + j of the pixel of lane 32 b2 + l31
+        const long opix = live ? (long)im * kbt * ohw + (long)oy * ow + ox : -1;
+        long opix_b[2];
+        opix_b[0] = ((long)__shfl((int)(opix >> 32), l31, kWave) << 32) | (unsigned)__shfl((int)opix, l31, kWave);
+        opix_b[1] = ((long)__shfl((int)(opix >> 32), 32 + l31, kWave) << 32) | (unsigned)__shfl((int)opix, 32 + l31, kWave);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                float bs[2][4];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kk = 32 * kt + 8 * (2 * gp + h2) + 4 * lh + j;
+                        bs[h2][j] = (cbias != nullptr && kk < k_out) ? cbias[kk] : 0.0f;
+                    }
+                const int blk = 4 * kt + 2 * gp + lh;            // the block this lane holds after the swap
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    unsigned w0[2], w1[2];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        half4 hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[kt][16 * b2 + 4 * (2 * gp + h2) + j] + bs[h2][j];
+                            if (act != 0) v = __builtin_elementwise_maximum(v, 0.0f);
+                            hv[j] = (_Float16)v;
+                        }
+                        const uint2 u = __builtin_bit_cast(uint2, hv);
+                        if (h2 == 0) { w0[0] = u.x; w0[1] = u.y; } else { w1[0] = u.x; w1[1] = u.y; }
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(w0[0], w1[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(w0[1], w1[1], false, false);
+                    uint4v piece;
+                    piece[0] = s0[0]; piece[1] = s1[0]; piece[2] = s0[1]; piece[3] = s1[1];
+                    if (opix_b[b2] >= 0 && blk < kbt)
+                        *reinterpret_cast<uint4v*>(y + ((size_t)opix_b[b2] + (size_t)blk * ohw) * 8) = piece;
+                }
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -769,6 +907,38 @@ int pvhip_maxpool3x3_c8(const void* x, void* y, int n, int c, int h, int w, int 
     const size_t total = (size_t)n * cb * oh * ow;
     hipLaunchKernelGGL(maxpool3x3_c8_kernel, dim3(grid_for(total)), dim3(kBlock), 0, state().stream, static_cast<const _Float16*>(x),
                        static_cast<_Float16*>(y), n, cb, h, w, oh, ow, sh, sw, pad_top, pad_left, hp, wp);
+    PVHIP_LAUNCH_CHECK();
+    return PVHIP_OK;
+}
+
+/* ... and with the 1x1 / stride 1 / unpadded convolution behind the LRN in the same launch (ABI v15; the FP16-IR twin of pvhip_maxpool_lrn_conv1x1_f32):
+ * x: c8 (n, c, h, w), c <= 64; w_oihw: the (k_out, c, 1, 1) fp32 weights (holding fp16 values), k_out <= 64; y: c8 (n, k_out, oh, ow); act none / ReLU. */
+int pvhip_maxpool3x3_lrn_conv1x1_c8_supported(int c, int k_out, int size) { return (c > 0 && c <= 64 && k_out > 0 && k_out <= 64 && size == 5) ? 1 : 0; }
+
+int pvhip_maxpool3x3_lrn_conv1x1_c8(const void* x, const float* w_oihw, void* y, int n, int c, int h, int w, int oh, int ow, int sh, int sw,
+                                    int pad_top, int pad_left, int pad_bottom, int pad_right, int size, float alpha, float beta, float bias,
+                                    int k_out, const float* conv_bias, int act) {
+    PVHIP_REQUIRE_INIT();
+    PVHIP_CHECK_ARG(n >= 0 && c > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && sh > 0 && sw > 0 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 && pad_right >= 0);
+    PVHIP_CHECK_ARG(act == 0 || act == 1);
+    if (!pvhip_maxpool3x3_lrn_conv1x1_c8_supported(c, k_out, size))
+        return fail(PVHIP_EUNSUPPORTED, "pvhip_maxpool3x3_lrn_conv1x1_c8: a window of five channels, at most 64 channels either side");
+    const int hp = h + pad_top + pad_bottom, wp = w + pad_left + pad_right;
+    PVHIP_CHECK_ARG((oh - 1) * sh < hp && (ow - 1) * sw < wp);
+    if ((unsigned long long)n * 64 * oh * ow >= (1ull << 31)) return fail(PVHIP_EUNSUPPORTED, "pvhip_maxpool3x3_lrn_conv1x1_c8: tensor too large");
+    if (n == 0) return PVHIP_OK;
+    PVHIP_CHECK_ARG(x != nullptr && y != nullptr && w_oihw != nullptr);
+    const int cb = c8m_blocks(c);
+    const int bm = lrn_beta_mode(beta, bias);
+    const size_t total = (size_t)n * oh * ow;
+    const int kt = (k_out + 31) / 32;
+#define PVM_PLC(BM_, KT_) hipLaunchKernelGGL((maxpool3x3_lrn_conv1x1_c8_kernel<BM_, KT_>), dim3(grid_for(total)), dim3(kBlock), 0, state().stream,                   \
+                                             static_cast<const _Float16*>(x), static_cast<_Float16*>(y), w_oihw, conv_bias, n, cb, c, h, w, oh, ow, sh, sw, pad_top, \
+                                             pad_left, hp, wp, alpha, beta, bias, k_out, act)
+    if (bm == 4) { if (kt == 1) PVM_PLC(4, 1); else PVM_PLC(4, 2); }
+    else if (bm == 1) { if (kt == 1) PVM_PLC(1, 1); else PVM_PLC(1, 2); }
+    else { if (kt == 1) PVM_PLC(0, 1); else PVM_PLC(0, 2); }
+#undef PVM_PLC
     PVHIP_LAUNCH_CHECK();
     return PVHIP_OK;
 }

@@ -743,6 +743,25 @@ class Executable_Network:
                     if conv_plugin.c8_writer_ok(G.nodes[cid]) or conv_plugin.c8_dma_writer_ok(G.nodes[cid]) or \
                             (own_blocked and conv_plugin.c8_module_member_ok(G.nodes[cid])):
                         self._c8_out.add(cid)
+            if device.conv_f16_c8 == 2 and device.fuse_stem_conv != 0 and pool_plugin is not None and getattr(pool_plugin, 'SUPPORTS_FUSED_LRN_CONV', False):
+                # ... and the 1x1 convolution behind a blocked MaxPool + LRN rides in that launch, as in an fp32 IR (GoogLeNet: conv1 [blocked] ->
+                # pool1 + norm1 -> conv2/3x3_reduce [blocked for conv2/3x3]): pvhip_maxpool3x3_lrn_conv1x1_c8
+                tails = {(self._fusion[c_]['relu'] if self._fusion[c_]['relu'] is not None else self._fusion[c_]['add']) for c_ in self._c8_out}
+                for pid, lid in self._lrn_pool.items():
+                    if G.nodes[pid]['type'] != 'MaxPool' or pid in self._stem_conv:
+                        continue
+                    src = next((p_ for p_ in G.pred[pid] if G.edges[(p_, pid)]['connection'][3] == 0), None)
+                    readers = list(G.successors(lid))
+                    if src not in tails or len(readers) != 1 or G.edges[(lid, readers[0])]['connection'][3] != 0:
+                        continue
+                    cid = readers[0]
+                    f = self._fusion.get(cid)
+                    if f is None or cid not in self._c8_out or cid in self._siblings or cid in self._fused_away or cid in self._pool_conv \
+                            or (f['act'] is not None and f['act'][0] != 'relu'):
+                        continue
+                    if pool_plugin.lrn_conv_fusable(G.nodes[pid], G.nodes[lid], G.nodes[cid], True):
+                        self._stem_conv[pid] = cid
+                        self._fused_away.update(n_ for n_ in (cid, f['add'], f['relu']) if n_ is not None)
             if device.conv_f16_c8 == 2 and getattr(conv_plugin, 'SUPPORTS_C8_MODULES', False):
                 self.plan_c8_modules(conv_plugin)
         self.order_for_locality()
@@ -1170,7 +1189,8 @@ class Executable_Network:
                 sf = self._fusion[stem_conv]
                 wsrc = next(G.edges[(p_, stem_conv)]['connection'] for p_ in G.pred[stem_conv] if G.edges[(p_, stem_conv)]['connection'][3] == 1)
                 node['_fuse_conv'] = {'node': G.nodes[stem_conv], 'w': G.nodes[wsrc[0]]['output'][wsrc[1]]['data'],
-                                      'bias': G.nodes[sf['bias']]['output'][0]['data'], 'act': sf['act']}
+                                      'bias': G.nodes[sf['bias']]['output'][0]['data'], 'act': sf['act'],
+                                      'c8': bool(getattr(self.ienet, 'f16_mfma', False))}       # FP16 IRs: on blocked fp16 tensors
             else:
                 node.pop('_fuse_conv', None)
             plugin = registry.get(node_type)

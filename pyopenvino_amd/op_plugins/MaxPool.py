@@ -49,9 +49,22 @@ def lrn_fusable(node: dict, lrn_node: dict) -> bool:
 SUPPORTS_FUSED_LRN_CONV = True
 
 
-def lrn_conv_fusable(node: dict, lrn_node: dict, conv_node: dict) -> bool:
-    """True when libpvhip's MaxPool -> LRN -> 1x1 convolution kernel covers this triple (IR attributes and port dims; no device needed)."""
+def lrn_conv_fusable(node: dict, lrn_node: dict, conv_node: dict, f16: bool = False) -> bool:
+    """True when libpvhip's MaxPool -> LRN -> 1x1 convolution kernel covers this triple (IR attributes and port dims; no device needed).
+    f16: the triple of an FP16 IR on blocked fp16 tensors (pvhip_maxpool3x3_lrn_conv1x1_c8)."""
     try:
+        if f16:
+            if not blocked_ok(node, lrn_node):
+                return False
+            dims, wd, ca = node['input'][0]['dims'], conv_node['input'][1]['dims'], conv_node['data']
+            n, c, h, w = (int(d) for d in dims)
+            kernel, strides, pads_begin, pads_end, oh, ow = _geometry(node, h, w)
+            cs, cpb, cpe = (common_def.string_to_tuple(ca[k]) for k in ('strides', 'pads_begin', 'pads_end'))
+            if tuple(wd[2:]) != (1, 1) or tuple(cs) != (1, 1) or tuple(cpb) != (0, 0) or tuple(cpe) != (0, 0) or ca['auto_pad'] not in ('explicit', 'valid'):
+                return False
+            if tuple(conv_node['input'][0]['dims']) != (n, c, oh, ow) or int(wd[1]) != c or n * 64 * oh * ow >= 2 ** 31:
+                return False
+            return bool(dev.call('pvhip_maxpool3x3_lrn_conv1x1_c8_supported', c, int(wd[0]), int(lrn_node['data']['size'])))
         if not lrn_fusable(node, lrn_node):
             return False
         dims = node['input'][0]['dims']
@@ -109,6 +122,9 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     kernel = common_def.string_to_tuple(attrs['kernel'])
     lrn_in = node.get('_fuse_lrn')
     blocked = inputs[0] if isinstance(inputs[0], dev.BlockedHalf) and blocked_ok(node, lrn_in) else None
+    if blocked is None and node.get('_fuse_conv') is not None and node['_fuse_conv'].get('c8'):
+        # the plan folded the convolution of an FP16 IR behind this launch (blocked tensors) but a dense tensor arrived: convert it, go on
+        blocked = dev.BlockedHalf.from_dense(dev.as_device(inputs[0]))
     x = blocked if blocked is not None else dev.as_device(inputs[0])
     n, c, h, w = x.shape
     oh, ow = calc_output_shape((h, w), kernel, strides, pads_begin, pads_end, attrs['rounding_type'], attrs['auto_pad'])
@@ -119,6 +135,20 @@ def compute(node: dict, inputs: dict = None, kernel_type: str = 'hip', debug: bo
     if blocked is not None and oh > 0 and ow > 0:
         # FP16 IRs: the input is fp16 blocked by eight channels (dev.BlockedHalf, what the reference holds here is a float16 tensor):
         # pooled as it is, the output is blocked too
+        conv = node.get('_fuse_conv')
+        if lrn_in is not None and conv is not None:
+            # MaxPool -> LRN -> 1x1 convolution (+ bias, ReLU) as one launch on the blocked tensor: the output is the convolution's, blocked too
+            la = lrn_in['data']
+            cw = dev.as_device(conv['w'])
+            cb_ = dev.as_device(conv['bias']) if conv.get('bias') is not None else None
+            k_out = cw.shape[0]
+            assert tuple(cw.shape[1:]) == (c, 1, 1) and (cb_ is None or cb_.size == k_out) and (conv.get('act') is None or conv['act'][0] == 'relu')
+            yc = dev.BlockedHalf((n, k_out, oh, ow))
+            dev.call('pvhip_maxpool3x3_lrn_conv1x1_c8', ctypes.c_void_p(blocked.ptr), ctypes.c_void_p(cw.ptr), ctypes.c_void_p(yc.ptr), n, c, h, w, oh, ow,
+                     strides[0], strides[1], pads_begin[0], pads_begin[1], pads_end[0], pads_end[1], int(la['size']), float(la['alpha']), float(la['beta']),
+                     float(la['bias']), k_out, ctypes.c_void_p(cb_.ptr if cb_ is not None else 0), 1 if conv.get('act') is not None else 0)
+            conv['node']['_hip_f16'] = 'inside MaxPool + LRN (blocked tensors)'
+            return {common_def.first_output_port(node): yc}
         yb = dev.BlockedHalf((n, c, oh, ow))
         if lrn_in is not None:       # MaxPool + LRN as one launch, on the blocked tensor
             la = lrn_in['data']

@@ -661,6 +661,9 @@ def test_googlenet_fp16_ir_whole_modules_on_blocked_fp16_tensors(hip, tmp_path, 
     ex = ie.load_network(net)
     prob = helpers.infer_one(ex, net, images)
     assert len(ex._c8_concat) == 9 and len(ex._c8_entry) == 0          # (no conversion: the stem hands module 3a a blocked tensor)
+    assert len(ex._stem_conv) == 1                                       # conv2/3x3_reduce rides in the blocked MaxPool + LRN launch (round 5)
+    reduce_ = next(iter(ex._stem_conv.values()))
+    assert net.G.nodes[reduce_]['_hip_f16'] == 'inside MaxPool + LRN (blocked tensors)'
     conv1 = next(n for n in net.G.nodes if net.G.nodes[n]['type'] == 'Convolution' and net.G.nodes[n]['input'][1]['dims'][2] == 7)
     assert net.G.nodes[conv1]['_hip_f16'] == 'row spans, blocked output'        # the stem: conv1 -> (MaxPool + LRN on the blocked tensor) -> conv2/3x3_reduce
     pool1 = next(iter(net.G.successors(ex._fusion[conv1]['relu'])))

@@ -1577,6 +1577,50 @@ def test_fp16_stem_on_blocked_tensors(hip):
         assert_close(np.nan_to_num(g), np.nan_to_num(want), 1e-3, 'LRN + MaxPool on a blocked tensor {}'.format(xs), elementwise=False)
 
 
+@pytest.mark.parametrize('xs,st,pb,pe,rounding,k_out,act', [
+    ((2, 64, 112, 112), (2, 2), (0, 0), (0, 0), 'ceil', 64, ('relu',)),      # GoogLeNet (FP16 IR) pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce
+    ((3, 20, 13, 11), (2, 2), (0, 0), (0, 0), 'ceil', 40, None),             # channels that end inside a block, output channels inside a 32-channel tile
+    ((1, 24, 12, 16), (1, 1), (1, 1), (1, 1), 'floor', 8, ('relu',)),
+    ((5, 48, 30, 28), (2, 2), (1, 0), (0, 1), 'floor', 33, ('relu',)),
+])
+def test_fused_maxpool_lrn_conv1x1_on_blocked_tensors(hip, xs, st, pb, pe, rounding, k_out, act):
+    """FP16 IRs: MaxPool 3x3 -> LRN -> 1x1 convolution (+ bias, ReLU) on blocked fp16 tensors as ONE launch (pvhip_maxpool3x3_lrn_conv1x1_c8,
+    round 5: the eight normalised channels a lane holds are two operands of v_mfma_f32_32x32x4_2b_f16).  Against MaxPool + LRN on the blocked
+    tensor followed by the fp32 arithmetic of the convolution on ITS fp16 output (one fp16 rounding of the result: 2e-3), and the blocked output
+    holds fp16 values with zeros past k_out."""
+    from pyopenvino_amd import device as dev
+    pool = hip_plugin('MaxPool')
+    x = f16r(rnd(sum(xs), xs, 40.0))
+    axes = np.array([1], dtype=np.int64)
+    pnode = make_node('MaxPool', [x], pool_data((3, 3), st, pb, pe, rounding))
+    pooled = np.asarray(pool.compute(dict(pnode), {0: x})[1])
+    lnode = make_node('LRN', [pooled, axes], {'alpha': '9.9999997473787516e-05', 'beta': '0.75', 'bias': '1', 'size': '5'})
+    lnode['output'][2]['dims'] = tuple(pooled.shape)
+    w = f16r(rnd(7, (k_out, xs[1], 1, 1), (2.0 / xs[1]) ** 0.5))
+    bias = rnd(9, (1, k_out, 1, 1))
+    cnode = make_node('Convolution', [pooled, w], conv_data((1, 1), (0, 0), (0, 0)))
+    assert pool.lrn_conv_fusable(pnode, lnode, cnode, True)
+    two = dict(pnode)
+    two['output'] = {1: {'precision': 'FP32', 'dims': tuple(pooled.shape)}}
+    two['_fuse_lrn'] = lnode
+    xb = dev.BlockedHalf.from_dense(dev.DeviceTensor.from_numpy(x))
+    normed = pool.compute(dict(two), {0: xb})[1]
+    assert isinstance(normed, dev.BlockedHalf)
+    want = first_out(oracle_plugin('Convolution').compute(cnode, {0: np.asarray(normed), 1: w}, kernel_type='special')) + bias
+    if act is not None:
+        want = np.where(want < 0, 0, want)
+    fused = dict(two)
+    fused['_fuse_conv'] = {'node': cnode, 'w': w, 'bias': dev.DeviceTensor.from_numpy(bias), 'act': act, 'c8': True}
+    got = pool.compute(fused, {0: xb})[1]
+    assert isinstance(got, dev.BlockedHalf) and got.shape == want.shape
+    g = np.asarray(got)
+    assert_bit_exact(g, f16r(g), 'a blocked output holds fp16 values')
+    assert_close(g, want.astype(np.float32), 2e-3, 'MaxPool + LRN + 1x1 on blocked tensors {}'.format(xs), elementwise=False)
+    # a dense input where the plan promised a blocked one is converted, not an error
+    g2 = np.asarray(pool.compute(dict(fused), {0: x})[1])
+    assert_bit_exact(g2, g, 'dense input converted by the plugin')
+
+
 def test_avgpool_on_a_blocked_tensor(hip):
     """AvgPool (the reference's window rule: the 7x7 pool averages the top-left 6x6) on fp16 blocked by eight channels, fp32 output holding
     fp16 VALUES (the reference's AvgPool of a float16 tensor returns float16: AvgPool.py:57-58): the fp16 rounding of what the fp32 launch
