@@ -116,10 +116,11 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
 // IEEE 754-2019 maximum of three (gfx950: v_maximum3_f32): a NaN operand gives NaN -- np.max's rule -- in ONE instruction.  v_max3_f32
 // is maxNum (a NaN operand LOSES): next to it every window needed unordered compares, an OR chain and a select (a third of the pooling
 // arithmetic of conv_pool1x1_kernel, which runs on the SIMDs that run the MFMAs).  Two operands: max3_nan(a, b, b).
+// Through the builtin, not inline asm: an asm statement is opaque to hipcc's hazard recognizer, and a value it writes one or two issue
+// slots before a v_mfma reads it as an operand arrives STALE (gfx950 wants two wait states between a VALU write and the matrix
+// instruction's read; round 5, a pooled value fed straight into v_mfma_f32_32x32x1_2b_f32: three of four pixel columns wrong).
 __device__ __forceinline__ float max3_nan(float a, float b, float c) {
-    float r;
-    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
 }
 
 
