@@ -34,7 +34,7 @@ extern "C" {
 #define PVHIP_ECOMM        -4   /* RCCL failure / library not loadable                        */
 #define PVHIP_EUNSUPPORTED -5   /* configuration outside what the kernels implement           */
 
-#define PVHIP_ABI_VERSION   15
+#define PVHIP_ABI_VERSION   16
 
 /* ---------------------------------------------------------------- runtime plumbing ---------- */
 /* No reference counterpart: the reference computes in host numpy arrays (inference_engine.py:245-256
@@ -208,6 +208,7 @@ int    pvhip_conv2d_f32(const float* x, const float* wpack, float* y,
 #define PVHIP_CONV_KIND_WINO_F4_3X3  3
 #define PVHIP_CONV_KIND_WINO_F2_5X5  4
 #define PVHIP_CONV_KIND_STEM         5   /* ABI v15: 7x7 / 2 over three channels from row spans (pvhip_stem.hip)  */
+#define PVHIP_CONV_KIND_STEM_WINO    6   /* ABI v16: the same layer as Winograd F(3x3,4x4) on the space-to-depth image  */
 int    pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int kw, int oh, int ow,
                                 int sh, int sw, int pad_top, int pad_left);
 /* MaxPool.py:41-72 (3x3 window, stride 1, pad 1 all round: output extent = input extent) followed by a 1x1 / stride 1 / unpadded
@@ -375,6 +376,18 @@ int    pvhip_conv2d_stem_f32(const float* xp, const float* wf, float* y, int n, 
 int    pvhip_conv2d_stem_direct_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
 int    pvhip_conv2d_stem_direct_f32(const float* x, const float* wf, float* y, int n, int h, int w, int k_out, int oh, int ow,
                                     const float* pre_add, const float* bias, int act, float act_lo, float act_hi);
+/* The same first convolution as WINOGRAD F(3x3, 4x4) on the space-to-depth image (ABI v16; Convolution.py:57-87 for a 7x7 / stride 2 / pad 3 layer
+ * over three channels): x'(c; py, px; i, j) = xpad(c, 2 i + py, 2 j + px) turns it into a 4x4 / stride 1 convolution over 12 channels, which
+ * 6x6-point tiles (the interpolation points of the F(4x4,3x3) / F(2x2,5x5) kernels) compute with 0.34 of the multiplies.  x: the UNPADDED
+ * (n, 3, h, w) fp32 image, h even, w % 4 == 0, w <= 224; oh = h / 2, ow = w / 2; k_out <= 64 and a multiple of 16; u: pvhip_conv2d_stem_wino_pack's transformed weights
+ * (pvhip_conv2d_stem_wino_pack_elems floats); pre_add / bias / act as pvhip_conv2d_stem_direct_f32.  NOT the bits of pvhip_conv2d_f32 (another
+ * order of summation): the tolerance of the other Winograd forms.  OPT-IN: pvhip_conv2d_kernel_kind answers PVHIP_CONV_KIND_STEM_WINO only with
+ * PVHIP_CONV_STEM_WINO=1 (measured at batch 256: 0.50 ms against the row-span kernel's 0.56, at 0.26 of the fp32 MFMA peak on executed flops).    */
+int    pvhip_conv2d_stem_wino_supported(int c, int h, int w, int k_out, int kh, int kw, int sh, int sw, int pad_top, int pad_left, int oh, int ow);
+long   pvhip_conv2d_stem_wino_pack_elems(void);
+int    pvhip_conv2d_stem_wino_pack(const float* w_oihw, float* u, int k_out);
+int    pvhip_conv2d_stem_wino_f32(const float* x, const float* u, float* y, int n, int h, int w, int k_out, int oh, int ow,
+                                  const float* pre_add, const float* bias, int act, float act_lo, float act_hi);
 /* AvgPool.py:41-59 on a c8 tensor (the window rule of pvhip_avgpool2d_f32); the output is fp32 NCHW holding fp16 values (the mean in fp32,
  * rounded once: the reference's AvgPool of a float16 tensor returns float16). */
 int    pvhip_avgpool_c8(const void* x, float* y, int n, int c, int h, int w, int oh, int ow, int kh, int kw, int sh, int sw);

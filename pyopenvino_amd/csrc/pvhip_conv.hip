@@ -1293,7 +1293,8 @@ int pvhip_conv2d_kernel_kind(int n, int c, int h, int w, int k_out, int kh, int 
     // (the row-span kernel is an entry of its own, pvhip_conv2d_stem_f32: the caller pads the image to the row length it asks for)
     if (settings().conv_stem && pvhip_conv2d_stem_f32_supported(c, h, w, k_out, kh, kw, sh, sw, pad_top, pad_left, oh, ow) > 0 &&
         (unsigned long long)n * k_out * oh * ow * 4ull < (1ull << 31) && (unsigned long long)n * c * (h + 6) * 256ull * 4ull < (1ull << 31))
-        return PVHIP_CONV_KIND_STEM;
+        return (settings().conv_stem_wino && pvhip_conv2d_stem_wino_supported(c, h, w, k_out, kh, kw, sh, sw, pad_top, pad_left, oh, ow) > 0)
+                   ? PVHIP_CONV_KIND_STEM_WINO : PVHIP_CONV_KIND_STEM;
     if (pw_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow)) return PVHIP_CONV_KIND_POINTWISE;
     if (wino25_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) return PVHIP_CONV_KIND_WINO_F2_5X5;
     if (wino4_eligible(c, kh, kw, sh, sw, pad_top, pad_left, h, w, oh, ow, n)) return PVHIP_CONV_KIND_WINO_F4_3X3;

@@ -37,6 +37,7 @@ void load_settings() {
     s.conv_winograd5 = tri("PVHIP_CONV_WINOGRAD5");
     s.conv_pointwise = !is0("PVHIP_CONV_POINTWISE");
     s.conv_stem      = !is0("PVHIP_CONV_STEM");
+    { const char* e = env("PVHIP_CONV_STEM_WINO"); s.conv_stem_wino = e != nullptr && e[0] == '1'; }
     for (int i = 0; i < 8; ++i) {
         char name[16];
         snprintf(name, sizeof(name), "PVHIP_TUNE%d", i);

@@ -121,6 +121,10 @@ SIGNATURES = {
     'pvhip_conv2d_stem_f32_pack': (_c.c_int, [_fp, _fp, _c.c_int]),
     'pvhip_conv2d_stem_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 6 + [_fp, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_stem_direct_supported': (_c.c_int, [_c.c_int] * 12),
+    'pvhip_conv2d_stem_wino_supported': (_c.c_int, [_c.c_int] * 12),
+    'pvhip_conv2d_stem_wino_pack_elems': (_c.c_long, []),
+    'pvhip_conv2d_stem_wino_pack': (_c.c_int, [_fp, _fp, _c.c_int]),
+    'pvhip_conv2d_stem_wino_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 6 + [_fp, _fp, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_stem_direct_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 6 + [_fp, _fp, _c.c_int, _c.c_float, _c.c_float]),
     'pvhip_conv2d_pooled_supported': (_c.c_int, [_c.c_int] * 5),
     'pvhip_conv2d_pooled_f32': (_c.c_int, [_fp, _fp, _fp] + [_c.c_int] * 5 + [_fp, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float]),
@@ -139,7 +143,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_maxpool3x3_lrn_conv1x1_c8_supported', 'pvhip_conv2d_f16_stem_direct_supported', 'pvhip_maxpool_lrn_conv1x1_supported', 'pvhip_conv2d_stem_direct_supported', 'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_conv2d_stem_wino_supported', 'pvhip_conv2d_stem_wino_pack_elems', 'pvhip_maxpool3x3_lrn_conv1x1_c8_supported', 'pvhip_conv2d_f16_stem_direct_supported', 'pvhip_maxpool_lrn_conv1x1_supported', 'pvhip_conv2d_stem_direct_supported', 'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 

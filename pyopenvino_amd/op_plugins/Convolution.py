@@ -266,7 +266,7 @@ def prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end
     if f16:         # FP16 IRs: the c-major f16 form of the LDS-DMA kernel (every such layer: there is no Winograd or pointwise form in front of it)
         return dev.conv_f16_dma and bool(dev.call('pvhip_conv2d_f16_dma_supported', c, kh, kw))
     # (kind 5, the row-span kernel, pads its input in a pass of its own too: the Add in front of the layer rides in that pass just the same)
-    return int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) in (0, 5)
+    return int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) in (0, 5, 6)
 
 
 def pre_add_fusable(node: dict, add_node: dict, const_node: dict, f16: bool = False) -> bool:
@@ -369,15 +369,34 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
     if route is None or route[0] != route_key:
         span_ok, dma_ok = f16_route(c, h, wd, kh, kw, strides, pads_begin, oh, ow) if f16 else (False, False)
         stem_wps = 0           # fp32: a 7x7 / 2 first convolution over three channels from row spans (pvhip_conv2d_stem_f32): floats per padded row
-        if not f16 and tuple(pads_begin) == tuple(pads_end) and oh > 0 and ow > 0 and \
-                int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1])) == 5:
-            stem_wps = int(dev.call('pvhip_conv2d_stem_f32_supported', c, h, wd, kn, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
-        route = (route_key, prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16), span_ok, dma_ok, stem_wps)
+        stem_wino = False      # ... or as Winograd F(3x3,4x4) on the space-to-depth image (pvhip_conv2d_stem_wino_f32; kind 6)
+        if not f16 and tuple(pads_begin) == tuple(pads_end) and oh > 0 and ow > 0:
+            kind = int(dev.call('pvhip_conv2d_kernel_kind', n, c, h, wd, kn, kh, kw, oh, ow, strides[0], strides[1], pads_begin[0], pads_begin[1]))
+            if kind in (5, 6):
+                stem_wps = int(dev.call('pvhip_conv2d_stem_f32_supported', c, h, wd, kn, kh, kw, strides[0], strides[1], pads_begin[0], pads_begin[1], oh, ow))
+                stem_wino = kind == 6
+        route = (route_key, prepad_wanted(n, c, h, wd, kn, kh, kw, oh, ow, strides, pads_begin, pads_end, f16), span_ok, dma_ok, stem_wps, stem_wino)
         node['_hip_route'] = route
     if route[4] > 0 and into is None:
         # the zero-padded image in rows of route[4] floats (the per-channel Add in front of the layer rides in the padding pass), then the
         # row-span kernel: weights resident in registers, no vector instruction in its reduction loop
         wps = route[4]
+        if route[5]:
+            # Winograd F(3x3,4x4) on the space-to-depth image: the 7x7 / 2 layer as a 4x4 / 1 one over 12 phase channels, 0.34 of the multiplies
+            cached = node.get('_hip_wpack_stemw')
+            if cached is None or cached[0] is not w._block:
+                u = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_stem_wino_pack_elems')),))
+                dev.call('pvhip_conv2d_stem_wino_pack', ctypes.c_void_p(w.ptr), ctypes.c_void_p(u.ptr), kn)
+                cached = node['_hip_wpack_stemw'] = (w._block, u)
+            y = dev.DeviceTensor.empty((n, kn, oh, ow))
+            act_code, act_lo, act_hi = 0, 0.0, 0.0
+            if act is not None:
+                act_code = 1 if act[0] == 'relu' else 2
+                if act_code == 2:
+                    act_lo, act_hi = float(act[1]), float(act[2])
+            dev.call('pvhip_conv2d_stem_wino_f32', ctypes.c_void_p(x.ptr), ctypes.c_void_p(cached[1].ptr), ctypes.c_void_p(y.ptr), n, h, wd, kn, oh, ow,
+                     ctypes.c_void_p(pre_add.ptr if pre_add is not None else 0), ctypes.c_void_p(bias.ptr if bias is not None else 0), act_code, act_lo, act_hi)
+            return y
         cached = node.get('_hip_wpack_stem32')
         if cached is None or cached[0] is not w._block:
             wf = dev.DeviceTensor.empty((int(dev.call('pvhip_conv2d_stem_f32_pack_elems', kn)),))
@@ -451,6 +470,7 @@ def launch(node, x, w, strides, pads_begin, pads_end, auto_pad, bias=None, act=N
 
 # pvhip_conv2d_kernel_kind codes -> (family name, fraction of the algorithmic multiply-adds the matrix cores execute)
 KERNEL_KINDS = {5: ('row spans (stem)', 148.0 / 147.0),          # four taps per MFMA step: 147 taps in 37 steps, one slot of zero weight
+                6: ('Winograd F(3x3,4x4), space-to-depth (stem)', 36.0 * 4.0 / (9.0 * 49.0)),      # 36 points x 4 phases per 9 outputs x 49 taps
                 0: ('implicit GEMM (LDS-DMA)', 1.0), 1: ('pointwise', 1.0), 2: ('Winograd F(2x2,3x3)', 16.0 / 36.0),
                 3: ('Winograd F(4x4,3x3)', 36.0 / 144.0), 4: ('Winograd F(2x2,5x5)', 36.0 / 100.0)}
 
@@ -463,7 +483,7 @@ def kernel_kind(node: dict):
     code = dev.call('pvhip_conv2d_kernel_kind', int(xd[0]), int(xd[1]), int(xd[2]), int(xd[3]), int(wd[0]), int(wd[2]), int(wd[3]), oh, ow,
                     strides[0], strides[1], pb[0], pb[1])
     family, frac = KERNEL_KINDS[int(code)]
-    m = {2: 2, 3: 4, 4: 2}.get(int(code))          # Winograd: whole m x m output patches are computed (14x14 as 16x16 under F(4x4))
+    m = {2: 2, 3: 4, 4: 2, 6: 3}.get(int(code))          # Winograd: whole m x m output patches are computed (14x14 as 16x16 under F(4x4))
     if m:
         frac *= (-(-oh // m) * m) * (-(-ow // m) * m) / float(oh * ow)
     return family, frac

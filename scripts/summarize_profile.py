@@ -15,13 +15,13 @@ import sys
 
 def is_conv(name):
     """The kernels behind the Convolution nodes: implicit GEMM (also with the MaxPool in front folded in), the Winograd forms, the pointwise kernel."""
-    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name or 'conv_stem_f32_kernel' in name
+    return 'conv_igemm' in name or 'conv_wino' in name or 'conv_pool1x1' in name or 'conv_pw_kernel' in name or 'conv_stem_f32_kernel' in name or 'conv_stem_wino_kernel' in name
 
 
 def conv_family(name):
     """Which convolution kernel: the split of `convolution_kernels` (profiles/<tag>_traffic.json: convolution_kernels_by_family)."""
     for key, fam in (('conv_wino4s_kernel', 'conv_wino4s_kernel'), ('conv_wino4_kernel', 'conv_wino4_kernel'), ('conv_wino_kernel', 'conv_wino_kernel'), ('conv_pw_kernel', 'conv_pw_kernel'),
-                     ('conv_pool1x1_kernel', 'conv_pool1x1_kernel'), ('conv_stem_f32_kernel', 'conv_stem_kernel'), ('conv_igemm_dma_kernel', 'conv_igemm_dma_kernel'), ('conv_igemm', 'conv_igemm_other')):
+                     ('conv_pool1x1_kernel', 'conv_pool1x1_kernel'), ('conv_stem_f32_kernel', 'conv_stem_kernel'), ('conv_stem_wino_kernel', 'conv_stem_kernel'), ('conv_igemm_dma_kernel', 'conv_igemm_dma_kernel'), ('conv_igemm', 'conv_igemm_other')):
         if key in name:
             return fam
     return None

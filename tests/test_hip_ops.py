@@ -427,6 +427,59 @@ def test_conv_prepadded_input_is_bit_identical(hip, monkeypatch):
     hip.reload_settings()
 
 
+def test_conv_stem_as_winograd_on_the_space_to_depth_image(hip, monkeypatch):
+    """PVHIP_CONV_STEM_WINO=1 (opt-in, round 5): a 7x7 / 2 / pad 3 first convolution over three channels as Winograd F(3x3,4x4) over the twelve
+    phase channels x'(c; py, px; i, j) = xpad(c, 2 i + py, 2 j + px) (pvhip_conv2d_stem_wino_f32: 0.34 of the multiplies).  Another order of
+    summation, so not the bits of the general kernel: against the oracle within the path's 1e-4 in the max norm AND element by element at
+    half the |d| <= 1e-4 |want| + 1e-4 rms(want) bound, as for the other Winograd forms -- whole images, bands of one tile row, partial tile
+    columns and rows (112 = 37 x 3 + 1), every epilogue, the Add in front of the layer (applied to the image, not to its padding),
+    un-centred pixels with outlier weights.  Without the knob, and for geometries the kernel does not take, the row-span kernel stays."""
+    from pyopenvino_amd import synth
+    from pyopenvino_amd.op_plugins import Convolution
+    st, pb, pe = (2, 2), (3, 3), (3, 3)
+    node0 = make_node('Convolution', [np.zeros((2, 3, 224, 224), np.float32), np.zeros((64, 3, 7, 7), np.float32)], conv_data(st, pb, pe))
+    assert Convolution.kernel_kind(node0)[0] == 'row spans (stem)'                    # the default
+    helpers.setenv(monkeypatch, 'PVHIP_CONV_STEM_WINO', '1')
+    family, frac = Convolution.kernel_kind(node0)
+    assert family.startswith('Winograd F(3x3,4x4)') and abs(frac - 38 * 38 * 36 * 12 / (112.0 * 112 * 147)) < 1e-9, (family, frac)
+    cases = [((2, 3, 224, 224), 64, ('relu',), False), ((3, 3, 56, 56), 64, None, False), ((1, 3, 36, 24), 48, ('relu',), False),
+             ((5, 3, 30, 32), 16, ('clamp', -40.0, 75.0), False), ((9, 3, 14, 8), 32, ('relu',), False), ((2, 3, 100, 224), 64, None, True)]
+    for i, (xs, k, act, hostile) in enumerate(cases):
+        ws = (k, 3, 7, 7)
+        if hostile:
+            x = synth.uniform_pixels(70 + i, xs)                                      # integers 0 .. 255, not centred
+            w = rnd(50 + i, ws, (2.0 / 147.0) ** 0.5)
+            w = np.where(synth.uniform_pixels(90 + i, ws) < 2.56, w * 50.0, w).astype(np.float32)      # ~1 % of the weights x 50
+        else:
+            x, w = rnd(40 + i, xs, 60.0), rnd(50 + i, ws, (2.0 / 147.0) ** 0.5)
+        c_add = rnd(11, (1, 3, 1, 1), 50.0)
+        bias = hip.DeviceTensor.from_numpy(rnd(5, (1, k, 1, 1))) if i != 1 else None
+        node = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+        node['_fuse_bias'], node['_fuse_act'] = bias, act
+        assert Convolution.kernel_kind(node)[0].startswith('Winograd F(3x3,4x4)'), (xs, k)
+        for add in (None, c_add):
+            n2 = dict(node)
+            if add is not None:
+                n2['_pre_add'] = hip.DeviceTensor.from_numpy(add)
+            got = np.asarray(first_out(hip_plugin('Convolution').compute(n2, {0: x, 1: w})))
+            plain = make_node('Convolution', [x, w], conv_data(st, pb, pe))
+            xin = x if add is None else (x + add).astype(np.float32)
+            want = np.asarray(first_out(oracle_plugin('Convolution').compute(plain, {0: xin, 1: w}, kernel_type='special')))
+            if bias is not None:
+                want = want + np.asarray(bias).reshape(1, k, 1, 1)
+            if act is not None:
+                want = np.where(want < 0, 0, want) if act[0] == 'relu' else np.clip(want, act[1], act[2])
+            want = want.astype(np.float32)
+            what = 'conv1 as F(3x3,4x4) {} k={} {} add={}'.format(xs, k, act, add is not None)
+            assert_close(got, want, helpers.REL_TOL, what)
+            excess = helpers.elementwise_excess(got, want)
+            assert excess <= 0.5, '{}: only {:.2f} x inside the element-wise bound'.format(what, 1.0 / max(excess, 1e-9))
+    # geometries the Winograd form does not take stay on the row-span kernel (or wherever they were)
+    for xs, ws in (((2, 3, 30, 32), (40, 3, 7, 7)), ((2, 3, 31, 32), (16, 3, 7, 7)), ((2, 3, 32, 228), (16, 3, 7, 7))):
+        node = make_node('Convolution', [np.zeros(xs, np.float32), np.zeros(ws, np.float32)], conv_data(st, pb, pe))
+        assert not Convolution.kernel_kind(node)[0].startswith('Winograd F(3x3,4x4)'), (xs, ws)
+
+
 def test_conv_stem_row_span_kernel_has_the_bits_of_the_general_kernel(hip, monkeypatch):
     """A 7x7 / 2 / pad 3 first convolution over three channels (GoogLeNet's conv1) runs from row spans of the padded image with its weights
     resident in registers (pvhip_conv2d_stem_f32 on a padded copy; pvhip_conv2d_stem_direct_f32 straight from the image: no padding pass, the
