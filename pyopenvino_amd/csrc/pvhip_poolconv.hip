@@ -12,6 +12,7 @@
 // 0.0 -- no window logic at all.  NaN wins, as np.max.  The loads of the next stage's groups are issued as soon as a
 // group's registers are free, so a whole stage of them is always in flight.
 #include <cstdlib>
+#include <type_traits>
 
 #include "pvhip_common.h"
 
@@ -64,15 +65,18 @@ __device__ __forceinline__ void pc_load(pc_f1& d, __amdgpu_buffer_rsrc_t r, unsi
 
 // kF16 (FP16 IRs): the same tiles, a stage of 16 channels as ONE v_mfma_f32_32x32x16_f16 per 32-channel tile, both operands rounded to
 // fp16 as they are read from LDS (the maximum of the window is taken in fp32, then rounded: what MaxPool followed by pvhip_conv2d_f16_dma does)
-template <int BM, int VEC, bool kF16 = false>
-__global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(PoolConvArgs a) {      // 64 channels: 73 -> 64 registers, four workgroups per CU (3b: -3 %)
-    constexpr int BN = 128, TM = BM / 32, KK = kBK / 2;
-    constexpr int CONSUMERS = 4, PRODUCERS = 4;
+// NW (round 5): consumer waves = producer waves = pixels of the tile / 32; NW = 2 (tiles of 64 pixels, twice the workgroups, the same work per wave)
+// is an experiment that did not pay -- see conv2d_pooled_impl.
+template <int BM, int VEC, bool kF16 = false, int NW = 4>
+__global__ __launch_bounds__(NW * 128, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(PoolConvArgs a) {      // 64 channels: 73 -> 64 registers, four workgroups per CU (3b: -3 %)
+    constexpr int BN = 32 * NW, TM = BM / 32, KK = kBK / 2;
+    constexpr int CONSUMERS = NW, PRODUCERS = NW;
     constexpr int A_PIECES = kBK * BM * 4 / 1024, A_PER_WAVE = (A_PIECES + CONSUMERS - 1) / CONSUMERS;
     constexpr int GROUPS = BN / VEC;                 // pixel groups per channel row of the tile
     constexpr int CSUB = PRODUCERS * kWave / GROUPS;  // channels the producer lanes cover at once
     constexpr int ITER = kBK / CSUB;                 // producer iterations per stage
     constexpr unsigned kOob = 0x80000000u;
+    constexpr bool kWide = VEC == 2;                 // a group of two pixels is loaded as four (the columns around it ride along)
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
 
     __shared__ __attribute__((aligned(1024))) float As[2][kBK][BM];
@@ -135,9 +139,14 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
                 const bool ok = live && (unsigned)iy < (unsigned)a.H;
                 offv[r] = ok ? base + (unsigned)(iy * a.W) * 4u : kOob;
                 offe[r] = (ok && first && !zl) ? offv[r] - 4u : ((ok && last && !zr) ? offv[r] + (unsigned)VEC * 4u : kOob);
+                // VEC = 2 (round 5): ONE 16-byte load per row fetches the group AND both outer columns (from the column left of the group, or from the
+                // group itself where that column is padding: no offset below the tensor) -- the launch is bound by the NUMBER of vector-memory
+                // instructions its producers issue (ablation: the mostly out-of-range outer-column loads cost as much as the group loads)
+                if (kWide) offv[r] = ok ? offv[r] - (zl ? 0u : 4u) : kOob;
             }
         }
-        vec_t ring[ITER][3];                 // per iteration and row: the group
+        typedef typename std::conditional<kWide, pc_f4, vec_t>::type ring_t;
+        ring_t ring[ITER][3];                // per iteration and row: the group (kWide: with the columns around it)
         float edge[ITER][3];                 //                        first / last lane: its outer column
 #define PVP_LOAD(it_, s_)                                                                                        \
     {                                                                                                            \
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
         _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
             if (abl & 1) continue;                                                                               \
             pc_load(ring[it_][r], xr, offv[r], soff);                                                            \
+            if (kWide) continue;                                                                                 \
             if (abl & 32) { edge[it_][r] = 0.0f; continue; }                                                     \
             edge[it_][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offe[r], soff, 0));  \
         }                                                                                                        \
@@ -156,7 +166,21 @@ __global__ __launch_bounds__(512, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(Poo
 #define PVP_POOL(it_, buf_, s_next_)                                                                             \
     {                                                                                                            \
         if (abl & 2) {                                                                                           \
-            *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = ring[it_][1];                     \
+            vec_t q_;                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < VEC; ++i) q_[i] = ring[it_][1][i];                             \
+            *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = q_;                               \
+            PVP_LOAD(it_, s_next_);                                                                              \
+            continue;                                                                                            \
+        }                                                                                                        \
+        if (kWide) {                                                                                             \
+            float q_[4];                 /* column maxima of the four loaded columns */                          \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) q_[c] = max3_nan(ring[it_][0][c], ring[it_][1][c], ring[it_][2][c]); \
+            const float own0_ = zl ? q_[0] : q_[1], own1_ = zl ? q_[1] : q_[2];                                  \
+            const float lft_ = zl ? 0.0f : q_[0], rgt_ = zr ? 0.0f : (zl ? q_[2] : q_[3]);                       \
+            vec_t o2_;                                                                                           \
+            o2_[0] = max3_nan(lft_, own0_, own1_);                                                               \
+            o2_[VEC - 1] = max3_nan(own0_, own1_, rgt_);                                                         \
+            *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = o2_;                              \
             PVP_LOAD(it_, s_next_);                                                                              \
             continue;                                                                                            \
         }                                                                                                        \
@@ -330,9 +354,26 @@ static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int 
     int bm = k_out <= 32 ? 32 : (k_out <= 64 ? 64 : 128);
     if (settings().tune[0] == 32 || settings().tune[0] == 64) bm = settings().tune[0] < bm ? settings().tune[0] : bm;      // experiment: narrower channel tiles = more workgroups
     a.n_mtiles = (k_out + bm - 1) / bm;
-    const int n_ptiles = (a.P + 127) / 128;
-    const dim3 grid((unsigned)(a.n_mtiles * n_ptiles)), block(512);
+    // Tiles of 64 pixels (NW = 2: twice the workgroups) only with PVHIP_TUNE1=2 (A/B runs; scripts/time_poolconv_bn.py).  MEASURED, same box: the 14x14
+    // modules at batch 256 (392 tiles of 128 pixels for 256 CUs) 0.064-0.067 ms either way, 4e and 3b 15-30 % SLOWER on the narrow tiles: a CU's
+    // rate over these stages does not depend on how many workgroups share it (16 images: one tile per CU takes 0.037 ms = 1.25 us per stage,
+    // the load latency; 256 images: 0.066 ms at 1.5 tiles per CU) -- the bound is not occupancy.
+    const int  n_pt128 = (a.P + 127) / 128;
+    const bool narrow  = !f16 && w % 2 == 0 && settings().tune[1] == 2;
+    const int  n_ptiles = narrow ? (a.P + 63) / 64 : n_pt128;
+    const dim3 grid((unsigned)(a.n_mtiles * n_ptiles)), block(narrow ? 256 : 512);
     const bool v4 = w % 4 == 0;
+    if (narrow) {
+#define PVP_NARROW(BM_)                                                                                                       \
+        { if (v4) hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 4, false, 2>), grid, block, 0, state().stream, a);             \
+          else    hipLaunchKernelGGL((conv_pool1x1_kernel<BM_, 2, false, 2>), grid, block, 0, state().stream, a); }
+        if (bm == 32) PVP_NARROW(32)
+        else if (bm == 64) PVP_NARROW(64)
+        else PVP_NARROW(128)
+#undef PVP_NARROW
+        PVHIP_LAUNCH_CHECK();
+        return PVHIP_OK;
+    }
 #define PVP_LAUNCH(BM_)                                                                                           \
     do {                                                                                                          \
         if (f16) {                                                                                                \
