@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU-box tool: MaxPool 3x3/s1 + pool_proj (pvhip_conv2d_pooled_f32) of GoogLeNet's inception modules at batch 256 on tiles of 128 pixels
-(PVHIP_TUNE1=1), of 64 (=2) and with the rule (unset), alternating on one box, with a bit comparison."""
+(the default; PVHIP_TUNE1=1 too), of 64 (=2), alternating on one box, with a bit comparison."""
 import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
