@@ -48,6 +48,8 @@ struct WinoArgs {
     int   s_prio;           // conv_wino4s_kernel: producers at wave priority 3, epilogues at 2 (PVHIP_WINO_SHARED_PRIO=0: everything at 0)
     int   s_old;            // conv_wino4s_kernel: producers are waves 0-3 (the oldest) rather than 12-15
     int   s_lag;            // conv_wino4s_kernel: the second consumer group starts kSLag stages behind the first (PVHIP_WINO_SHARED_LAG=0: together)
+    int   s_order;          // conv_wino4s_kernel: 1 = tiles in channel-pair-major order (a workgroup, and with it an XCD, stays on ONE pair's slice of the transformed weights
+                            // across patch blocks); 0 = patch-block-major (the pairs of a patch block follow each other: its patches come out of L2)
     // conv_wino4_kernel: patch index -> (image, patch row, patch column) by multiply-high and shift (w4_magic): the divisors are
     // wave-uniform, but hipcc's own division keeps their reciprocals in VECTOR registers across the main loop -- spilled there
     unsigned tpi_mul, tpi_sh, tx_mul, tx_sh;
@@ -1217,6 +1219,9 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int n_kp    = (a.n_kb + 1) >> 1;              // pairs of channel blocks (an odd count: the last pair is one block, its second consumer group only keeps the counters going)
+    const int n_tb_s  = a.n_tiles / n_kp;               // patch blocks
+#define PVS_PAIR(t_)  (a.s_order ? (t_) / n_tb_s : (t_) % n_kp)
+#define PVS_BLOCK(t_) (a.s_order ? (t_) % n_tb_s : (t_) / n_kp)
     const int n_tiles = a.n_tiles;                      // patch blocks x pairs
     const int n_eff   = a.n_stages;                     // a multiple of 4 (wino4_conv)
 
@@ -1264,7 +1269,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         const bool first = l31 == 0, last = l31 == 31;
 #define PVS_ADDRESSES(tile_, zl_, zh_, nv_)                                                                       \
     {                                                                                                            \
-        const int  t    = ((tile_) / n_kp) * NT + l31;                                                           \
+        const int  t    = PVS_BLOCK(tile_) * NT + l31;                                                           \
         const bool live = (tile_) < n_tiles && t < a.T;                                                          \
         const int  tq = live ? t : 0;                                                                            \
         const int  n = w4_div(tq, a.tpi_mul, a.tpi_sh), rem = tq - n * TPI;                                      \
@@ -1368,7 +1373,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
     {                                                                                                            \
         const int it_ = (int)(p_store >> 3), p_ = (int)(p_store & 7u);                                           \
         const int tile_s = L + it_ * G;                                                                          \
-        const int kb_e = 2 * (tile_s % n_kp) + pair, tb_e = tile_s / n_kp;                                       \
+        const int kb_e = 2 * PVS_PAIR(tile_s) + pair, tb_e = PVS_BLOCK(tile_s);                                 \
         int lane_e;                                                                                              \
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));            \
         const int tl = lane_e & 31, lh_e = lane_e >> 5;                                                          \
@@ -1529,7 +1534,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         unsigned pass_n = 0u;                            // exchange passes of this group written so far
         const unsigned ready0 = PVS_LDS_ADDR(&sm.ready[0]), done0 = PVS_LDS_ADDR(&sm.done[0]);
         typedef float exv_t __attribute__((ext_vector_type(M)));
-#define PVS_U_BASE(tile_) ((unsigned)(min(2 * ((tile_) % n_kp) + grp, a.n_kb - 1) * (a.n_stages + 1)) * u_stage_bytes)
+#define PVS_U_BASE(tile_) ((unsigned)(min(2 * PVS_PAIR(tile_) + grp, a.n_kb - 1) * (a.n_stages + 1)) * u_stage_bytes)
         w4_float4v ua[3];
         {
             const unsigned u_first = PVS_U_BASE(L);
@@ -1545,7 +1550,7 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         if (grp == 1 && a.s_lag != 0) w4s_wait_ge(done0 + 4u * (unsigned)(kSLag - 1), 6u);
         for (int tile = L; tile < n_tiles; tile += G) {
             const unsigned u_base = PVS_U_BASE(tile), u_next = PVS_U_BASE(tile + G);
-            if (2 * (tile % n_kp) + grp >= a.n_kb) {
+            if (2 * PVS_PAIR(tile) + grp >= a.n_kb) {
                 // the unpaired last block of an odd count: this group has no channels in the tile.  It releases every image at once and
                 // hands the producers empty passes (they store nothing: kg >= K), so that the counters of both protocols keep their meaning
                 for (int s = 0; s < n_eff; ++s, ++q) {
@@ -1654,6 +1659,8 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
         }
 #undef PVS_LOAD_U
 #undef PVS_U_BASE
+#undef PVS_PAIR
+#undef PVS_BLOCK
 #undef Exg
     }
 #ifdef PVHIP_DIAG
@@ -1714,7 +1721,7 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.u_bytes = (unsigned)(wino_pack_elems(k_out, c) * 4);
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
-    a.balance = 0; a.n_tiles = 0; a.s_lag = 0; a.s_prio = 0; a.s_old = 0;
+    a.balance = 0; a.n_tiles = 0; a.s_lag = 0; a.s_prio = 0; a.s_old = 0; a.s_order = 0;
     a.tpi_mul = a.tpi_sh = a.tx_mul = a.tx_sh = 0u;
 #ifdef PVHIP_DIAG
     if (settings().wino4_ablate == 5) a.balance = 5;          // diagnostic build: s_memtime stamps (scripts/stamps_wino.py)
@@ -1797,6 +1804,11 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     a.s_lag = settings().wino_shared_lag;
     a.s_prio = settings().wino_shared_prio;
     a.s_old = settings().wino_shared_old;
+    // Tile order of the shared-V form.  MEASURED (scripts/traffic_wino_order.sh, FETCH_SIZE per launch; scripts/time_wino_order.py): channel-pair-major reads
+    // 58.5 / 79.8 MB instead of 68.9 / 96.8 on the 7x7 layers 5a / 5b (their transformed weights, 7.4 / 10.6 MB, are the LARGER operand and do not fit an
+    // XCD's 4 MB L2; -1.2 % time) and 90-191 MB instead of 70-186 on the 14x14 layers (there the input is the larger one and is then re-read per pair; time
+    // within +-1 %).  So: pair-major where twice the weights outweigh the input (5a, 5b).  PVHIP_TUNE3=1: always, =2: never (A/B runs).
+    a.s_order = settings().tune[3] == 1 ? 1 : (settings().tune[3] == 2 ? 0 : (2 * wino4_pack_elems(k_out, c) > (size_t)n * c * h * w ? 1 : 0));
     a.n_stages = c / kCB;
     a.x_bytes = (unsigned)((size_t)n * c * h * w * 4);
     a.u_bytes = (unsigned)(wino4_pack_elems(k_out, c) * 4);
