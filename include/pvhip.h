@@ -60,6 +60,8 @@ int         pvhip_pool_epoch_dispatched(void);          /* later allocations bel
 int         pvhip_pool_epoch_end(int epoch);
 int         pvhip_memcpy_h2d(void* dst, const void* src, size_t bytes);  /* Parameter.py:11-13, Const.py:11-13 upload; async w.r.t. device, host buffer reusable on return */
 int         pvhip_memcpy_d2h(void* dst, const void* src, size_t bytes);  /* Result.py:17 read-back; SYNCHRONISES the stream */
+void*       pvhip_host_alloc(size_t bytes);   /* ABI v16: page-locked host memory for read-backs (NULL when it cannot be had: use pageable memory) */
+int         pvhip_host_free(void* p);
 int         pvhip_memcpy_d2d(void* dst, const void* src, size_t bytes);
 int         pvhip_memset(void* dst, int byte, size_t bytes);
 int         pvhip_sync(void);                           /* host-side wait for every compute stream   */

@@ -6,6 +6,7 @@ library is missing or no GPU is visible, every entry point raises -- there is no
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -40,6 +41,8 @@ SIGNATURES = {
     'pvhip_pool_stats': (_c.c_int, [_c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
     'pvhip_memcpy_h2d': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
     'pvhip_memcpy_d2h': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
+    'pvhip_host_alloc': (_c.c_void_p, [_c.c_size_t]),
+    'pvhip_host_free': (_c.c_int, [_c.c_void_p]),
     'pvhip_memcpy_d2d': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t]),
     'pvhip_memset': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_size_t]),
     'pvhip_sync': (_c.c_int, []),
@@ -143,7 +146,7 @@ SIGNATURES = {
 }
 
 # entry points whose return value is not a status code
-_NOT_STATUS = {'pvhip_conv2d_stem_wino_supported', 'pvhip_conv2d_stem_wino_pack_elems', 'pvhip_maxpool3x3_lrn_conv1x1_c8_supported', 'pvhip_conv2d_f16_stem_direct_supported', 'pvhip_maxpool_lrn_conv1x1_supported', 'pvhip_conv2d_stem_direct_supported', 'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
+_NOT_STATUS = {'pvhip_host_alloc', 'pvhip_conv2d_stem_wino_supported', 'pvhip_conv2d_stem_wino_pack_elems', 'pvhip_maxpool3x3_lrn_conv1x1_c8_supported', 'pvhip_conv2d_f16_stem_direct_supported', 'pvhip_maxpool_lrn_conv1x1_supported', 'pvhip_conv2d_stem_direct_supported', 'pvhip_conv2d_stem_f32_supported', 'pvhip_conv2d_stem_f32_pack_elems', 'pvhip_conv2d_f16_stem_supported', 'pvhip_conv2d_f16_stem_pack_elems', 'pvhip_lrn_maxpool3x3_c8_supported', 'pvhip_conv2d_f16_c8_multi_supported', 'pvhip_c8_f16_elems', 'pvhip_conv2d_f16_c8_supported', 'pvhip_conv2d_f16_c8_pack_elems', 'pvhip_conv2d_f16_pack_elems', 'pvhip_conv2d_f16_dma_supported', 'pvhip_conv2d_f16_span_supported', 'pvhip_conv2d_f16_span_pack_elems', 'pvhip_conv2d_kernel_kind', 'pvhip_abi_version', 'pvhip_last_error', 'pvhip_conv2d_pack_elems', 'pvhip_lrn_maxpool_supported', 'pvhip_maxpool_lrn_supported',
                'pvhip_conv2d_multi_supported', 'pvhip_conv2d_pooled_supported'}
 
 
@@ -320,6 +323,39 @@ def _contig_strides(shape):
     return tuple(reversed(st))
 
 
+_PINNED_MAX_BYTES = 8 << 20          # per array; larger read-backs (activations in tests) stay pageable
+_PINNED_POOL_BYTES = 64 << 20        # page-locked memory this process keeps at most
+_pinned_free = {}                    # rounded size -> [address, ...]
+_pinned_total = 0
+
+
+def _pinned_release(size, addr):
+    _pinned_free.setdefault(size, []).append(addr)
+
+
+def _pinned_empty(shape, dtype):
+    """np.empty in page-locked memory when the pool allows it (PVHIP_PINNED_RESULTS=0: never), else plain np.empty."""
+    global _pinned_total
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize if len(shape) else dtype.itemsize
+    if nbytes == 0 or nbytes > _PINNED_MAX_BYTES or os.environ.get('PVHIP_PINNED_RESULTS', '1') == '0':
+        return np.empty(shape, dtype=dtype)
+    size = 1 << max(12, (nbytes - 1).bit_length())
+    free = _pinned_free.get(size)
+    if free:
+        addr = free.pop()
+    else:
+        if _pinned_total + size > _PINNED_POOL_BYTES:
+            return np.empty(shape, dtype=dtype)
+        addr = call('pvhip_host_alloc', size)
+        if not addr:
+            return np.empty(shape, dtype=dtype)
+        _pinned_total += size
+    buf = (_c.c_char * size).from_address(addr)
+    weakref.finalize(buf, _pinned_release, size, addr)          # the array (and every view of it) keeps `buf` alive
+    return np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+
+
 class DeviceTensor:
     """A dense, C-contiguous tensor resident in HBM.
 
@@ -396,8 +432,9 @@ class DeviceTensor:
         return DeviceTensor(self._block, shape, self.dtype)
 
     def numpy(self) -> np.ndarray:
-        """Device-to-host copy (synchronises the compute stream)."""
-        out = np.empty(self.shape, dtype=self.dtype)
+        """Device-to-host copy (synchronises the compute stream).  Read-backs of up to a few MB (a Result) land in page-locked host memory from a
+        small pool -- one DMA instead of the runtime's staged copy into pageable memory; the block returns to the pool when the array is collected."""
+        out = _pinned_empty(self.shape, self.dtype)
         if out.nbytes:
             call('pvhip_memcpy_d2h', out.ctypes.data_as(_c.c_void_p), _c.c_void_p(self.ptr), out.nbytes)
         return out

@@ -1175,6 +1175,35 @@ def test_device_tensor_roundtrip_and_pool_reuse(hip):
     assert t2.ptr == ptr, 'a freed block of the same size is reused'
 
 
+def test_read_backs_land_in_page_locked_memory_and_the_pool_reuses_it(hip, monkeypatch):
+    """DeviceTensor.numpy() of up to a few MB copies into page-locked host memory (pvhip_host_alloc: one DMA instead of the runtime's staged copy
+    into pageable memory); the block goes back to the pool when the array AND its views are gone, larger read-backs and PVHIP_PINNED_RESULTS=0
+    use pageable memory.  The values are the tensor's either way; an array stays valid after the tensor is freed."""
+    import gc
+    from pyopenvino_amd import device as dev
+    x = rnd(3, (256, 1000))
+    t = hip.DeviceTensor.from_numpy(x)
+    a = t.numpy()
+    assert_bit_exact(a, x)
+    assert a.flags.writeable and a.base is not None                  # a view of a pool block
+    addr, size = a.ctypes.data, 1 << (x.nbytes - 1).bit_length()
+    row = a[7]
+    del a
+    gc.collect()
+    assert addr not in dev._pinned_free.get(size, []), 'a view keeps the block out of the pool'
+    del row
+    gc.collect()
+    assert addr in dev._pinned_free.get(size, [])
+    b = t.numpy()
+    assert b.ctypes.data == addr, 'the pool hands the block out again'
+    del t
+    assert_bit_exact(b, x)
+    big = hip.DeviceTensor.from_numpy(rnd(4, (3, 1024, 1024)))       # 12 MB: pageable
+    assert big.numpy().base is None
+    helpers.setenv(monkeypatch, 'PVHIP_PINNED_RESULTS', '0')
+    assert hip.DeviceTensor.from_numpy(x).numpy().base is None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # f16-MFMA kernels for FP16 IRs (SURVEY 8(f)-4): fp16 operands, fp32 accumulation
 FP16_TOL = 2e-2      # against the reference's OWN float16 arithmetic (it accumulates in float16: 11 significant bits per partial sum)
