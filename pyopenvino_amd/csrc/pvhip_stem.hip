@@ -18,7 +18,9 @@
 //     its pixel: ONE ds_read_b32 at [per-step lane offset] + [immediate: pixel group, buffer] serves the two MFMAs of a step and group --
 //     the 37 lane offsets (which row, which tap column: a step may straddle a filter row or a channel) are made once per kernel;
 //   * the weights of the wave's 32 channels x 148 slots live in 74 registers for the whole launch (fragment order, packed once);
-//   * epilogue: a lane holds four consecutive pixels of one channel per accumulator tile: bias, activation, one 16-byte store.
+//   * epilogue: a lane holds four consecutive pixels of one channel per accumulator tile: bias, activation -- and (the form that reads the image itself) the
+//     16 channels x 112 pixels of a tile pass through the wave's own 7 KB of LDS and leave as whole 448-byte rows, two channels per store instruction
+//     (0.584 -> 0.556 ms on one box: 16 x 64-byte pieces per instruction cost the address unit more than the same bytes as two rows).
 #include "pvhip_common.h"
 
 using namespace pvhip;
@@ -40,6 +42,11 @@ constexpr int kNG    = 7;                            // 16-pixel groups per outp
 constexpr int kWaves = 2 * kTR;                      // 8: two per SIMD
 constexpr int kThreads = kWaves * kWave;             // 512; ONE workgroup per CU
 constexpr unsigned kOob = 0x80000000u;
+constexpr bool kTransposeStores = true;              // the epilogue's stores as whole output rows, through LDS (a.tstores; PVHIP_TUNE4=1 switches it off)
+constexpr int kTsPitch = 116;                        // floats per channel row of a wave's transposition buffer (112 pixels + 4)
+constexpr int kTsWave  = 16 * kTsPitch;              // one accumulator tile: 16 channels
+constexpr int kTsBase  = 2 * kCopies * kLdsRow + 16; // floats: behind the two tile buffers, the spilled piece and the Add's constants
+constexpr int kTsBytes = kWaves * kTsWave * 4;       // 59392
 
 struct StemArgs {
     const float* xp;       // zero-padded input [N][3][HP][WP], WP % 4 == 0
@@ -52,6 +59,7 @@ struct StemArgs {
     unsigned x_bytes, y_bytes;
     int act;
     float act_lo, act_hi;
+    int tstores;           // 1: the epilogue's stores as whole rows through LDS (DIRECT form)
 };
 
 __device__ __forceinline__ float lds_read_f32(unsigned addr) {
@@ -237,6 +245,27 @@ __global__ __launch_bounds__(kThreads, 1) void conv_stem_f32_kernel(StemArgs a) 
             }
             // (each activation stores by itself: merging three register assignments of the 56 sums behind the branches cost ~200 copies and spills)
             auto store_all = [&]() {
+                if (kTransposeStores && a.tstores != 0) {
+                    // Whole rows instead of 16 x 64 bytes per instruction (round 5): the 16 channels x 112 pixels of an accumulator tile pass through THIS
+                    // wave's 7 KB of LDS (row pitch 116 floats; no barrier: LDS executes a wave's instructions in order) and leave as 448-byte rows,
+                    // two channels per store instruction (lanes 0-27 / 28-55).  The address pattern is what the stores cost (LESSONS 55, 59).
+                    float* const tl = stem_lds + kTsBase + wid * kTsWave;
+                    const int c2 = lane / 28, q = lane - 28 * c2;               // reader: channel c2 of a pair (lanes 56-63: none), pixel quad q
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                        for (int g = 0; g < kNG; ++g) *reinterpret_cast<floatx4*>(tl + l15 * kTsPitch + 16 * g + 4 * kq) = acc[g][t];
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) {
+                            const int ch = 32 * hf + 16 * t + 2 * p + c2;
+                            const floatx4 v = *reinterpret_cast<const floatx4*>(tl + (2 * p + (c2 & 1)) * kTsPitch + 4 * q);
+                            const bool ok = rowok && c2 < 2 && ch < a.K && 4 * q < a.OW;
+                            const unsigned vo = ok ? (unsigned)(((img * a.K + ch) * a.OH + oy) * a.OW * 4 + 16 * q) : kOob;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), yr, vo, 0, 0);
+                        }
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const bool chok = rowok && ch0 + 16 * t < a.K;
@@ -296,7 +325,8 @@ __global__ __launch_bounds__(kBlock) void conv_stem_f32_pack_kernel(const float*
 template <bool DIRECT>
 static int stem_launch(StemArgs& a, long tiles) {
     const int grid = (int)(tiles < kNumCU ? tiles : kNumCU);
-    const size_t lds = (size_t)2 * kBufBytes + (DIRECT ? 64 : 0);          // DIRECT: + the last row's lane 63, + the three constants of the folded Add
+    a.tstores = (DIRECT && settings().tune[4] != 1) ? 1 : 0;
+    const size_t lds = (size_t)2 * kBufBytes + (DIRECT ? 64 + kTsBytes : 0);          // DIRECT: + the last row's lane 63, + the three constants of the folded Add, + the waves' transposition buffers
     static bool attr_set = false;
     if (!attr_set) {
         PVHIP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_f32_kernel<0, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
