@@ -48,6 +48,7 @@ struct WinoArgs {
     int   s_prio;           // conv_wino4s_kernel: producers at wave priority 3, epilogues at 2 (PVHIP_WINO_SHARED_PRIO=0: everything at 0)
     int   s_old;            // conv_wino4s_kernel: producers are waves 0-3 (the oldest) rather than 12-15
     int   s_lag;            // conv_wino4s_kernel: the second consumer group starts kSLag stages behind the first (PVHIP_WINO_SHARED_LAG=0: together)
+    int   s_wide;           // conv_wino4s_kernel, ragged extents: whole patches store a row as ONE 16-byte piece (8-byte aligned on 14-wide rows) instead of two 8-byte ones
     int   s_order;          // conv_wino4s_kernel: 1 = tiles in channel-pair-major order (a workgroup, and with it an XCD, stays on ONE pair's slice of the transformed weights
                             // across patch blocks); 0 = patch-block-major (the pairs of a patch block follow each other: its patches come out of L2)
     // conv_wino4_kernel: patch index -> (image, patch row, patch column) by multiply-high and shift (w4_magic): the divisors are
@@ -1429,7 +1430,9 @@ __global__ __launch_bounds__(1024, 4) void conv_wino4s_kernel(WinoArgs a) {
                 float ov[M];                                                                                     \
                 _Pragma("unroll") for (int c2 = 0; c2 < M; ++c2) ov[c2] = yv[r2][c2];                            \
                 if (RAGGED) {                                                                                    \
-                    if (r2 < rows_ok) {                                                                          \
+                    if (r2 < rows_ok && M == 4 && cols_ok == M && a.s_wide != 0) {                               \
+                        conv_store4(yp + (size_t)r2 * OW, ov[0], ov[1], ov[2], ov[M - 1]);                       \
+                    } else if (r2 < rows_ok) {                                                                   \
                         _Pragma("unroll") for (int c2 = 0; c2 < M; c2 += 2) {                                    \
                             if (even_w && c2 + 1 < cols_ok) conv_store2(yp + (size_t)r2 * OW + c2, ov[c2], ov[c2 + 1]); \
                             else {                                                                               \
@@ -1721,7 +1724,7 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.u_bytes = (unsigned)(wino_pack_elems(k_out, c) * 4);
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
-    a.balance = 0; a.n_tiles = 0; a.s_lag = 0; a.s_prio = 0; a.s_old = 0; a.s_order = 0;
+    a.balance = 0; a.n_tiles = 0; a.s_lag = 0; a.s_prio = 0; a.s_old = 0; a.s_order = 0; a.s_wide = 0;
     a.tpi_mul = a.tpi_sh = a.tx_mul = a.tx_sh = 0u;
 #ifdef PVHIP_DIAG
     if (settings().wino4_ablate == 5) a.balance = 5;          // diagnostic build: s_memtime stamps (scripts/stamps_wino.py)
@@ -1804,6 +1807,7 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     a.s_lag = settings().wino_shared_lag;
     a.s_prio = settings().wino_shared_prio;
     a.s_old = settings().wino_shared_old;
+    a.s_wide = settings().tune[5] == 1 ? 0 : 1;       // (PVHIP_TUNE5=1: the old pieces.  Same box, alternating: the 7x7 layers -3 % -- their odd rows stored single floats --, the 14x14 layers +-0.5 %)
     // Tile order of the shared-V form.  MEASURED (scripts/traffic_wino_order.sh, FETCH_SIZE per launch; scripts/time_wino_order.py): channel-pair-major reads
     // 58.5 / 79.8 MB instead of 68.9 / 96.8 on the 7x7 layers 5a / 5b (their transformed weights, 7.4 / 10.6 MB, are the LARGER operand and do not fit an
     // XCD's 4 MB L2; -1.2 % time) and 90-191 MB instead of 70-186 on the 14x14 layers (there the input is the larger one and is then re-read per pair; time
