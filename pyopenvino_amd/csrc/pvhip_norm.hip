@@ -169,6 +169,7 @@ struct LrnPoolArgs {
     int   band_rows, n_bands;
     int   plane_l;               // floats per normalised plane in LDS
     float alpha, beta, bias;
+    int   pool4;                 // lrn_maxpool3x3_kernel: a lane pools FOUR adjacent outputs of a row (stride 2, no padding on top / left, ow % 4 == 0), the planes dealt over the waves
     int   abl;                   // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no LRN arithmetic, 2 no pooling, 4 no stores, 8 loads hit L2
 };
 
@@ -247,8 +248,60 @@ __global__ __launch_bounds__(kBlock) void lrn_maxpool3x3_kernel(LrnPoolArgs a, F
     const char* const planes_b = reinterpret_cast<const char*>(planes);
     const unsigned plane_bytes = (unsigned)a.plane_l * 4u;
 
+    // ---- the same pooling with FOUR adjacent outputs of a row per lane (round 5; a.pool4): their windows are nine columns of three rows -- two 16-byte
+    // and one 4-byte LDS read per row instead of 36 4-byte ones, sixteen v_maximum3_f32 as before, ONE 16-byte store instead of four 4-byte ones; the
+    // quads of a band fit one wave's lanes (rows_t x ow / 4 <= 64), so the planes of a chunk are dealt over the four waves (plane p: wave p % 4).
+    unsigned p4_row[3] = {0u, 0u, 0u}, p4_c8 = 0u, p4_out = 0u, p4_z = 0u;
+    bool     p4_live = false;
+    const int wv4 = tid >> 6;
+    if constexpr (VEC == 4 && ST == 2) {
+        if (a.pool4 != 0) {
+            const int ql = tid & 63, qpr = a.ow >> 2;
+            const int oyl = ql / qpr, oxq = ql - oyl * qpr;
+            p4_live = oyl < rows_t;
+            const int oy = oy0 + (p4_live ? oyl : 0);
+            const int py0 = oy * ST, c0 = 8 * oxq;                    // (pt = pl = 0)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p4_row[k] = (unsigned)((min(py0 + k, a.h - 1) - iy_lo) * a.w + c0) * 4u;
+            p4_c8 = (unsigned)(min(c0 + 8, a.w - 1) - c0) * 4u;        // the ninth column, clamped into the window (a duplicate does not change a maximum)
+            const bool zr = min(oy * ST + 2, a.hp - 1) >= a.h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p4_z |= ((zr || min((4 * oxq + j) * ST + 2, a.wp - 1) >= a.w) ? 1u : 0u) << j;
+            p4_out = (unsigned)(oy * a.ow + 4 * oxq);
+        }
+    }
+    auto pool4 = [&](int n_pl, int ch0) {
+        __syncthreads();
+        if (p4_live && !(abl & 2)) {
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            for (int p = wv4; p < n_pl; p += 4) {
+                const char* const pb = reinterpret_cast<const char*>(planes) + (unsigned)p * ((unsigned)a.plane_l * 4u);
+                float hm[3][4];                  // row maxima of the four windows: a NaN IS the maximum (max3_nan), as for np.max
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const f4_t lo = *reinterpret_cast<const f4_t*>(pb + p4_row[k]), hi = *reinterpret_cast<const f4_t*>(pb + p4_row[k] + 16);
+                    const float c8 = *reinterpret_cast<const float*>(pb + p4_row[k] + p4_c8);
+                    hm[k][0] = max3_nan(lo[0], lo[1], lo[2]);
+                    hm[k][1] = max3_nan(lo[2], lo[3], hi[0]);
+                    hm[k][2] = max3_nan(hi[0], hi[1], hi[2]);
+                    hm[k][3] = max3_nan(hi[2], hi[3], c8);
+                }
+                f4_t m;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float mj = max3_nan(hm[0][j], hm[1][j], hm[2][j]);
+                    m[j] = ((p4_z >> j) & 1u) ? max3_nan(mj, 0.0f, 0.0f) : mj;
+                }
+                if (!(abl & 4)) *reinterpret_cast<f4_t*>(a.y + (size_t)img * a.c * (a.oh * a.ow) + (size_t)(ch0 + p) * (a.oh * a.ow) + p4_out) = m;
+            }
+        }
+        __syncthreads();
+    };
     // pool the first n_pl planes of LDS into channels [ch0, ch0 + n_pl)
     auto pool = [&](int n_pl, int ch0) {
+        if constexpr (VEC == 4 && ST == 2) {
+            if (a.pool4 != 0) { pool4(n_pl, ch0); return; }
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -934,6 +987,8 @@ int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, 
 #ifdef PVHIP_DIAG
     a.abl = settings().conv_ablate;
 #endif
+    // four pooled outputs per lane (pool4 in the kernel): PVHIP_TUNE6=1 keeps one per lane (A/B runs)
+    a.pool4 = (vec == 4 && sh == 2 && pad_top == 0 && pad_left == 0 && ow % 4 == 0 && (ow / 4) * a.band_rows <= kWave && settings().tune[6] != 1) ? 1 : 0;
     const dim3 grid((unsigned)(n * a.n_bands));
     const FastDiv d_bands = make_fastdiv((unsigned)a.n_bands), d_ow = make_fastdiv((unsigned)ow);
     const int ni = (a.band_rows * ow + kBlock - 1) / kBlock;          // 1 at stride 2 (a band holds <= 1024 input pixels), up to 4 at stride 1

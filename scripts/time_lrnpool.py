@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU-box tool: GoogLeNet's conv2/norm2 + pool2/3x3_s2 at batch 256 as one launch against the two launches; checks the bits too."""
+"""GPU-box tool: GoogLeNet's conv2/norm2 + pool2/3x3_s2 at batch 256 as one launch (workgroup form with four pooled outputs per lane: the default; with one:
+PVHIP_TUNE6=1; the wave form: PVHIP_LRNPOOL_WAVE=1) against the two launches; checks the bits too."""
 import os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +21,9 @@ def fused_wg():
 def two():
     dev.call("pvhip_lrn_f32", _c.c_void_p(x.ptr), _c.c_void_p(t.ptr), n, c, h * w, 5, _c.c_float(1e-4 / 5 * 5), _c.c_float(0.75), _c.c_float(1.0))
     dev.call("pvhip_maxpool2d_f32", _c.c_void_p(t.ptr), _c.c_void_p(y2.ptr), n, c, h, w, oh, ow, 3, 3, 2, 2, 0, 0, 0, 0)
-for name, f in (('wave form', fused), ('workgroup form', fused_wg), ('two launches', two), ('wave form', fused)):
+for name, f in (('wave form', fused), ('workgroup form', fused_wg), ('workgroup form, one output per lane', fused_wg), ('two launches', two), ('workgroup form', fused_wg), ('workgroup form, one output per lane', fused_wg)):
     os.environ['PVHIP_LRNPOOL_WAVE'] = '1' if name == 'wave form' else '0'
+    os.environ['PVHIP_TUNE6'] = '1' if 'one output' in name else '0'
     dev.reload_settings()
     for _ in range(3):
         f()
@@ -32,6 +34,6 @@ for name, f in (('wave form', fused), ('workgroup form', fused_wg), ('two launch
     e1 = dev.Event().record(); e1.synchronize()
     ms = e0.elapsed_ms(e1) / 10
     mb = (x.nbytes + y.nbytes) / 1e6
-    print('{:15s} {:.3f} ms  {:.0f} GB/s of input + output'.format(name, ms, mb / ms))
+    print('{:38s} {:.4f} ms  {:.0f} GB/s of input + output'.format(name, ms, mb / ms))
 a, b = np.asarray(y), np.asarray(y2)
 print('same bits:', bool((a.view(np.uint32) == b.view(np.uint32)).all()))
