@@ -24,6 +24,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kBK = 16;
+constexpr int kRingDepth4 = 1;          // ... for groups of four pixels (the 28x28 modules: two stages need 73 registers -- fewer waves per SIMD -- and measured 6-12 % SLOWER)
+constexpr int kRingDepth2 = 2;          // stages of producer loads in flight for groups of two pixels (the 14x14 modules).  Three (168 registers, two workgroups per CU): 0.064 ms on 4a against 0.055 with two -- the waves a CU holds matter as much as the loads in flight
 
 struct PoolConvArgs {
     const float* x;
@@ -68,7 +70,7 @@ __device__ __forceinline__ void pc_load(pc_f1& d, __amdgpu_buffer_rsrc_t r, unsi
 // NW (round 5): consumer waves = producer waves = pixels of the tile / 32; NW = 2 (tiles of 64 pixels, twice the workgroups, the same work per wave)
 // is an experiment that did not pay -- see conv2d_pooled_impl.
 template <int BM, int VEC, bool kF16 = false, int NW = 4>
-__global__ __launch_bounds__(NW * 128, BM <= 64 ? 8 : 4) void conv_pool1x1_kernel(PoolConvArgs a) {      // 64 channels: 73 -> 64 registers, four workgroups per CU (3b: -3 %)
+__global__ __launch_bounds__(NW * 128, (BM <= 64 && VEC == 1) || (BM <= 64 && VEC == 4 && kRingDepth4 == 1) ? 8 : (VEC == 2 && kRingDepth2 > 2 ? 2 : 4)) void conv_pool1x1_kernel(PoolConvArgs a) {      // 64 channels: 73 -> 64 registers, four workgroups per CU (3b: -3 %)
     constexpr int BN = 32 * NW, TM = BM / 32, KK = kBK / 2;
     constexpr int CONSUMERS = NW, PRODUCERS = NW;
     constexpr int A_PIECES = kBK * BM * 4 / 1024, A_PER_WAVE = (A_PIECES + CONSUMERS - 1) / CONSUMERS;
@@ -146,47 +148,51 @@ __global__ __launch_bounds__(NW * 128, BM <= 64 ? 8 : 4) void conv_pool1x1_kerne
             }
         }
         typedef typename std::conditional<kWide, pc_f4, vec_t>::type ring_t;
-        ring_t ring[ITER][3];                // per iteration and row: the group (kWide: with the columns around it)
-        float edge[ITER][3];                 //                        first / last lane: its outer column
-#define PVP_LOAD(it_, s_)                                                                                        \
+        // TWO stages of loads in flight (round 5): with one, a stage lasted as long as its loads took to arrive -- s_memtime stamps on 4a: 3.0 k cycles
+        // per stage, the consumers 1.3 k of them in their MFMAs and 1.6 k at the barrier waiting for the producers, who were waiting for memory
+        // (groups of two pixels only -- the 14x14 modules, few tiles per CU: 128 registers there; the 28x28 modules keep one stage and 64 registers: eight waves per SIMD)
+        constexpr int RD = kWide ? kRingDepth2 : (VEC == 4 ? kRingDepth4 : 1);
+        ring_t ring[RD][ITER][3];            // per slot (stage % RD), iteration and row: the group (kWide: with the columns around it)
+        float edge[RD][ITER][3];             //                                          first / last lane: its outer column
+#define PVP_LOAD(it_, s_, sl_)                                                                                   \
     {                                                                                                            \
         const int se_ = (s_) < nk ? (s_) : nk - 1;                 /* past the end: the last stage again (unused) */ \
         const unsigned soff = (unsigned)(se_ * kBK + (it_) * CSUB) * chan_bytes;                                 \
         _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                          \
             if (abl & 1) continue;                                                                               \
-            pc_load(ring[it_][r], xr, offv[r], soff);                                                            \
+            pc_load(ring[sl_][it_][r], xr, offv[r], soff);                                                       \
             if (kWide) continue;                                                                                 \
-            if (abl & 32) { edge[it_][r] = 0.0f; continue; }                                                     \
-            edge[it_][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offe[r], soff, 0));  \
+            if (abl & 32) { edge[sl_][it_][r] = 0.0f; continue; }                                                \
+            edge[sl_][it_][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offe[r], soff, 0));  \
         }                                                                                                        \
     }
         // 3x3 max of iteration it_ into the B tile of buffer buf_ (columns first: one NaN-propagating max3 per column, the
         // outer columns' from the neighbour lanes, then a max3 over three adjacent columns per pixel), then the same registers
         // fetch stage s_next_
-#define PVP_POOL(it_, buf_, s_next_)                                                                             \
+#define PVP_POOL(it_, buf_, s_next_, sl_)                                                                             \
     {                                                                                                            \
         if (abl & 2) {                                                                                           \
             vec_t q_;                                                                                            \
-            _Pragma("unroll") for (int i = 0; i < VEC; ++i) q_[i] = ring[it_][1][i];                             \
+            _Pragma("unroll") for (int i = 0; i < VEC; ++i) q_[i] = ring[sl_][it_][1][i];                             \
             *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = q_;                               \
-            PVP_LOAD(it_, s_next_);                                                                              \
+            PVP_LOAD(it_, s_next_, sl_);                                                                              \
             continue;                                                                                            \
         }                                                                                                        \
         if (kWide) {                                                                                             \
             float q_[4];                 /* column maxima of the four loaded columns */                          \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) q_[c] = max3_nan(ring[it_][0][c], ring[it_][1][c], ring[it_][2][c]); \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) q_[c] = max3_nan(ring[sl_][it_][0][c], ring[sl_][it_][1][c], ring[sl_][it_][2][c]); \
             const float own0_ = zl ? q_[0] : q_[1], own1_ = zl ? q_[1] : q_[2];                                  \
             const float lft_ = zl ? 0.0f : q_[0], rgt_ = zr ? 0.0f : (zl ? q_[2] : q_[3]);                       \
             vec_t o2_;                                                                                           \
             o2_[0] = max3_nan(lft_, own0_, own1_);                                                               \
             o2_[VEC - 1] = max3_nan(own0_, own1_, rgt_);                                                         \
             *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = o2_;                              \
-            PVP_LOAD(it_, s_next_);                                                                              \
+            PVP_LOAD(it_, s_next_, sl_);                                                                              \
             continue;                                                                                            \
         }                                                                                                        \
         float cm_[VEC + 2];                  /* column maxima; a NaN in the column IS the maximum (max3_nan): no bookkeeping beside it */ \
-        _Pragma("unroll") for (int c = 0; c < VEC; ++c) cm_[c + 1] = max3_nan(ring[it_][0][c], ring[it_][1][c], ring[it_][2][c]); \
-        const float em_ = max3_nan(edge[it_][0], edge[it_][1], edge[it_][2]);                                    \
+        _Pragma("unroll") for (int c = 0; c < VEC; ++c) cm_[c + 1] = max3_nan(ring[sl_][it_][0][c], ring[sl_][it_][1][c], ring[sl_][it_][2][c]); \
+        const float em_ = max3_nan(edge[sl_][it_][0], edge[sl_][it_][1], edge[sl_][it_][2]);                                    \
         const float lm_ = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, cm_[VEC]), 0x138, 0xf, 0xf, true)); \
         const float rm_ = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, cm_[1]), 0x130, 0xf, 0xf, true)); \
         cm_[0]       = zl ? 0.0f : (first ? em_ : lm_);                                                          \
@@ -194,18 +200,25 @@ __global__ __launch_bounds__(NW * 128, BM <= 64 ? 8 : 4) void conv_pool1x1_kerne
         vec_t o_;                                                                                                \
         _Pragma("unroll") for (int i = 0; i < VEC; ++i) o_[i] = max3_nan(cm_[i], cm_[i + 1], cm_[i + 2]);        \
         *reinterpret_cast<vec_t*>(&Bs[buf_][(it_) * CSUB + cc][g * VEC]) = o_;                                   \
-        PVP_LOAD(it_, s_next_);                                                                                  \
+        PVP_LOAD(it_, s_next_, sl_);                                                                                  \
     }
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) PVP_LOAD(it, 0);
+        for (int q = 0; q < RD; ++q)
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) PVP_POOL(it, 0, 1);
+            for (int it = 0; it < ITER; ++it) PVP_LOAD(it, q, q);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) PVP_POOL(it, 0, RD, 0);              // B(0) from slot 0, which then fetches stage RD
         __syncthreads();
-        for (int s = 0; s < nk; ++s) {
-            const int buf = s & 1;
+        for (int s = 0; s < nk; s += RD) {                                     // stage q sits in slot q % RD and goes into B tile q & 1
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) PVP_POOL(it, buf ^ 1, s + 2);     // B(s+1); past the end: an unused tile
-            __syncthreads();
+            for (int d = 0; d < RD; ++d) {
+                if (s + d < nk) {
+                    const int bn = (s + d + 1) & 1;
+#pragma unroll
+                    for (int it = 0; it < ITER; ++it) PVP_POOL(it, bn, s + d + 1 + RD, (d + 1) % RD);     // B(s+d+1); past the end: an unused tile
+                    __syncthreads();
+                }
+            }
         }
 #undef PVP_LOAD
 #undef PVP_POOL
