@@ -72,7 +72,12 @@ struct Settings {
     int  wino_shared_min_tiles = 2048;      // PVHIP_WINO_SHARED_MIN_TILES: tiles (patch blocks x channel-block pairs) from which the rule picks it for launches of 12-16 stages
     // ---- wrong-on-purpose ablations: honoured only by the diagnostic build (make diag -> libpvhip_diag.so, -DPVHIP_DIAG)
     int  conv_ablate = 0, wino4_ablate = 0, pw_ablate = 0, stem_ablate = 0;
-    int  tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // PVHIP_TUNE0 .. PVHIP_TUNE7: free knobs of whatever experiment is running (A/B scripts; 0 = the product's choice)
+    // PVHIP_TUNE0 .. PVHIP_TUNE7: A/B knobs of the measurements this round kept (0 = the product's choice; every alternative is bit-identical):
+    //   0: 32 | 64 = narrower channel tiles of MaxPool + pool_proj          1: 2 = its pixel tiles of 64 instead of 128 (1 = never)
+    //   3: shared-V Winograd tile order, 1 = channel-pair-major always, 2 = never     4: 1 = conv1's stores as 16 x 64-byte pieces (not whole rows through LDS)
+    //   5: 1 = ragged Winograd patches store 8-byte / 4-byte pieces           6: 1 = LRN + MaxPool pools one output per lane (not four)
+    //   2, 7: free
+    int  tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool pool3_tuning() const { return pool3_kb != 16 || pool3_stage != 1 || pool3_wg != 0 || pool3_g != 0; }
 };
 const Settings& settings();
