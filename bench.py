@@ -212,6 +212,27 @@ def copy_ceiling(device):
     return out
 
 
+def rocprof_per_op():
+    """ms per step of the memory-bound launches from the committed rocprofv3 kernel statistics (profiles/r05_kernel_stats.csv: the one-stream bench command), keyed
+    like per_op: average duration x launches per pass.  {} when the file is not there."""
+    import csv
+    path = os.path.join(REPO, 'profiles', 'r05_kernel_stats.csv')
+    if not os.path.isfile(path):
+        return {}
+    families = {'MaxPool+LRN+1x1': ('maxpool3x3_lrn_conv1x1_kernel',), 'LRN+MaxPool': ('lrn_maxpool3x3_kernel',), 'MaxPool': ('maxpool3x3_cols_kernel', 'maxpool2d'),
+                'AvgPool': ('avgpool2d_lds_kernel',), 'SoftMax': ('softmax_rows_kernel',), 'Add': ('binary_channel_kernel',), 'MatMul': ('matmul_kernel', 'matmul_reduce_kernel')}
+    rows = list(csv.DictReader(open(path)))
+    passes = max([int(r['Calls']) for r in rows if 'conv_stem_f32_kernel' in r['Name']] or [0])
+    if passes == 0:
+        return {}
+    out = {}
+    for typ, names in families.items():
+        total = sum(float(r['TotalDurationNs']) for r in rows if any(nm in r['Name'] for nm in names))
+        if total > 0:
+            out[typ] = total / passes * 1e-6
+    return out
+
+
 def median_infer_rate(ex, feed, batch, reps, warm=3):
     from pyopenvino_amd import device
     for _ in range(warm):
@@ -860,6 +881,7 @@ def main():
                         'per_kernel_measured_on': 'the untimed per-layer pass (one hipEvent bracket per launch, one stream; Convolution total there {:.3f} ms '
                                                   'against {:.3f} ms with run brackets in the timed blocks)'.format(layer_pass_ms, conv['ms'])}
             breakdown = {}
+            rocprof_ms = rocprof_per_op()
             for typ, agg in sorted(by_type.items(), key=lambda kv: -kv[1]['ms']):
                 row = {'launches': agg['launches'], 'ms_per_step': round(agg['ms'], 4)}
                 if agg['flops'] > 0:
@@ -869,8 +891,16 @@ def main():
                 if agg['ms'] > 0:
                     row['GB/s'] = round(agg['bytes'] / (agg['ms'] * 1e-3) / 1e9, 1)
                     row['frac_hbm_peak'] = round(row['GB/s'] / PEAK_HBM_GBS, 4)
+                prof = rocprof_ms.get(typ)
+                if prof is not None:
+                    # the same launches' durations in the committed rocprofv3 kernel trace (no bracket around them: a bracket adds ~10 us per launch)
+                    row['ms_per_step_rocprofv3'] = round(prof, 4)
+                    if agg['bytes'] > 0:
+                        row['frac_hbm_peak_rocprofv3'] = round(agg['bytes'] / (prof * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
                 breakdown[typ] = row
             result['per_op'] = breakdown
+            if rocprof_ms:
+                result['per_op_rocprofv3_source'] = 'static: profiles/r05_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the one-stream bench command, scripts/profile_bench.sh; average duration x launches per step)'
             print('per-op breakdown (device time per step):', file=sys.stderr)
             for typ, row in breakdown.items():
                 print('  {:12s} {}'.format(typ, row), file=sys.stderr)
