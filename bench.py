@@ -394,6 +394,7 @@ def extra_configs(blob=None):
         # conv1 as Winograd F(3x3,4x4) on the space-to-depth image (opt-in, PVHIP_CONV_STEM_WINO=1): faster than the row-span kernel of the headline, at a
         # lower fraction of the MFMA peak on executed flops and not its bits.  A separate entry, one synchronous infer() at a time, both ways on this box.
         rates = {}
+        knob_before = os.environ.get('PVHIP_CONV_STEM_WINO')
         for knob in ('0', '1'):
             os.environ['PVHIP_CONV_STEM_WINO'] = knob
             device.reload_settings()
@@ -403,7 +404,10 @@ def extra_configs(blob=None):
             x = device.DeviceTensor.from_numpy(synth.uniform_pixels(1000, (BATCH_PER_GPU, 3, 224, 224)))
             rates[knob] = median_infer_rate(ex, {net.inputs[0]['name']: x}, BATCH_PER_GPU, 10)
             del ex, net, x
-        os.environ.pop('PVHIP_CONV_STEM_WINO', None)
+        if knob_before is None:
+            os.environ.pop('PVHIP_CONV_STEM_WINO', None)
+        else:
+            os.environ['PVHIP_CONV_STEM_WINO'] = knob_before
         device.reload_settings()
         out.append({'workload': 'models/googlenet-v1.xml fp32 batch 256 with conv1 as Winograd F(3x3,4x4) on the space-to-depth image (PVHIP_CONV_STEM_WINO=1, opt-in: '
                                 'not the headline); one synchronous infer() at a time',

@@ -988,7 +988,7 @@ int pvhip_lrn_maxpool_f32(const float* x, float* y, int n, int c, int h, int w, 
     a.abl = settings().conv_ablate;
 #endif
     // four pooled outputs per lane (pool4 in the kernel): PVHIP_TUNE6=1 keeps one per lane (A/B runs)
-    a.pool4 = (vec == 4 && sh == 2 && pad_top == 0 && pad_left == 0 && ow % 4 == 0 && (ow / 4) * a.band_rows <= kWave && settings().tune[6] != 1) ? 1 : 0;
+    a.pool4 = (vec == 4 && sh == 2 && pad_top == 0 && pad_left == 0 && ow % 4 == 0 && 2 * ow <= w && (ow / 4) * a.band_rows <= kWave && settings().tune[6] != 1) ? 1 : 0;      // (2 ow <= w: the eight columns a quad reads whole lie in the row; only the ninth is clamped)
     const dim3 grid((unsigned)(n * a.n_bands));
     const FastDiv d_bands = make_fastdiv((unsigned)a.n_bands), d_ow = make_fastdiv((unsigned)ow);
     const int ni = (a.band_rows * ow + kBlock - 1) / kBlock;          // 1 at stride 2 (a band holds <= 1024 input pixels), up to 4 at stride 1
