@@ -885,7 +885,7 @@ def main():
                         'per_kernel_measured_on': 'the untimed per-layer pass (one hipEvent bracket per launch, one stream; Convolution total there {:.3f} ms '
                                                   'against {:.3f} ms with run brackets in the timed blocks)'.format(layer_pass_ms, conv['ms'])}
             breakdown = {}
-            rocprof_ms = rocprof_per_op()
+            rocprof_ms = rocprof_per_op() if args.batch == BATCH_PER_GPU else {}          # (the committed trace is the batch-256 workload)
             for typ, agg in sorted(by_type.items(), key=lambda kv: -kv[1]['ms']):
                 row = {'launches': agg['launches'], 'ms_per_step': round(agg['ms'], 4)}
                 if agg['flops'] > 0:
