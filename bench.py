@@ -803,7 +803,8 @@ def main():
                 tf = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
                 tf_exec = conv['exec'] / (conv['ms'] * 1e-3) / 1e12
                 traffic, traffic_src, traffic_by_kernel = None, None, None
-                for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_traffic.json')), reverse=True):
+                # (the committed counters are those of the batch-256 workload: no static traffic beside another batch's algorithmic bytes)
+                for path in (sorted(glob.glob(os.path.join(REPO, 'profiles', '*_traffic.json')), reverse=True) if args.batch == BATCH_PER_GPU else []):
                     try:
                         doc = json.load(open(path))
                         k = doc['kernels']['convolution_kernels']
