@@ -151,15 +151,15 @@ __device__ unsigned long long g_pw_stamps[8];      // ABL = 8: cycles of every 6
 #else
 #define PW_NOW() 0ull
 #endif
-template <int TN, bool kVec, int ABL = 0>
-__global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
+template <int TN, bool kVec, int ABL = 0, int NB = 4>      // NB: LDS stage buffers (4: three stages of copies in flight, 32 KB; 3: two, 24 KB -- six workgroups per CU)
+__global__ __launch_bounds__(kBlock, NB == 3 ? 6 : 4) void conv_pw_kernel(PwArgs a) {
     const unsigned long long pw_t0 = PW_NOW();
 #ifdef PVHIP_DIAG
     const unsigned long long pw_r0 = (ABL == 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
     constexpr int BN = 128;
     constexpr int NP = kVec ? 2 : 8;                     // LDS-DMA instructions per wave and stage (1 KiB or 256 B each)
-    __shared__ __attribute__((aligned(1024))) float Bs[4][kBK][BN];
+    __shared__ __attribute__((aligned(1024))) float Bs[NB][kBK][BN];
 
     // XCD-aware tile order: the channel chunks of one pixel tile run back to back on one XCD (the chunks after the first
     // find the activation tile in that L2)
@@ -267,16 +267,16 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
         asm volatile("s_barrier" ::: "memory");                                                              \
         PW_LOAD_A(ld_, (s_) + 2);                                                                            \
         {                                                                                                    \
-            const int sd_ = (s_) + 3 < S ? (s_) + 3 : S - 1;                                                 \
-            PW_ISSUE(sd_, ((s_) + 3) & 3);                                                                   \
+            const int sd_ = (s_) + NB - 1 < S ? (s_) + NB - 1 : S - 1;                                       \
+            PW_ISSUE(sd_, ((s_) + NB - 1) % NB);                                                             \
         }                                                                                                    \
-        if (active && !(ABL & 4)) pw_mfma_stage<TN>(&Bs[(s_) & 3][lh][boff], ra[cur_], acc);   \
+        if (active && !(ABL & 4)) pw_mfma_stage<TN>(&Bs[(s_) % NB][lh][boff], ra[cur_], acc);  \
         PW_WAIT_A(nx_);                                                                                      \
         /* this wave's pieces of B(j+1) must be in LDS before the next barrier.  Younger than them are B(j+2) and B(j+3) -- and */ \
         /* the weight loads A(j+1), A(j+2), which are NOT counted: hipcc deletes the loads of the stages past the end, and a */ \
         /* count that relied on them would let two pieces of B(j+1) fly there.  Not counting them only waits for more.  (No  */ \
         /* register is involved: a hand-counted wait is safe here, and hipcc's own wait above has usually satisfied it.)     */ \
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NP) : "memory");                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NB - 2) * NP) : "memory");                                \
     }
 
     // prologue: A(0), A(1), B(0), B(1), B(2); A(0) and B(0) must have landed
@@ -284,9 +284,9 @@ __global__ __launch_bounds__(kBlock, 4) void conv_pw_kernel(PwArgs a) {
     PW_LOAD_A(1, 1);
     PW_ISSUE(0, 0);
     { const int s1 = 1 < S ? 1 : S - 1; PW_ISSUE(s1, 1); }
-    { const int s2 = 2 < S ? 2 : S - 1; PW_ISSUE(s2, 2); }
+    if (NB == 4) { const int s2 = 2 < S ? 2 : S - 1; PW_ISSUE(s2, 2); }
     PW_WAIT_A(0);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NP) : "memory");     // B(0) of this wave (B(1), B(2) may fly)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NB - 2) * NP) : "memory");     // B(0) of this wave (B(1), B(2) may fly)
     const unsigned long long pw_t1 = PW_NOW();
 
     // whole triples in the loop, the one or two stages left behind it: with `break`s inside the loop hipcc's structurizer gave the
@@ -376,6 +376,13 @@ void launch_pw(const PwArgs& a, bool vec, int grid) {
     }
     if (vec && settings().pw_ablate == 8) { hipLaunchKernelGGL((conv_pw_kernel<TN, true, 8>), dim3(grid), dim3(kBlock), 0, st, a); return; }   // s_memtime stamps
 #endif
+    // Three stage buffers (24 KB: six workgroups per CU instead of four, two stages of copies in flight instead of three), PVHIP_TUNE2=3 only.  MEASURED
+    // (scripts/time_pw.py, same box): alone, the 28x28 sibling launches gain 5 % (3a 0.148 -> 0.141 ms, 3b 0.281 -> 0.267), the 14x14 ones lose up to 8 %; with
+    // a rule that takes the former the step does not move (54.96 / 54.57 / 55.13 k images/s against 54.97 / 54.41 / 55.04): not the default.
+    if (vec && TN == 2 && settings().tune[2] == 3) {
+        hipLaunchKernelGGL((conv_pw_kernel<TN, true, 0, 3>), dim3(grid), dim3(kBlock), 0, st, a);
+        return;
+    }
     if (vec) hipLaunchKernelGGL((conv_pw_kernel<TN, true>), dim3(grid), dim3(kBlock), 0, st, a);
     else     hipLaunchKernelGGL((conv_pw_kernel<TN, false>), dim3(grid), dim3(kBlock), 0, st, a);
 }

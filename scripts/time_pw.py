@@ -38,6 +38,7 @@ def main():
     dev.init(0)
     n = args.batch
     variants = [('general', {'PVHIP_CONV_POINTWISE': '0'})] + [('pw tn ' + t, {'PVHIP_CONV_POINTWISE': '1', 'PVHIP_PW_TN': t}) for t in args.tiles.split(',')]
+    variants = variants + [('pw, three stage buffers', {'PVHIP_CONV_POINTWISE': '1', 'PVHIP_TUNE2': '3'})]
     variants += [('pw128 ablate ' + v, {'PVHIP_CONV_POINTWISE': '1', 'PVHIP_PW_STAGGER': '0', 'PVHIP_PW_ABLATE': v}) for v in args.ablate.split(',') if v]
     total = {v[0]: 0.0 for v in variants}
     for name, c, side, ks in SHAPES:
@@ -73,7 +74,7 @@ def main():
         stamp_note = ''
         for rnd in range(args.rounds):
             for vname, env in variants:
-                for kenv in ('PVHIP_CONV_POINTWISE', 'PVHIP_PW_STAGGER', 'PVHIP_PW_TN', 'PVHIP_PW_ABLATE'):
+                for kenv in ('PVHIP_CONV_POINTWISE', 'PVHIP_PW_STAGGER', 'PVHIP_PW_TN', 'PVHIP_PW_ABLATE', 'PVHIP_TUNE2'):
                     os.environ.pop(kenv, None)
                 os.environ.update(env)
                 dev.reload_settings()
