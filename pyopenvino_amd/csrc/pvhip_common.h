@@ -34,7 +34,7 @@ struct Settings {
     bool conv_pointwise = true;  // PVHIP_CONV_POINTWISE=0: 1x1 layers on the general LDS-DMA kernel
     bool conv_stem      = true;  // PVHIP_CONV_STEM=0: a 7x7 / 2 first convolution over three channels on the general LDS-DMA kernel, not from row spans (pvhip_stem.hip)
     bool conv_stem_wino = false; // PVHIP_CONV_STEM_WINO=1: that layer as Winograd F(3x3,4x4) on the space-to-depth image (0.34 of the multiplies, 0.50 ms against 0.56: faster, but not the bits of the general kernel and 0.26 of the MFMA peak on executed flops -- measured, opt-in)
-    int  poolconv_prio  = 0;     // PVHIP_POOLCONV_PRIO=1|2: wave priority 3 for the producers | consumers of conv_pool1x1_kernel (A/B runs: +11..14 % | +-1 %, off)
+    int  poolconv_prio  = -1;    // PVHIP_POOLCONV_PRIO=0|1|2: no wave priority | priority 3 for the producers | for the consumers of conv_pool1x1_kernel; unset: the producers where they keep two stages of loads in flight (groups of two pixels: 4a .. 4e -7..-8 %; with one stage it cost 11-14 %, on the 28x28 modules it still costs 5-15 %)
     int  fuse_poolconv  = 2;     // PVHIP_FUSE_POOLCONV: 0 off, 1 any width (odd widths: 65-128 output channels, single-pixel groups -- measured slower than the two launches on the 7x7 modules: 0.089 against 0.064 ms), 2 (default) rows of whole 16- or 8-byte groups, 4 only 16-byte groups (A/B runs)
     bool pool3          = true;  // PVHIP_POOL3=0: the one-shot MaxPool kernel for 3x3 windows too
     int  stream_nt      = 1;     // PVHIP_STREAM_NT: nontemporal loads / stores in the streaming kernels: 0 never, 1 from 64 MiB moved on, 2 always

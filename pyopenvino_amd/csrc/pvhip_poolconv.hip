@@ -360,7 +360,7 @@ static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int 
     a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
     a.abl = 0;
-    a.prio = settings().poolconv_prio;
+    a.prio = settings().poolconv_prio >= 0 ? settings().poolconv_prio : ((w % 2 == 0 && w % 4 != 0) ? 1 : 0);      // (see pvhip_common.h)
 #ifdef PVHIP_DIAG
     a.abl = settings().conv_ablate;
 #endif

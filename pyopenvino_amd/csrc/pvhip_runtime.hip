@@ -81,7 +81,7 @@ void load_settings() {
     s.wino_shared_lag = num("PVHIP_WINO_SHARED_LAG", 0);
     s.wino_shared_prio = num("PVHIP_WINO_SHARED_PRIO", 1);
     s.wino_shared_odd = num("PVHIP_WINO_SHARED_ODD", 1) != 0;
-    s.poolconv_prio = num("PVHIP_POOLCONV_PRIO", 0);
+    s.poolconv_prio = num("PVHIP_POOLCONV_PRIO", -1);
     s.wino_shared_old = num("PVHIP_WINO_SHARED_OLD", 1);
 #ifdef PVHIP_DIAG
     // the predecessor convolution kernels and their tile overrides exist in the diagnostic build only
