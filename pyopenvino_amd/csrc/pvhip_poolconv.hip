@@ -24,6 +24,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kBK = 16;
+constexpr int kRingDepth1 = 2;          // ... for single pixels (odd rows: the 7x7 modules, only with PVHIP_FUSE_POOLCONV=1: 0.080 ms against 0.067 for the two launches; 0.089 with one stage)
 constexpr int kRingDepth4 = 1;          // ... for groups of four pixels (the 28x28 modules: two stages need 73 registers -- fewer waves per SIMD -- and measured 6-12 % SLOWER)
 constexpr int kRingDepth2 = 2;          // stages of producer loads in flight for groups of two pixels (the 14x14 modules).  Three (168 registers, two workgroups per CU): 0.064 ms on 4a against 0.055 with two -- the waves a CU holds matter as much as the loads in flight
 
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NW * 128, (BM <= 64 && VEC == 1) || (BM <= 64 && VE
         // TWO stages of loads in flight (round 5): with one, a stage lasted as long as its loads took to arrive -- s_memtime stamps on 4a: 3.0 k cycles
         // per stage, the consumers 1.3 k of them in their MFMAs and 1.6 k at the barrier waiting for the producers, who were waiting for memory
         // (groups of two pixels only -- the 14x14 modules, few tiles per CU: 128 registers there; the 28x28 modules keep one stage and 64 registers: eight waves per SIMD)
-        constexpr int RD = kWide ? kRingDepth2 : (VEC == 4 ? kRingDepth4 : 1);
+        constexpr int RD = kWide ? kRingDepth2 : (VEC == 4 ? kRingDepth4 : kRingDepth1);
         ring_t ring[RD][ITER][3];            // per slot (stage % RD), iteration and row: the group (kWide: with the columns around it)
         float edge[RD][ITER][3];             //                                          first / last lane: its outer column
 #define PVP_LOAD(it_, s_, sl_)                                                                                   \
@@ -360,7 +361,7 @@ static int conv2d_pooled_impl(const float* x, const float* wpack, float* y, int 
     a.y_ctotal = out_channels_total > 0 ? out_channels_total : k_out;
     a.y_coff   = out_channels_total > 0 ? out_channel_offset : 0;
     a.abl = 0;
-    a.prio = settings().poolconv_prio >= 0 ? settings().poolconv_prio : ((w % 2 == 0 && w % 4 != 0) ? 1 : 0);      // (see pvhip_common.h)
+    a.prio = settings().poolconv_prio >= 0 ? settings().poolconv_prio : ((w % 4 != 0) ? 1 : 0);      // (see pvhip_common.h)
 #ifdef PVHIP_DIAG
     a.abl = settings().conv_ablate;
 #endif
