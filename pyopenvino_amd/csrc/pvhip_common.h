@@ -76,7 +76,7 @@ struct Settings {
     //   0: 32 | 64 = narrower channel tiles of MaxPool + pool_proj          1: 2 = its pixel tiles of 64 instead of 128 (1 = never)
     //   3: shared-V Winograd tile order, 1 = channel-pair-major always, 2 = never     4: 1 = conv1's stores as 16 x 64-byte pieces (not whole rows through LDS)
     //   5: 1 = ragged Winograd patches store 8-byte / 4-byte pieces           6: 1 = LRN + MaxPool pools one output per lane (not four)
-    //   2: 3 = the pointwise kernel with three stage buffers (six workgroups per CU; measured neutral in the step)      7: free
+    //   2: 3 = the pointwise kernel with three stage buffers (six workgroups per CU; measured neutral in the step)      7: 1 = conv_wino4_kernel's producer waves at priority 0 (not 3)
     int  tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool pool3_tuning() const { return pool3_kb != 16 || pool3_stage != 1 || pool3_wg != 0 || pool3_g != 0; }
 };

@@ -49,6 +49,7 @@ struct WinoArgs {
     int   s_old;            // conv_wino4s_kernel: producers are waves 0-3 (the oldest) rather than 12-15
     int   s_lag;            // conv_wino4s_kernel: the second consumer group starts kSLag stages behind the first (PVHIP_WINO_SHARED_LAG=0: together)
     int   s_wide;           // conv_wino4s_kernel, ragged extents: whole patches store a row as ONE 16-byte piece (8-byte aligned on 14-wide rows) instead of two 8-byte ones
+    int   p_prio;           // conv_wino4_kernel: its two producer waves at wave priority 3
     int   s_order;          // conv_wino4s_kernel: 1 = tiles in channel-pair-major order (a workgroup, and with it an XCD, stays on ONE pair's slice of the transformed weights
                             // across patch blocks); 0 = patch-block-major (the pairs of a patch block follow each other: its patches come out of L2)
     // conv_wino4_kernel: patch index -> (image, patch row, patch column) by multiply-high and shift (w4_magic): the divisors are
@@ -807,6 +808,10 @@ __global__ __launch_bounds__(512, 4) void conv_wino4_kernel(WinoArgs a) {
     (void)t_epi; (void)t_head;
     if (producer) {
         // ------------------------------------------------------------------ producers
+        // round 5: the two producer waves at priority 3 -- their transform is the long pole of a stage and the arbiter prefers the (older) consumers'
+        // MFMA streams (lesson 45).  Same box, alternating: the nine 5x5 layers -1 .. -4 % (sum with 3a/3x3 0.612 -> 0.599 ms), same bits; choosing them
+        // among the four OLDEST waves on top of it: another -0.4 %, not kept.  PVHIP_TUNE7=1: priority 0 (scripts/time_wino4_prio.py).
+        if (a.p_prio != 0) __builtin_amdgcn_s_setprio(3);
         const int g_chan = pidx * 2 + lh;                             // channel inside the stage
         // Lane <-> (patch, channel of the stage).  Columns 1..4 of a patch row are ONE aligned 16-byte load (extents are
         // multiples of 4; consecutive lanes = consecutive patches = consecutive 16-byte pieces: fully coalesced).  Column 0 is
@@ -1724,7 +1729,7 @@ int wino_conv(const float* x, const float* u, float* y, int n, int c, int h, int
     a.u_bytes = (unsigned)(wino_pack_elems(k_out, c) * 4);
     a.act = act; a.act_lo = act_lo; a.act_hi = act_hi;
     a.y_ctotal = out_channels_total; a.y_coff = out_channel_offset;
-    a.balance = 0; a.n_tiles = 0; a.s_lag = 0; a.s_prio = 0; a.s_old = 0; a.s_order = 0; a.s_wide = 0;
+    a.balance = 0; a.n_tiles = 0; a.s_lag = 0; a.s_prio = 0; a.s_old = 0; a.s_order = 0; a.s_wide = 0; a.p_prio = 0;
     a.tpi_mul = a.tpi_sh = a.tx_mul = a.tx_sh = 0u;
 #ifdef PVHIP_DIAG
     if (settings().wino4_ablate == 5) a.balance = 5;          // diagnostic build: s_memtime stamps (scripts/stamps_wino.py)
@@ -1807,6 +1812,7 @@ int wino4_conv(int m, const float* x, const float* u, float* y, int n, int c, in
     a.s_lag = settings().wino_shared_lag;
     a.s_prio = settings().wino_shared_prio;
     a.s_old = settings().wino_shared_old;
+    a.p_prio = settings().tune[7] == 1 ? 0 : 1;        // PVHIP_TUNE7=1: no priority for conv_wino4_kernel's producers (A/B runs)
     a.s_wide = settings().tune[5] == 1 ? 0 : 1;       // (PVHIP_TUNE5=1: the old pieces.  Same box, alternating: the 7x7 layers -3 % -- their odd rows stored single floats --, the 14x14 layers +-0.5 %)
     // Tile order of the shared-V form.  MEASURED (scripts/traffic_wino_order.sh, FETCH_SIZE per launch; scripts/time_wino_order.py): channel-pair-major reads
     // 58.5 / 79.8 MB instead of 68.9 / 96.8 on the 7x7 layers 5a / 5b (their transformed weights, 7.4 / 10.6 MB, are the LARGER operand and do not fit an
