@@ -35,6 +35,10 @@ int pvhip_diag_pw_stamps(unsigned long long* out);
 
 /* scripts/stamps_wino4.py (PVHIP_WINO4_ABLATE=5): where the waves of conv_wino4_kernel ran (64 x 8 x 2 words of HW_ID / LDS_ALLOC; the
  * ticket counter is reset), and its s_memtime stamps (64 counters; cleared).                                                        */
+/* scripts/stamps_poolconv.py (PVHIP_CONV_ABLATE=64): s_memtime accounts of conv_pool1x1_kernel, workgroup 77, summed over its stages: out[0] stages, [1] producer
+ * pooling (incl. waiting for its loads), [2] producer barrier, [3] producer loop, [4] consumer MFMA section, [5] its wait for the weight copy, [6] consumer barrier,
+ * [7] consumer loop (cycles).                                                                                                            */
+int pvhip_diag_poolconv_stamps(unsigned long long* out);
 int pvhip_diag_wino4_hw(unsigned* out);
 int pvhip_diag_wino4_stamps(unsigned long long* out);
 int pvhip_diag_wino4s_stamps(unsigned long long* out);

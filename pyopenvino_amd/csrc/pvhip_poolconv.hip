@@ -41,7 +41,7 @@ struct PoolConvArgs {
     float act_lo, act_hi;
     int y_ctotal, y_coff;
     int prio;             // producers at wave priority 3 (PVHIP_POOLCONV_PRIO=0: everything at 0)
-    int abl;              // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no activation loads, 2 no pooling arithmetic, 4 no MFMAs, 8 no weight copies, 16 no stores, 32 no loads of the outer columns
+    int abl;              // diagnostic build (PVHIP_CONV_ABLATE bits, wrong results): 1 no activation loads, 2 no pooling arithmetic, 4 no MFMAs, 8 no weight copies, 16 no stores, 32 no loads of the outer columns, 64 s_memtime stamps (pvhip_diag_poolconv_stamps)
 };
 
 __device__ __forceinline__ void pc_dma_b128(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff, unsigned soff) {
@@ -70,6 +70,15 @@ __device__ __forceinline__ void pc_load(pc_f1& d, __amdgpu_buffer_rsrc_t r, unsi
 // fp16 as they are read from LDS (the maximum of the window is taken in fp32, then rounded: what MaxPool followed by pvhip_conv2d_f16_dma does)
 // NW (round 5): consumer waves = producer waves = pixels of the tile / 32; NW = 2 (tiles of 64 pixels, twice the workgroups, the same work per wave)
 // is an experiment that did not pay -- see conv2d_pooled_impl.
+#ifdef PVHIP_DIAG
+// diagnostic build, PVHIP_CONV_ABLATE bit 64 (scripts/stamps_poolconv.py): s_memtime accounts of workgroup 77's first consumer and first producer wave, summed over the
+// stages: [0] stages, [1] producer pooling (incl. waiting for its loads), [2] producer barrier, [3] producer loop, [4] consumer MFMA section, [5] its wait for the
+// weight copy, [6] consumer barrier, [7] consumer loop
+__device__ unsigned long long g_pc_stamps[8];
+#define PC_NOW() ((abl & 64) ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#else
+#define PC_NOW() 0ull
+#endif
 template <int BM, int VEC, bool kF16 = false, int NW = 4>
 __global__ __launch_bounds__(NW * 128, (BM <= 64 && VEC == 1) || (BM <= 64 && VEC == 4 && kRingDepth4 == 1) ? 8 : (VEC == 2 && kRingDepth2 > 2 ? 2 : 4)) void conv_pool1x1_kernel(PoolConvArgs a) {      // 64 channels: 73 -> 64 registers, four workgroups per CU (3b: -3 %)
     constexpr int BN = 32 * NW, TM = BM / 32, KK = kBK / 2;
@@ -210,17 +219,28 @@ __global__ __launch_bounds__(NW * 128, (BM <= 64 && VEC == 1) || (BM <= 64 && VE
 #pragma unroll
         for (int it = 0; it < ITER; ++it) PVP_POOL(it, 0, RD, 0);              // B(0) from slot 0, which then fetches stage RD
         __syncthreads();
+        unsigned long long tp_pool = 0ull, tp_bar = 0ull;
+        const unsigned long long tp_begin = PC_NOW();
         for (int s = 0; s < nk; s += RD) {                                     // stage q sits in slot q % RD and goes into B tile q & 1
 #pragma unroll
             for (int d = 0; d < RD; ++d) {
                 if (s + d < nk) {
                     const int bn = (s + d + 1) & 1;
+                    const unsigned long long t0_ = PC_NOW();
 #pragma unroll
                     for (int it = 0; it < ITER; ++it) PVP_POOL(it, bn, s + d + 1 + RD, (d + 1) % RD);     // B(s+d+1); past the end: an unused tile
+                    const unsigned long long t1_ = PC_NOW();
                     __syncthreads();
+                    tp_pool += t1_ - t0_; tp_bar += PC_NOW() - t1_;
                 }
             }
         }
+#ifdef PVHIP_DIAG
+        if ((abl & 64) && blockIdx.x == 77 && wid == CONSUMERS && lane == 0) {
+            g_pc_stamps[0] = (unsigned long long)nk; g_pc_stamps[1] = tp_pool; g_pc_stamps[2] = tp_bar; g_pc_stamps[3] = PC_NOW() - tp_begin;
+        }
+#endif
+        (void)tp_pool; (void)tp_bar; (void)tp_begin;
 #undef PVP_LOAD
 #undef PVP_POOL
     } else {
@@ -246,8 +266,11 @@ __global__ __launch_bounds__(NW * 128, (BM <= 64 && VEC == 1) || (BM <= 64 && VE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int b_col = wid * 32 + l31;
+        unsigned long long tc_mfma = 0ull, tc_vm = 0ull, tc_bar = 0ull;
+        const unsigned long long tc_begin = PC_NOW();
         for (int s = 0; s < nk; ++s) {
             const int buf = s & 1;
+            const unsigned long long t0_ = PC_NOW();
             PVP_LOAD_A(s + 1, buf ^ 1);          // past the end: the spare zero stages of the panel
             __builtin_amdgcn_sched_barrier(0);
             if (kF16) {
@@ -285,9 +308,18 @@ __global__ __launch_bounds__(NW * 128, (BM <= 64 && VEC == 1) || (BM <= 64 && VE
                 __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t1_ = PC_NOW();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t2_ = PC_NOW();
             __syncthreads();
+            tc_mfma += t1_ - t0_; tc_vm += t2_ - t1_; tc_bar += PC_NOW() - t2_;
         }
+#ifdef PVHIP_DIAG
+        if ((abl & 64) && blockIdx.x == 77 && wid == 0 && lane == 0) {
+            g_pc_stamps[4] = tc_mfma; g_pc_stamps[5] = tc_vm; g_pc_stamps[6] = tc_bar; g_pc_stamps[7] = PC_NOW() - tc_begin;
+        }
+#endif
+        (void)tc_mfma; (void)tc_vm; (void)tc_bar; (void)tc_begin;
 #undef PVP_LOAD_A
 
         // epilogue (consumers only): bias, activation, NCHW stores -- 128-byte runs of consecutive pixels
@@ -336,6 +368,15 @@ bool pooled_supported(int n, int c, int h, int w, int k_out) {
 }  // namespace
 
 extern "C" {
+
+#ifdef PVHIP_DIAG
+// diagnostic build only: the cycle accounts of conv_pool1x1_kernel (PVHIP_CONV_ABLATE bit 64); out = 8 counters
+int pvhip_diag_poolconv_stamps(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return PVHIP_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pc_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return PVHIP_EHIP;
+    return PVHIP_OK;
+}
+#endif
 
 int pvhip_conv2d_pooled_supported(int n, int c, int h, int w, int k_out) { return pooled_supported(n, c, h, w, k_out) ? 1 : 0; }
 
